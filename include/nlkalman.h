@@ -1,0 +1,67 @@
+/* nlkalman.h — drop-in C API of the per-frame non-local Kalman hot path.
+ *
+ * This header mirrors, symbol for symbol and argument for argument, the public
+ * interface of the reference (reference: src/nlkalman.h:14-53, built with its
+ * K_SIMILAR_PATCHES / WEIGHTED_AGGREGATION switches on, src/nlkalman.h:8,11).
+ * A program written against the reference header links against libnlkalman.so
+ * of this repo unchanged; the work is done by the HIP kernels behind the C-ABI
+ * declared in nlk_hip.h.
+ *
+ * Images are HWC interleaved float32, index (x + y*w)*ch + c (reference:
+ * src/nlkalman.c:555-560). The caller owns every buffer. `deno0`/`smoo0` and
+ * `bsic1` may be NULL. Outputs are fully overwritten. `frame` is unused.
+ * The functions return void; fatal conditions (no GPU, unsupported patch size,
+ * HIP error) print a message on stderr and exit(1), like the reference's own
+ * fatal paths (reference: src/nlkalman.c:165-177).
+ */
+#ifndef NLKALMAN_H
+#define NLKALMAN_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* reference: src/nlkalman.h:14-15 — orthonormal RGB<->opponent transform,
+ * in place, no-op unless ch == 3 */
+void rgb2opp(float *im, int w, int h, int ch);
+void opp2rgb(float *im, int w, int h, int ch);
+
+/* reference: src/nlkalman.h:18-19 — bicubic backward warp of `im` by the flow
+ * `of` (HW2) with NaN marking of occluded (`msk != 0`) and out-of-image taps */
+void warp_bicubic(float *imw, float *im, float *of, float *msk, int w, int h,
+                  int ch);
+
+/* reference: src/nlkalman.h:22-37 (K_SIMILAR_PATCHES layout): 6 int + 3 float */
+struct nlkalman_params {
+  int patch_sz;       /* patch size */
+  int search_sz_x;    /* search window radius, spatial filtering */
+  int search_sz_t;    /* search window radius, temporal filtering */
+  int npatches_x;     /* similar patches, spatial filtering */
+  int npatches_t;     /* similar patches, temporal filtering */
+  int npatches_tagg;  /* patches of the group that are filtered + aggregated */
+  float dista_lambda; /* unused by the compiled reference (LAMBDA_DISTANCE off) */
+  float beta_x;       /* noise multiplier, spatial (Wiener) branch */
+  float beta_t;       /* noise multiplier, temporal (Kalman) branch */
+};
+
+/* reference: src/nlkalman.h:40 */
+enum FILTER_MODE { FLT1, FLT2, SMO1 };
+
+/* reference: src/nlkalman.h:42-43 — fills every field that is < 0 */
+void nlkalman_default_params(struct nlkalman_params *p, float sigma,
+                             enum FILTER_MODE mode);
+
+/* reference: src/nlkalman.h:46-48 */
+void nlkalman_filter_frame(float *deno1, float *nisy1, float *deno0,
+                           float *bsic1, int w, int h, int ch, float sigma,
+                           const struct nlkalman_params prms, int frame);
+
+/* reference: src/nlkalman.h:51-53 */
+void nlkalman_smooth_frame(float *smoo1, float *filt1, float *smoo0,
+                           float *bsic1, int w, int h, int ch, float sigma,
+                           const struct nlkalman_params prms, int frame);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NLKALMAN_H */

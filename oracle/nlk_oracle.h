@@ -1,0 +1,43 @@
+/* nlk_oracle.h — interface of the CPU oracle (TEST INFRASTRUCTURE ONLY; see the
+ * header of nlk_oracle.c: parity unpinned). */
+#ifndef NLK_ORACLE_H
+#define NLK_ORACLE_H
+#include <stdint.h>
+
+enum { NLKO_FLT1 = 0, NLKO_FLT2 = 1, NLKO_SMO1 = 2 };
+
+/* same field order as struct nlkalman_params (reference: src/nlkalman.h:22-37) */
+typedef struct {
+  int patch_sz, search_sz_x, search_sz_t, npatches_x, npatches_t, npatches_tagg;
+  float dista_lambda, beta_x, beta_t;
+} nlko_params;
+
+/* optional per-target trace, indexed by grid index gx + gy*ngx; every pointer
+ * may be NULL. Coordinates are packed as x | y << 16, -1 = unused entry. */
+typedef struct {
+  int kmax;      /* row length of topk */
+  int gmax;      /* row length of gcoords */
+  int *topk;     /* [ngrid][kmax] kept candidates in sorted order */
+  int *gcoords;  /* [ngrid][gmax] aggregated group members */
+  int *nsel, *np0, *np1, *nagg, *active;
+  float *vp;
+  float *aggr;   /* [w*h] aggregation weights before normalisation */
+} nlko_trace;
+
+void nlko_default_params(nlko_params *p, float sigma, int mode);
+void nlko_window(float *W, int psz);
+void nlko_rgb2opp(float *im, int w, int h, int ch);
+void nlko_opp2rgb(float *im, int w, int h, int ch);
+void nlko_warp_bicubic(float *imw, const float *im, const float *of,
+                       const float *msk, int w, int h, int ch);
+void nlko_awgn(float *x, long n, float sigma, uint32_t seed);
+void nlko_dct_basis(float *C, int n);
+void nlko_dct2(float *planes, int n, int nplanes, int inverse);
+void nlko_filter_frame(float *deno1, const float *nisy1, const float *deno0,
+                       const float *bsic1, int w, int h, int ch, float sigma,
+                       const nlko_params *P, int nthreads, nlko_trace *tr);
+void nlko_smooth_frame(float *smoo1, const float *filt1, const float *smoo0,
+                       const float *bsic1, int w, int h, int ch, float sigma,
+                       const nlko_params *P, int nthreads, nlko_trace *tr);
+int nlko_max_threads(void);
+#endif

@@ -1,0 +1,188 @@
+"""ctypes bindings of the CPU oracle (oracle/nlk_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg. The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+FLT1, FLT2, SMO1 = 0, 1, 2
+
+
+class Params(C.Structure):
+    # reference: src/nlkalman.h:22-37 (K_SIMILAR_PATCHES layout)
+    _fields_ = [("patch_sz", C.c_int), ("search_sz_x", C.c_int),
+                ("search_sz_t", C.c_int), ("npatches_x", C.c_int),
+                ("npatches_t", C.c_int), ("npatches_tagg", C.c_int),
+                ("dista_lambda", C.c_float), ("beta_x", C.c_float),
+                ("beta_t", C.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class Trace(C.Structure):
+    _fields_ = [("kmax", C.c_int), ("gmax", C.c_int),
+                ("topk", C.POINTER(C.c_int)), ("gcoords", C.POINTER(C.c_int)),
+                ("nsel", C.POINTER(C.c_int)), ("np0", C.POINTER(C.c_int)),
+                ("np1", C.POINTER(C.c_int)), ("nagg", C.POINTER(C.c_int)),
+                ("active", C.POINTER(C.c_int)), ("vp", C.POINTER(C.c_float)),
+                ("aggr", C.POINTER(C.c_float))]
+
+
+def build():
+    """Compile oracle/libnlk_oracle.so if missing or stale."""
+    so = os.path.join(_HERE, "libnlk_oracle.so")
+    src = [os.path.join(_HERE, f) for f in ("nlk_oracle.c", "nlk_oracle.h")]
+    if (not os.path.exists(so)
+            or os.path.getmtime(so) < max(os.path.getmtime(s) for s in src)):
+        subprocess.check_call(["make", "-C", _HERE, "libnlk_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        fp = C.POINTER(C.c_float)
+        L.nlko_default_params.argtypes = [C.POINTER(Params), C.c_float, C.c_int]
+        L.nlko_window.argtypes = [fp, C.c_int]
+        for f in (L.nlko_rgb2opp, L.nlko_opp2rgb):
+            f.argtypes = [fp, C.c_int, C.c_int, C.c_int]
+        L.nlko_warp_bicubic.argtypes = [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int]
+        L.nlko_awgn.argtypes = [fp, C.c_long, C.c_float, C.c_uint32]
+        L.nlko_dct_basis.argtypes = [fp, C.c_int]
+        L.nlko_dct2.argtypes = [fp, C.c_int, C.c_int, C.c_int]
+        for f in (L.nlko_filter_frame, L.nlko_smooth_frame):
+            f.argtypes = [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float,
+                          C.POINTER(Params), C.c_int, C.POINTER(Trace)]
+        L.nlko_max_threads.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _img(a):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    return a
+
+
+def default_params(sigma, mode, **over):
+    p = Params(-1, -1, -1, -1, -1, -1, -1.0, -1.0, -1.0)
+    for k, v in over.items():
+        setattr(p, k, v)
+    lib().nlko_default_params(C.byref(p), float(sigma), int(mode))
+    return p
+
+
+def window(psz):
+    W = np.zeros((psz, psz), np.float32)
+    lib().nlko_window(_fp(W), psz)
+    return W
+
+
+def rgb2opp(im):
+    a = _img(im).copy()
+    lib().nlko_rgb2opp(_fp(a), a.shape[1], a.shape[0], a.shape[2])
+    return a
+
+
+def opp2rgb(im):
+    a = _img(im).copy()
+    lib().nlko_opp2rgb(_fp(a), a.shape[1], a.shape[0], a.shape[2])
+    return a
+
+
+def warp_bicubic(im, flow, occ=None):
+    im = _img(im)
+    h, w, ch = im.shape
+    flow = np.ascontiguousarray(flow, np.float32)
+    occ = None if occ is None else np.ascontiguousarray(occ, np.float32)
+    out = np.empty_like(im)
+    lib().nlko_warp_bicubic(_fp(out), _fp(im), _fp(flow), _fp(occ), w, h, ch)
+    return out
+
+
+def awgn(im, sigma, seed):
+    a = np.ascontiguousarray(im, np.float32).copy()
+    lib().nlko_awgn(_fp(a), a.size, float(sigma), int(seed))
+    return a
+
+
+def dct_basis(n):
+    Cm = np.zeros((n, n), np.float32)
+    lib().nlko_dct_basis(_fp(Cm), n)
+    return Cm
+
+
+def dct2(planes, inverse=False):
+    a = np.ascontiguousarray(planes, np.float32).copy()
+    n = a.shape[-1]
+    assert a.shape[-2] == n
+    lib().nlko_dct2(_fp(a), n, a.size // (n * n), int(inverse))
+    return a
+
+
+def grid_shape(w, h, psz):
+    step = psz // 2
+    return (w - psz) // step + 1, (h - psz) // step + 1
+
+
+def _run(fn, cur, prev, basic, sigma, params, nthreads, trace):
+    cur, prev, basic = _img(cur), _img(prev), _img(basic)
+    h, w, ch = cur.shape
+    out = np.empty_like(cur)
+    tr = None
+    res = {}
+    if trace:
+        ngx, ngy = grid_shape(w, h, params.patch_sz)
+        ng = ngx * ngy
+        kmax = max(params.npatches_x, params.npatches_t, 1)
+        gmax = max(params.npatches_tagg, 1)
+        res = dict(
+            topk=np.full((ng, kmax), -1, np.int32),
+            gcoords=np.full((ng, gmax), -1, np.int32),
+            nsel=np.zeros(ng, np.int32), np0=np.zeros(ng, np.int32),
+            np1=np.zeros(ng, np.int32), nagg=np.zeros(ng, np.int32),
+            active=np.zeros(ng, np.int32), vp=np.zeros(ng, np.float32),
+            aggr=np.zeros((h, w), np.float32))
+        tr = Trace(kmax, gmax, _ip(res["topk"]), _ip(res["gcoords"]),
+                   _ip(res["nsel"]), _ip(res["np0"]), _ip(res["np1"]),
+                   _ip(res["nagg"]), _ip(res["active"]), _fp(res["vp"]),
+                   _fp(res["aggr"]))
+        res["grid"] = (ngx, ngy)
+    fn(_fp(out), _fp(cur), _fp(prev), _fp(basic), w, h, ch, float(sigma),
+       C.byref(params), int(nthreads), None if tr is None else C.byref(tr))
+    return (out, res) if trace else out
+
+
+def filter_frame(nisy1, deno0, bsic1, sigma, params, nthreads=1, trace=False):
+    return _run(lib().nlko_filter_frame, nisy1, deno0, bsic1, sigma, params,
+                nthreads, trace)
+
+
+def smooth_frame(filt1, smoo0, bsic1, sigma, params, nthreads=1, trace=False):
+    return _run(lib().nlko_smooth_frame, filt1, smoo0, bsic1, sigma, params,
+                nthreads, trace)
+
+
+def max_threads():
+    return lib().nlko_max_threads()
