@@ -1,0 +1,297 @@
+"""bwd-nlkalman_amd — MI355X-native NL-Kalman per-frame hot path.
+
+Python is only a thin ctypes mirror of the two C interfaces of the product:
+
+* ``libnlkalman.so``  — the drop-in C API of include/nlkalman.h (same symbols as
+  the reference's src/nlkalman.h:14-53), host pointers in / out;
+* ``libnlk_hip.so``   — the C-ABI of include/nlk_hip.h over the HIP kernels,
+  device pointers in / out (used by bench.py and the multi-GPU driver).
+
+There is no CPU fallback here: every function that touches pixels needs the
+HIP library and a GPU, and raises loudly otherwise.  (The directory name holds
+a hyphen: import it with ``importlib.import_module("bwd-nlkalman_amd")``.)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+FLT1, FLT2, SMO1 = 0, 1, 2
+
+HIP_SYMBOLS = [
+    "nlk_device_count", "nlk_ctx_create", "nlk_ctx_destroy", "nlk_last_error",
+    "nlk_ctx_set_profiling", "nlk_ctx_get_timings", "nlk_ctx_set_stream",
+    "nlk_ctx_get_stream", "nlk_dev_alloc", "nlk_dev_free", "nlk_h2d", "nlk_d2h",
+    "nlk_d2d", "nlk_sync", "nlk_dev_rgb2opp", "nlk_dev_opp2rgb",
+    "nlk_dev_warp_bicubic", "nlk_dev_filter_frame", "nlk_dev_smooth_frame",
+    "nlk_dev_frame_accumulate", "nlk_dev_frame_normalize", "nlk_ctx_read_records",
+]
+API_SYMBOLS = [
+    "rgb2opp", "opp2rgb", "warp_bicubic", "nlkalman_default_params",
+    "nlkalman_filter_frame", "nlkalman_smooth_frame",
+]
+
+
+class Params(C.Structure):
+    """struct nlkalman_params (reference: src/nlkalman.h:22-37)."""
+    _fields_ = [("patch_sz", C.c_int), ("search_sz_x", C.c_int),
+                ("search_sz_t", C.c_int), ("npatches_x", C.c_int),
+                ("npatches_t", C.c_int), ("npatches_tagg", C.c_int),
+                ("dista_lambda", C.c_float), ("beta_x", C.c_float),
+                ("beta_t", C.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class Timings(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("layout_ms", "match_ms", "commit_ms",
+                                          "group_ms", "normalize_ms", "total_ms")]
+
+
+def build(force=False):
+    """Compile the in-tree libraries with hipcc/gcc (gfx950). No GPU needed."""
+    args = ["make", "-C", _HERE, "all"]
+    if force:
+        args.insert(1, "-B")
+    subprocess.check_call(args)
+
+
+def _load(name):
+    path = os.path.join(_HERE, name)
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{name} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the HIP path is mandatory, there is no CPU fallback)")
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+_hip = None
+_api = None
+
+
+def hip():
+    """libnlk_hip.so with argtypes set."""
+    global _hip
+    if _hip is None:
+        L = _load("libnlk_hip.so")
+        vp, fp, i, f = C.c_void_p, C.c_void_p, C.c_int, C.c_float
+        L.nlk_device_count.restype = i
+        L.nlk_ctx_create.argtypes = [C.POINTER(vp), i]
+        L.nlk_ctx_destroy.argtypes = [vp]
+        L.nlk_ctx_destroy.restype = None
+        L.nlk_last_error.argtypes = [vp]
+        L.nlk_last_error.restype = C.c_char_p
+        L.nlk_ctx_set_profiling.argtypes = [vp, i]
+        L.nlk_ctx_get_timings.argtypes = [vp, C.POINTER(Timings)]
+        L.nlk_ctx_set_stream.argtypes = [vp, vp]
+        L.nlk_ctx_get_stream.argtypes = [vp]
+        L.nlk_ctx_get_stream.restype = vp
+        L.nlk_dev_alloc.argtypes = [vp, C.POINTER(vp), C.c_size_t]
+        L.nlk_dev_free.argtypes = [vp, vp]
+        for fn in (L.nlk_h2d, L.nlk_d2h, L.nlk_d2d):
+            fn.argtypes = [vp, vp, vp, C.c_size_t]
+        L.nlk_sync.argtypes = [vp]
+        for fn in (L.nlk_dev_rgb2opp, L.nlk_dev_opp2rgb):
+            fn.argtypes = [vp, fp, i, i, i]
+        L.nlk_dev_warp_bicubic.argtypes = [vp, fp, fp, fp, fp, i, i, i]
+        for fn in (L.nlk_dev_filter_frame, L.nlk_dev_smooth_frame):
+            fn.argtypes = [vp, fp, fp, fp, fp, i, i, i, f, C.POINTER(Params)]
+        L.nlk_dev_frame_accumulate.argtypes = [vp, fp, fp, fp, fp, i, i, i, f,
+                                               C.POINTER(Params), i, i, i]
+        L.nlk_dev_frame_normalize.argtypes = [vp, fp, fp, fp, i, i, i, i, i]
+        L.nlk_ctx_read_records.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i),
+                                           vp, vp, vp, vp, vp, vp]
+        _hip = L
+    return _hip
+
+
+def api():
+    """libnlkalman.so (drop-in C API) with argtypes set."""
+    global _api
+    if _api is None:
+        hip()  # dependency, RTLD_GLOBAL
+        L = _load("libnlkalman.so")
+        fp, i, f = C.POINTER(C.c_float), C.c_int, C.c_float
+        for fn in (L.rgb2opp, L.opp2rgb):
+            fn.argtypes = [fp, i, i, i]
+            fn.restype = None
+        L.warp_bicubic.argtypes = [fp, fp, fp, fp, i, i, i]
+        L.warp_bicubic.restype = None
+        L.nlkalman_default_params.argtypes = [C.POINTER(Params), f, i]
+        L.nlkalman_default_params.restype = None
+        for fn in (L.nlkalman_filter_frame, L.nlkalman_smooth_frame):
+            fn.argtypes = [fp, fp, fp, fp, i, i, i, f, Params, i]
+            fn.restype = None
+        _api = L
+    return _api
+
+
+class NlkError(RuntimeError):
+    pass
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _img(a):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a[:, :, None] if a.ndim == 2 else a
+
+
+# ---------------------------------------------------------------- drop-in API
+
+def default_params(sigma, mode, **over):
+    """nlkalman_default_params (reference: src/nlkalman.c:426-487); host-only."""
+    p = Params(-1, -1, -1, -1, -1, -1, -1.0, -1.0, -1.0)
+    for k, v in over.items():
+        setattr(p, k, v)
+    api().nlkalman_default_params(C.byref(p), float(sigma), int(mode))
+    return p
+
+
+def filter_frame(nisy1, deno0, bsic1, sigma, params):
+    """nlkalman_filter_frame through the drop-in C API (host arrays)."""
+    nisy1, deno0, bsic1 = _img(nisy1), _img(deno0), _img(bsic1)
+    h, w, ch = nisy1.shape
+    out = np.empty_like(nisy1)
+    api().nlkalman_filter_frame(_fp(out), _fp(nisy1), _fp(deno0), _fp(bsic1), w, h, ch,
+                                float(sigma), params, 0)
+    return out
+
+
+def smooth_frame(filt1, smoo0, bsic1, sigma, params):
+    filt1, smoo0, bsic1 = _img(filt1), _img(smoo0), _img(bsic1)
+    h, w, ch = filt1.shape
+    out = np.empty_like(filt1)
+    api().nlkalman_smooth_frame(_fp(out), _fp(filt1), _fp(smoo0), _fp(bsic1), w, h, ch,
+                                float(sigma), params, 0)
+    return out
+
+
+def rgb2opp(im):
+    a = _img(im).copy()
+    api().rgb2opp(_fp(a), a.shape[1], a.shape[0], a.shape[2])
+    return a
+
+
+def opp2rgb(im):
+    a = _img(im).copy()
+    api().opp2rgb(_fp(a), a.shape[1], a.shape[0], a.shape[2])
+    return a
+
+
+def warp_bicubic(im, flow, occ=None):
+    im = _img(im)
+    h, w, ch = im.shape
+    flow = np.ascontiguousarray(flow, np.float32)
+    occ = None if occ is None else np.ascontiguousarray(occ, np.float32)
+    out = np.empty_like(im)
+    api().warp_bicubic(_fp(out), _fp(im), _fp(flow), _fp(occ), w, h, ch)
+    return out
+
+
+# ------------------------------------------------------- device-resident C-ABI
+
+class Context:
+    """nlk_ctx wrapper: device pointers are plain ints (e.g. tensor.data_ptr())."""
+
+    def __init__(self, device=0):
+        self.L = hip()
+        self.h = C.c_void_p()
+        rc = self.L.nlk_ctx_create(C.byref(self.h), int(device))
+        if rc:
+            raise NlkError(self.L.nlk_last_error(None).decode())
+
+    def close(self):
+        if self.h:
+            self.L.nlk_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise NlkError(f"rc={rc}: " + self.L.nlk_last_error(self.h).decode())
+
+    def set_stream(self, hip_stream):
+        self._chk(self.L.nlk_ctx_set_stream(self.h, hip_stream))
+
+    def set_profiling(self, on):
+        self._chk(self.L.nlk_ctx_set_profiling(self.h, int(on)))
+
+    def timings(self):
+        t = Timings()
+        self._chk(self.L.nlk_ctx_get_timings(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in t._fields_}
+
+    def sync(self):
+        self._chk(self.L.nlk_sync(self.h))
+
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self.L.nlk_dev_alloc(self.h, C.byref(p), nbytes))
+        return p.value
+
+    def free(self, dptr):
+        self._chk(self.L.nlk_dev_free(self.h, dptr))
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        d = self.alloc(arr.nbytes)
+        self._chk(self.L.nlk_h2d(self.h, d, arr.ctypes.data, arr.nbytes))
+        return d
+
+    def download(self, dptr, shape, dtype=np.float32):
+        out = np.empty(shape, dtype)
+        self._chk(self.L.nlk_d2h(self.h, out.ctypes.data, dptr, out.nbytes))
+        return out
+
+    def rgb2opp(self, d_im, w, h, ch):
+        self._chk(self.L.nlk_dev_rgb2opp(self.h, d_im, w, h, ch))
+
+    def opp2rgb(self, d_im, w, h, ch):
+        self._chk(self.L.nlk_dev_opp2rgb(self.h, d_im, w, h, ch))
+
+    def warp_bicubic(self, d_out, d_im, d_flow, d_occ, w, h, ch):
+        self._chk(self.L.nlk_dev_warp_bicubic(self.h, d_out, d_im, d_flow, d_occ, w, h, ch))
+
+    def filter_frame(self, d_out, d_nisy, d_prev, d_basic, w, h, ch, sigma, params):
+        self._chk(self.L.nlk_dev_filter_frame(self.h, d_out, d_nisy, d_prev, d_basic, w, h,
+                                              ch, float(sigma), C.byref(params)))
+
+    def smooth_frame(self, d_out, d_filt, d_prev, d_basic, w, h, ch, sigma, params):
+        self._chk(self.L.nlk_dev_smooth_frame(self.h, d_out, d_filt, d_prev, d_basic, w, h,
+                                              ch, float(sigma), C.byref(params)))
+
+    def frame_accumulate(self, d_acc, d_cur, d_prev, d_basic, w, h, ch, sigma, params, oy,
+                         ngy, smoother=False):
+        self._chk(self.L.nlk_dev_frame_accumulate(self.h, d_acc, d_cur, d_prev, d_basic, w, h,
+                                                  ch, float(sigma), C.byref(params), oy, ngy,
+                                                  int(smoother)))
+
+    def frame_normalize(self, d_out, d_acc, d_cur, w, h, ch, y0, y1):
+        self._chk(self.L.nlk_dev_frame_normalize(self.h, d_out, d_acc, d_cur, w, h, ch, y0, y1))
+
+    def read_records(self):
+        n, k, g = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.L.nlk_ctx_read_records(self.h, C.byref(n), C.byref(k), C.byref(g),
+                                              None, None, None, None, None, None))
+        n, k, g = n.value, k.value, g.value
+        rec = dict(active=np.zeros(n, np.uint8), nsel=np.zeros(n, np.int32),
+                   np0=np.zeros(n, np.int32), nagg=np.zeros(n, np.int32),
+                   topk=np.zeros((n, k), np.uint32), gcoords=np.zeros((n, g), np.uint32))
+        self._chk(self.L.nlk_ctx_read_records(
+            self.h, None, None, None, rec["active"].ctypes.data, rec["nsel"].ctypes.data,
+            rec["np0"].ctypes.data, rec["nagg"].ctypes.data, rec["topk"].ctypes.data,
+            rec["gcoords"].ctypes.data))
+        return rec

@@ -1,0 +1,126 @@
+// k_frame.h — whole-frame, HBM-bound kernels: layout change, validity map,
+// normalisation, colour transform, bicubic warp.
+#pragma once
+#include "nlk_common.h"
+
+// HWC interleaved -> planar (one thread per pixel; reads ch consecutive floats)
+__global__ void k_hwc_to_planar(const float* __restrict__ src, float* __restrict__ dst,
+                                int npix, int ch) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix;
+       i += gridDim.x * blockDim.x) {
+    for (int c = 0; c < ch; ++c) dst[(size_t)c * npix + i] = src[(size_t)i * ch + c];
+  }
+}
+
+// valid[y][x] = 1 iff the psz x psz patch of plane 0 of the previous frame with
+// origin (x,y) lies in the image and holds no NaN
+// (reference: src/nlkalman.c:605-609, 725-730 — only channel 0 is tested).
+// Two separable passes over a byte map: rows then columns.
+__global__ void k_nan_rows(const float* __restrict__ p0, uint8_t* __restrict__ rowok,
+                           int w, int h, int psz) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  uint8_t ok = (x + psz <= w);
+  if (ok)
+    for (int i = 0; i < psz; ++i) {
+      const float v = p0[(size_t)y * w + x + i];
+      if (v != v) ok = 0;
+    }
+  rowok[(size_t)y * w + x] = ok;
+}
+__global__ void k_nan_cols(const uint8_t* __restrict__ rowok, uint8_t* __restrict__ valid,
+                           int w, int h, int psz) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  uint8_t ok = (y + psz <= h);
+  if (ok)
+    for (int i = 0; i < psz; ++i) ok &= rowok[(size_t)(y + i) * w + x];
+  valid[(size_t)y * w + x] = ok;
+}
+
+// out = acc_c / acc_w where acc_w > 1e-6 else the input frame
+// (reference: src/nlkalman.c:939-942, 1853-1856; the double literal 1e-6 there
+// compares like 1e-6f against a float weight)
+__global__ void k_normalize(float* __restrict__ out, const float* __restrict__ acc,
+                            const float* __restrict__ cur_hwc, int w, int h, int ch,
+                            int y0, int y1) {
+  const size_t npix = (size_t)w * h;
+  for (size_t i = (size_t)y0 * w + blockIdx.x * blockDim.x + threadIdx.x;
+       i < (size_t)y1 * w; i += (size_t)gridDim.x * blockDim.x) {
+    const float a = acc[(size_t)ch * npix + i];
+    for (int c = 0; c < ch; ++c) {
+      const float v = (a > 1e-6f) ? acc[(size_t)c * npix + i] / a : cur_hwc[i * ch + c];
+      out[i * ch + c] = v;
+    }
+  }
+}
+
+// reference: src/nlkalman.c:92-110 (in place, ch == 3)
+__global__ void k_rgb2opp(float* __restrict__ im, size_t npix) {
+  const float a = 1.f / sqrtf(3.f), b = 1.f / sqrtf(2.f);
+  const float c = 2.f * a * sqrtf(2.f);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npix;
+       i += (size_t)gridDim.x * blockDim.x) {
+    float* p = im + 3 * i;
+    const float r = p[0], g = p[1], bl = p[2];
+    p[0] = a * (r + g + bl);
+    p[1] = b * (r - bl);
+    p[2] = c * (0.25f * r - 0.5f * g + 0.25f * bl);
+  }
+}
+
+// reference: src/nlkalman.c:112-130
+__global__ void k_opp2rgb(float* __restrict__ im, size_t npix) {
+  const float a = 1.f / sqrtf(3.f), b = 1.f / sqrtf(2.f);
+  const float c = a / b;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npix;
+       i += (size_t)gridDim.x * blockDim.x) {
+    float* p = im + 3 * i;
+    const float y = p[0], u = p[1], v = p[2];
+    p[0] = a * y + b * u + 0.5f * c * v;
+    p[1] = a * y - c * v;
+    p[2] = a * y - b * u + 0.5f * c * v;
+  }
+}
+
+// Keys cubic with the reference's mixed float/double evaluation
+// (reference: src/nlkalman.c:36-41)
+__device__ inline float nlk_cubic(const float v[4], float x) {
+  return (float)(v[1] + 0.5 * x * (v[2] - v[0] +
+                 x * (2.0 * v[0] - 5.0 * v[1] + 4.0 * v[2] - v[3] +
+                      x * (3.0 * (v[1] - v[2]) + v[3] - v[0]))));
+}
+
+// reference: src/nlkalman.c:29-33, 43-88 — one thread per output pixel
+__global__ void k_warp_bicubic(float* __restrict__ imw, const float* __restrict__ im,
+                               const float* __restrict__ of, const float* __restrict__ msk,
+                               int w, int h, int ch) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const size_t pix = (size_t)x + (size_t)y * w;
+  float* o = imw + pix * ch;
+  if (msk && msk[pix] != 0.f) {
+    for (int c = 0; c < ch; ++c) o[c] = __builtin_nanf("");
+    return;
+  }
+  float xw = x + of[pix * 2 + 0];
+  float yw = y + of[pix * 2 + 1];
+  xw -= 1;
+  yw -= 1;
+  const int ix = (int)floorf(xw), iy = (int)floorf(yw);
+  const float fx = xw - ix, fy = yw - iy;
+  for (int c = 0; c < ch; ++c) {
+    float v[4];
+    for (int i = 0; i < 4; ++i) {
+      float col[4];
+      for (int j = 0; j < 4; ++j) {
+        const int sx = ix + i, sy = iy + j;
+        col[j] = (sx < 0 || sx >= w || sy < 0 || sy >= h)
+                     ? __builtin_nanf("")
+                     : im[((size_t)sx + (size_t)sy * w) * ch + c];
+      }
+      v[i] = nlk_cubic(col, fy);
+    }
+    o[c] = nlk_cubic(v, fx);
+  }
+}

@@ -1,0 +1,518 @@
+// nlk_hip.hip — C-ABI (include/nlk_hip.h) over the gfx950 kernels.
+//
+// One context per (process, device). All work is enqueued on the context's
+// stream; scratch buffers are grown on demand and kept, so a steady-state frame
+// call performs no allocation (context/alloc time is on the
+// CLI critical path).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/nlk_hip.h"
+#include "k_commit.h"
+#include "k_frame.h"
+#include "k_group.h"
+#include "k_match.h"
+#include "nlk_common.h"
+
+namespace {
+
+struct Buf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+char g_err[512] = "";
+
+}  // namespace
+
+struct nlk_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  char err[512] = "";
+  Buf pl_cur, pl_prev, pl_basic, rowok, vmap, topk, tinfo, gcoords, marks, active, acc, tabs;
+  int tabs_psz = 0;
+  NlkGeom last{};
+  bool have_last = false;
+  bool profiling = false;
+  hipEvent_t ev[6] = {};
+  nlk_timings tm{};
+};
+
+namespace {
+
+int fail(nlk_ctx* c, int code, const char* fmt, ...) {
+  char msg[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(msg, sizeof msg, fmt, ap);
+  va_end(ap);
+  snprintf(g_err, sizeof g_err, "%s", msg);
+  if (c) snprintf(c->err, sizeof c->err, "%s", msg);
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                         \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess)                                                         \
+      return fail(ctx, NLK_EHIP, "%s failed: %s (%s:%d)", #call,                  \
+                  hipGetErrorString(e_), __FILE__, __LINE__);                     \
+  } while (0)
+
+int reserve(nlk_ctx* c, Buf& b, size_t bytes) {
+  if (bytes <= b.cap) return NLK_OK;
+  if (b.p) HIPCHK(c, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  const size_t want = bytes + bytes / 8 + 256;
+  if (hipMalloc(&b.p, want) != hipSuccess)
+    return fail(c, NLK_ENOMEM, "hipMalloc of %zu bytes failed", want);
+  b.cap = want;
+  return NLK_OK;
+}
+
+// reference: src/nlkalman.c:365-419 ("gaussian"), float/double mix as written there
+void host_window(float* W, int psz) {
+  float w1[64];
+  const float N2 = ((float)psz - 1.) / 2.;
+  for (int n = 0; n < psz; ++n) {
+    const float s = .4;
+    const float x = ((float)n - N2) / N2 / s;
+    w1[n] = exp(-.5 * x * x);
+  }
+  for (int i = 0; i < psz; ++i)
+    for (int j = 0; j < psz; ++j) W[i * psz + j] = w1[i] * w1[j];
+}
+
+// orthonormal DCT-II basis = FFTW REDFT10 x the reference's scaling
+// (reference: src/nlkalman.c:204-212, 281-298)
+void host_basis(float* C, int n) {
+  for (int k = 0; k < n; ++k)
+    for (int j = 0; j < n; ++j) {
+      const double s = (k == 0) ? sqrt(1.0 / n) : sqrt(2.0 / n);
+      C[k * n + j] = (float)(s * cos(M_PI * (j + 0.5) * k / n));
+    }
+}
+
+int upload_tables(nlk_ctx* c, int psz) {
+  if (c->tabs_psz == psz) return NLK_OK;
+  float host[2 * 64 * 64];
+  host_basis(host, psz);
+  host_window(host + psz * psz, psz);
+  int rc = reserve(c, c->tabs, sizeof(float) * 2 * psz * psz);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->tabs.p, host, sizeof(float) * 2 * psz * psz,
+                           hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // host[] is on the stack
+  c->tabs_psz = psz;
+  return NLK_OK;
+}
+
+template <int PSZ, int CH>
+int launch_group_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
+                   const float* prev, float* acc) {
+  const int ngrid = g.ngx * g.ngy;
+  const float* basis = (const float*)c->tabs.p;
+  const float* window = basis + PSZ * PSZ;
+  if (g.smoother)
+    hipLaunchKernelGGL((k_group<PSZ, CH, true>), dim3(ngrid), dim3(64), 0, c->stream, img,
+                       cur, prev, (const uint8_t*)c->vmap.p, g, (const uint32_t*)c->topk.p,
+                       (const NlkTarget*)c->tinfo.p, (const uint32_t*)c->gcoords.p,
+                       (const uint8_t*)c->active.p, basis, window, acc);
+  else
+    hipLaunchKernelGGL((k_group<PSZ, CH, false>), dim3(ngrid), dim3(64), 0, c->stream, img,
+                       cur, prev, (const uint8_t*)c->vmap.p, g, (const uint32_t*)c->topk.p,
+                       (const NlkTarget*)c->tinfo.p, (const uint32_t*)c->gcoords.p,
+                       (const uint8_t*)c->active.p, basis, window, acc);
+  HIPCHK(c, hipGetLastError());
+  return NLK_OK;
+}
+
+template <int CH>
+int launch_group_ch(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
+                    const float* prev, float* acc) {
+  switch (g.psz) {
+    case 4: return launch_group_t<4, CH>(c, g, img, cur, prev, acc);
+    case 6: return launch_group_t<6, CH>(c, g, img, cur, prev, acc);
+    case 8: return launch_group_t<8, CH>(c, g, img, cur, prev, acc);
+    case 10: return launch_group_t<10, CH>(c, g, img, cur, prev, acc);
+    case 12: return launch_group_t<12, CH>(c, g, img, cur, prev, acc);
+    case 16: return launch_group_t<16, CH>(c, g, img, cur, prev, acc);
+  }
+  return fail(c, NLK_EUNSUP, "patch size %d not supported (4, 6, 8, 10, 12, 16)", g.psz);
+}
+
+int launch_group(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
+                 const float* prev, float* acc) {
+  if (g.ch == 1) return launch_group_ch<1>(c, g, img, cur, prev, acc);
+  if (g.ch == 3) return launch_group_ch<3>(c, g, img, cur, prev, acc);
+  return fail(c, NLK_EUNSUP, "%d channels not supported (1 or 3)", g.ch);
+}
+
+template <int MAXM>
+int launch_match_t(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds,
+                   const float* img) {
+  auto kern = k_bm_topk<MAXM>;
+  HIPCHK(c, hipFuncSetAttribute((const void*)kern,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(tl.ntx * tl.nty), dim3(NLK_BM_THREADS), lds, c->stream, img,
+                     (const uint8_t*)c->vmap.p, g, tl, (uint32_t*)c->topk.p,
+                     (NlkTarget*)c->tinfo.p, (uint32_t*)c->gcoords.p, (uint64_t*)c->marks.p);
+  HIPCHK(c, hipGetLastError());
+  return NLK_OK;
+}
+
+int to_planar(nlk_ctx* c, Buf& dst, const float* src, int npix, int ch, const float** out) {
+  if (ch == 1) {  // planar == interleaved
+    *out = src;
+    return NLK_OK;
+  }
+  int rc = reserve(c, dst, sizeof(float) * (size_t)npix * ch);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_hwc_to_planar, dim3(2048), dim3(256), 0, c->stream, src,
+                     (float*)dst.p, npix, ch);
+  HIPCHK(c, hipGetLastError());
+  *out = (const float*)dst.p;
+  return NLK_OK;
+}
+
+int check_images(nlk_ctx* c, const void* out, const void* cur, int w, int h, int ch) {
+  if (!c) return fail(nullptr, NLK_EINVAL, "null context");
+  if (!out || !cur) return fail(c, NLK_EINVAL, "null image pointer");
+  if (w <= 0 || h <= 0 || ch <= 0) return fail(c, NLK_EINVAL, "bad image size %dx%dx%d", w, h, ch);
+  if (w > 65535 || h > 65535) return fail(c, NLK_EUNSUP, "image side above 65535");
+  return NLK_OK;
+}
+
+void mark(nlk_ctx* c, int i) {
+  if (c->profiling) hipEventRecord(c->ev[i], c->stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nlk_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* nlk_last_error(const nlk_ctx* ctx) { return ctx ? ctx->err : g_err; }
+
+int nlk_ctx_create(nlk_ctx** out, int device) {
+  if (!out) return fail(nullptr, NLK_EINVAL, "null ctx pointer");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(nullptr, NLK_ENODEV, "no HIP device visible (the HIP path is mandatory: there is no CPU fallback)");
+  if (device < 0 || device >= n)
+    return fail(nullptr, NLK_ENODEV, "device %d out of range (%d visible)", device, n);
+  nlk_ctx* c = new nlk_ctx();
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return fail(nullptr, NLK_EHIP, "cannot create a stream on device %d", device);
+  }
+  c->stream = c->own_stream;
+  for (auto& e : c->ev) hipEventCreate(&e);
+  *out = c;
+  return NLK_OK;
+}
+
+void nlk_ctx_destroy(nlk_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  Buf* bufs[] = {&c->pl_cur, &c->pl_prev, &c->pl_basic, &c->rowok, &c->vmap, &c->topk,
+                 &c->tinfo, &c->gcoords, &c->marks, &c->active, &c->acc, &c->tabs};
+  for (Buf* b : bufs)
+    if (b->p) hipFree(b->p);
+  for (auto& e : c->ev) hipEventDestroy(e);
+  hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int nlk_ctx_set_profiling(nlk_ctx* c, int on) {
+  if (!c) return NLK_EINVAL;
+  c->profiling = on != 0;
+  return NLK_OK;
+}
+
+int nlk_ctx_get_timings(const nlk_ctx* c, struct nlk_timings* t) {
+  if (!c || !t) return NLK_EINVAL;
+  *t = c->tm;
+  return NLK_OK;
+}
+
+int nlk_ctx_set_stream(nlk_ctx* c, void* s) {
+  if (!c) return NLK_EINVAL;
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return NLK_OK;
+}
+
+void* nlk_ctx_get_stream(nlk_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int nlk_dev_alloc(nlk_ctx* c, void** d, size_t bytes) {
+  if (!c || !d) return fail(c, NLK_EINVAL, "null argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (hipMalloc(d, bytes) != hipSuccess) return fail(c, NLK_ENOMEM, "hipMalloc(%zu) failed", bytes);
+  return NLK_OK;
+}
+int nlk_dev_free(nlk_ctx* c, void* d) {
+  if (!c) return NLK_EINVAL;
+  HIPCHK(c, hipFree(d));
+  return NLK_OK;
+}
+int nlk_h2d(nlk_ctx* c, void* d, const void* h, size_t n) {
+  if (!c) return NLK_EINVAL;
+  HIPCHK(c, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return NLK_OK;
+}
+int nlk_d2h(nlk_ctx* c, void* h, const void* d, size_t n) {
+  if (!c) return NLK_EINVAL;
+  HIPCHK(c, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return NLK_OK;
+}
+int nlk_d2d(nlk_ctx* c, void* dst, const void* src, size_t n) {
+  if (!c) return NLK_EINVAL;
+  HIPCHK(c, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, c->stream));
+  return NLK_OK;
+}
+int nlk_sync(nlk_ctx* c) {
+  if (!c) return NLK_EINVAL;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return NLK_OK;
+}
+
+int nlk_dev_rgb2opp(nlk_ctx* c, float* im, int w, int h, int ch) {
+  int rc = check_images(c, im, im, w, h, ch);
+  if (rc) return rc;
+  if (ch != 3) return NLK_OK;
+  hipLaunchKernelGGL(k_rgb2opp, dim3(2048), dim3(256), 0, c->stream, im, (size_t)w * h);
+  HIPCHK(c, hipGetLastError());
+  return NLK_OK;
+}
+
+int nlk_dev_opp2rgb(nlk_ctx* c, float* im, int w, int h, int ch) {
+  int rc = check_images(c, im, im, w, h, ch);
+  if (rc) return rc;
+  if (ch != 3) return NLK_OK;
+  hipLaunchKernelGGL(k_opp2rgb, dim3(2048), dim3(256), 0, c->stream, im, (size_t)w * h);
+  HIPCHK(c, hipGetLastError());
+  return NLK_OK;
+}
+
+int nlk_dev_warp_bicubic(nlk_ctx* c, float* imw, const float* im, const float* of,
+                         const float* msk, int w, int h, int ch) {
+  int rc = check_images(c, imw, im, w, h, ch);
+  if (rc) return rc;
+  if (!of) return fail(c, NLK_EINVAL, "null flow");
+  hipLaunchKernelGGL(k_warp_bicubic, dim3((w + 127) / 128, h), dim3(128), 0, c->stream, imw,
+                     im, of, msk, w, h, ch);
+  HIPCHK(c, hipGetLastError());
+  return NLK_OK;
+}
+
+int nlk_dev_frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const float* prev,
+                             const float* basic, int w, int h, int ch, float sigma,
+                             const struct nlkalman_params* P, int oy, int ngy, int smoother) {
+  int rc = check_images(c, acc, cur, w, h, ch);
+  if (rc) return rc;
+  if (!P) return fail(c, NLK_EINVAL, "null parameters");
+  HIPCHK(c, hipSetDevice(c->device));
+  NlkGeom g{};
+  g.w = w; g.h = h; g.ch = ch;
+  g.psz = P->patch_sz;
+  if (g.psz < 2 || g.psz > 16) return fail(c, NLK_EUNSUP, "patch size %d not supported", g.psz);
+  g.step = g.psz / 2;
+  g.p2 = g.psz * g.psz;
+  g.E = g.p2 * ch;
+  if (w < g.psz || h < g.psz) return fail(c, NLK_EINVAL, "image smaller than a patch");
+  g.ngx = (w - g.psz) / g.step + 1;
+  g.oy = oy;
+  g.ngy = ngy;
+  if (oy < 0 || ngy < 1 || oy + (ngy - 1) * g.step + g.psz > h)
+    return fail(c, NLK_EINVAL, "target rows [%d + j*%d, j < %d) leave the %d-row strip", oy,
+                g.step, ngy, h);
+  g.wsz_x = P->search_sz_x; g.wsz_t = P->search_sz_t;
+  g.npx = P->npatches_x; g.npt = P->npatches_t; g.ntagg = P->npatches_tagg;
+  if (g.wsz_x < 0 || g.wsz_t < 0 || g.ntagg < 0)
+    return fail(c, NLK_EINVAL, "negative search radius or group size (call nlkalman_default_params first)");
+  g.have_prev = prev != nullptr;
+  g.have_basic = basic != nullptr;
+  g.smoother = smoother != 0;
+  g.sigma2 = sigma * sigma;
+  g.beta_x = P->beta_x; g.beta_t = P->beta_t;
+  const int wmax = g.smoother ? g.wsz_t : (g.have_prev ? max(g.wsz_x, g.wsz_t) : g.wsz_x);
+  g.R = wmax / g.step;
+  if (g.R > 3)
+    return fail(c, NLK_EUNSUP, "search radius %d with patch size %d: group reach %d grid cells > 3",
+                wmax, g.psz, g.R);
+  const int ncand = (2 * wmax + 1) * (2 * wmax + 1);
+  if (ncand > 64 * 16) return fail(c, NLK_EUNSUP, "search radius %d too large (max 15)", wmax);
+  g.kmax = max(max(g.npx, g.npt), 1);
+  const int ngrid = g.ngx * g.ngy;
+  const int npix = w * h;
+  const int ntagg_alloc = max(g.ntagg, 1);
+  g.gstride = ntagg_alloc;
+
+  mark(c, 0);
+  // ---- layout: planar copies, validity map
+  const float *img_cur, *img_prev = nullptr, *img_basic = nullptr;
+  if ((rc = to_planar(c, c->pl_cur, cur, npix, ch, &img_cur))) return rc;
+  if (prev && (rc = to_planar(c, c->pl_prev, prev, npix, ch, &img_prev))) return rc;
+  if (basic && (rc = to_planar(c, c->pl_basic, basic, npix, ch, &img_basic))) return rc;
+  if (prev) {
+    if ((rc = reserve(c, c->rowok, npix)) || (rc = reserve(c, c->vmap, npix))) return rc;
+    const dim3 grd((w + 255) / 256, h);
+    hipLaunchKernelGGL(k_nan_rows, grd, dim3(256), 0, c->stream, img_prev, (uint8_t*)c->rowok.p,
+                       w, h, g.psz);
+    hipLaunchKernelGGL(k_nan_cols, grd, dim3(256), 0, c->stream, (const uint8_t*)c->rowok.p,
+                       (uint8_t*)c->vmap.p, w, h, g.psz);
+    HIPCHK(c, hipGetLastError());
+  }
+  if ((rc = upload_tables(c, g.psz))) return rc;
+  if ((rc = reserve(c, c->topk, sizeof(uint32_t) * (size_t)ngrid * g.kmax)) ||
+      (rc = reserve(c, c->tinfo, sizeof(NlkTarget) * (size_t)ngrid)) ||
+      (rc = reserve(c, c->gcoords, sizeof(uint32_t) * (size_t)ngrid * ntagg_alloc)) ||
+      (rc = reserve(c, c->marks, sizeof(uint64_t) * (size_t)ngrid)) ||
+      (rc = reserve(c, c->active, (size_t)ngrid)))
+    return rc;
+  mark(c, 1);
+
+  // ---- block matching + selection
+  const float* img_match = basic ? img_basic : img_cur;
+  NlkTile tl{};
+  tl.tgx = 16; tl.tgy = 4;
+  tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
+  tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
+  tl.rw_max = ((tl.tgx - 1) * g.step + 2 * wmax + g.psz) | 1;
+  tl.rh_max = (tl.tgy - 1) * g.step + 2 * wmax + g.psz;
+  tl.ncand_max = ncand;
+  const size_t lds = sizeof(float) * ((size_t)ch * tl.rw_max * tl.rh_max +
+                                      (size_t)NLK_BM_WAVES * (2 * ncand + ntagg_alloc));
+  if (lds > 160 * 1024)
+    return fail(c, NLK_EUNSUP, "matching tile needs %zu bytes of LDS (> 160 KiB)", lds);
+  const int maxm = (ncand + 63) / 64;
+  if (maxm <= 2) rc = launch_match_t<2>(c, g, tl, lds, img_match);
+  else if (maxm <= 7) rc = launch_match_t<7>(c, g, tl, lds, img_match);
+  else rc = launch_match_t<16>(c, g, tl, lds, img_match);
+  if (rc) return rc;
+  mark(c, 2);
+
+  // ---- processed-mask replay
+  {
+    const int threads = min(1024, ((g.ngy + 63) / 64) * 64);
+    const size_t bits = sizeof(uint32_t) * ((size_t)(ngrid + 31) / 32);
+    if (bits > 160 * 1024) return fail(c, NLK_EUNSUP, "patch grid too large for the mask replay");
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_mask_commit,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bits));
+    hipLaunchKernelGGL(k_mask_commit, dim3(1), dim3(threads), bits, c->stream,
+                       (const uint64_t*)c->marks.p, (uint8_t*)c->active.p, g.ngx, g.ngy, g.R);
+    HIPCHK(c, hipGetLastError());
+  }
+  mark(c, 3);
+
+  // ---- group processing + aggregation
+  if ((rc = launch_group(c, g, img_match, img_cur, img_prev, acc))) return rc;
+  mark(c, 4);
+  c->last = g;
+  c->have_last = true;
+  return NLK_OK;
+}
+
+int nlk_dev_frame_normalize(nlk_ctx* c, float* out, const float* acc, const float* cur, int w,
+                            int h, int ch, int y0, int y1) {
+  int rc = check_images(c, out, cur, w, h, ch);
+  if (rc) return rc;
+  if (!acc || y0 < 0 || y1 > h || y0 > y1) return fail(c, NLK_EINVAL, "bad normalise range");
+  hipLaunchKernelGGL(k_normalize, dim3(2048), dim3(256), 0, c->stream, out, acc, cur, w, h, ch,
+                     y0, y1);
+  HIPCHK(c, hipGetLastError());
+  return NLK_OK;
+}
+
+static int run_frame(nlk_ctx* c, float* out, const float* cur, const float* prev,
+                     const float* basic, int w, int h, int ch, float sigma,
+                     const struct nlkalman_params* P, int smoother) {
+  int rc = check_images(c, out, cur, w, h, ch);
+  if (rc) return rc;
+  if (!P) return fail(c, NLK_EINVAL, "null parameters");
+  if (P->patch_sz < 2) return fail(c, NLK_EUNSUP, "patch size %d not supported", P->patch_sz);
+  const size_t accb = sizeof(float) * (size_t)w * h * (ch + 1);
+  if ((rc = reserve(c, c->acc, accb))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->acc.p, 0, accb, c->stream));
+  const int step = P->patch_sz / 2;
+  if (h < P->patch_sz || w < P->patch_sz) return fail(c, NLK_EINVAL, "image smaller than a patch");
+  const int ngy = (h - P->patch_sz) / step + 1;
+  rc = nlk_dev_frame_accumulate(c, (float*)c->acc.p, cur, prev, basic, w, h, ch, sigma, P, 0,
+                                ngy, smoother);
+  if (rc) return rc;
+  rc = nlk_dev_frame_normalize(c, out, (const float*)c->acc.p, cur, w, h, ch, 0, h);
+  if (rc) return rc;
+  mark(c, 5);
+  if (c->profiling) {
+    HIPCHK(c, hipEventSynchronize(c->ev[5]));
+    float* dst[5] = {&c->tm.layout_ms, &c->tm.match_ms, &c->tm.commit_ms, &c->tm.group_ms,
+                     &c->tm.normalize_ms};
+    for (int i = 0; i < 5; ++i) hipEventElapsedTime(dst[i], c->ev[i], c->ev[i + 1]);
+    hipEventElapsedTime(&c->tm.total_ms, c->ev[0], c->ev[5]);
+  }
+  return NLK_OK;
+}
+
+int nlk_dev_filter_frame(nlk_ctx* c, float* deno1, const float* nisy1, const float* deno0,
+                         const float* bsic1, int w, int h, int ch, float sigma,
+                         const struct nlkalman_params* P) {
+  return run_frame(c, deno1, nisy1, deno0, bsic1, w, h, ch, sigma, P, 0);
+}
+
+int nlk_dev_smooth_frame(nlk_ctx* c, float* smoo1, const float* filt1, const float* smoo0,
+                         const float* bsic1, int w, int h, int ch, float sigma,
+                         const struct nlkalman_params* P) {
+  return run_frame(c, smoo1, filt1, smoo0, bsic1, w, h, ch, sigma, P, 1);
+}
+
+int nlk_ctx_read_records(nlk_ctx* c, int* ngrid, int* kmax, int* gmax, unsigned char* active,
+                         int* nsel, int* np0, int* nagg, unsigned int* topk,
+                         unsigned int* gcoords) {
+  if (!c || !c->have_last) return fail(c, NLK_EINVAL, "no frame has been processed");
+  const NlkGeom& g = c->last;
+  const int n = g.ngx * g.ngy;
+  if (ngrid) *ngrid = n;
+  if (kmax) *kmax = g.kmax;
+  if (gmax) *gmax = g.gstride;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (active) HIPCHK(c, hipMemcpy(active, c->active.p, n, hipMemcpyDeviceToHost));
+  if (nsel || np0 || nagg) {
+    NlkTarget* t = (NlkTarget*)malloc(sizeof(NlkTarget) * n);
+    if (!t) return fail(c, NLK_ENOMEM, "host malloc failed");
+    hipError_t e = hipMemcpy(t, c->tinfo.p, sizeof(NlkTarget) * n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+      for (int i = 0; i < n; ++i) {
+        if (nsel) nsel[i] = t[i].nsel;
+        if (np0) np0[i] = t[i].np0;
+        if (nagg) nagg[i] = t[i].nagg;
+      }
+    free(t);
+    HIPCHK(c, e);
+  }
+  if (topk)
+    HIPCHK(c, hipMemcpy(topk, c->topk.p, sizeof(uint32_t) * (size_t)n * g.kmax,
+                        hipMemcpyDeviceToHost));
+  if (gcoords)
+    HIPCHK(c, hipMemcpy(gcoords, c->gcoords.p, sizeof(uint32_t) * (size_t)n * g.gstride,
+                        hipMemcpyDeviceToHost));
+  return NLK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,156 @@
+/* nlkalman.c — host side (plain C) of the drop-in API in include/nlkalman.h.
+ *
+ * Same six symbols, prototypes and calling conventions as the reference's
+ * src/nlkalman.h:14-53: host pointers in, host pointers out, void returns,
+ * fatal errors print to stderr and exit(1) (reference: src/nlkalman.c:165-177).
+ * All arithmetic on images happens in the HIP kernels behind include/nlk_hip.h;
+ * there is NO CPU fallback: without a usable GPU every frame function aborts.
+ *
+ * A process-wide device context is created on first use (the CLI makes one
+ * call per process; a long-running caller reuses the context and its scratch
+ * buffers) and torn down at exit. NLK_DEVICE selects the HIP device (default 0).
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "nlk_hip.h"
+#include "nlkalman.h"
+
+static nlk_ctx *g_ctx = NULL;
+
+static void ctx_atexit(void) {
+  if (g_ctx) nlk_ctx_destroy(g_ctx);
+  g_ctx = NULL;
+}
+
+static void die(const char *what, nlk_ctx *c) {
+  fprintf(stderr, "nlkalman (hip): %s: %s\n", what, nlk_last_error(c));
+  exit(1);
+}
+
+static nlk_ctx *ctx(void) {
+  if (!g_ctx) {
+    const char *dev = getenv("NLK_DEVICE");
+    if (nlk_ctx_create(&g_ctx, dev ? atoi(dev) : 0) != NLK_OK) die("cannot initialise the GPU", NULL);
+    atexit(ctx_atexit);
+  }
+  return g_ctx;
+}
+
+nlk_ctx *nlkalman_hip_context(void) { return ctx(); } /* for the CLIs */
+
+static float *upload(nlk_ctx *c, const float *h, size_t n) {
+  void *d = NULL;
+  if (!h) return NULL;
+  if (nlk_dev_alloc(c, &d, n * sizeof(float)) || nlk_h2d(c, d, h, n * sizeof(float)))
+    die("upload", c);
+  return (float *)d;
+}
+
+/* reference: src/nlkalman.c:92-110 */
+void rgb2opp(float *im, int w, int h, int ch) {
+  if (ch != 3) return;
+  nlk_ctx *c = ctx();
+  const size_t n = (size_t)w * h * ch;
+  float *d = upload(c, im, n);
+  if (nlk_dev_rgb2opp(c, d, w, h, ch) || nlk_d2h(c, im, d, n * sizeof(float))) die("rgb2opp", c);
+  nlk_dev_free(c, d);
+}
+
+/* reference: src/nlkalman.c:112-130 */
+void opp2rgb(float *im, int w, int h, int ch) {
+  if (ch != 3) return;
+  nlk_ctx *c = ctx();
+  const size_t n = (size_t)w * h * ch;
+  float *d = upload(c, im, n);
+  if (nlk_dev_opp2rgb(c, d, w, h, ch) || nlk_d2h(c, im, d, n * sizeof(float))) die("opp2rgb", c);
+  nlk_dev_free(c, d);
+}
+
+/* reference: src/nlkalman.c:71-88 */
+void warp_bicubic(float *imw, float *im, float *of, float *msk, int w, int h, int ch) {
+  nlk_ctx *c = ctx();
+  const size_t n = (size_t)w * h;
+  float *d_im = upload(c, im, n * ch), *d_of = upload(c, of, n * 2), *d_msk = upload(c, msk, n);
+  void *d_out = NULL;
+  if (nlk_dev_alloc(c, &d_out, n * ch * sizeof(float))) die("warp_bicubic", c);
+  if (nlk_dev_warp_bicubic(c, (float *)d_out, d_im, d_of, d_msk, w, h, ch) ||
+      nlk_d2h(c, imw, d_out, n * ch * sizeof(float)))
+    die("warp_bicubic", c);
+  nlk_dev_free(c, d_im);
+  nlk_dev_free(c, d_of);
+  if (d_msk) nlk_dev_free(c, d_msk);
+  nlk_dev_free(c, d_out);
+}
+
+/* reference: src/nlkalman.c:426-487 — sigma-dependent defaults for fields < 0.
+ * The expressions keep the reference's int/float/double mix. */
+void nlkalman_default_params(struct nlkalman_params *p, float sigma, enum FILTER_MODE mode) {
+  if (p->patch_sz < 0) p->patch_sz = 8;
+  if (p->search_sz_x < 0) p->search_sz_x = 10;
+  if (p->search_sz_t < 0) p->search_sz_t = 5;
+  if (p->dista_lambda < 0) p->dista_lambda = 1.0;
+  switch (mode) {
+    case FLT1:
+      if (p->npatches_x < 0) p->npatches_x = (int)(0.5 * sigma + 40.);
+      if (p->beta_x < 0) p->beta_x = -0.04 * sigma + 3.91;
+      if (p->npatches_t < 0) p->npatches_t = 30;
+      if (p->npatches_tagg < 0) p->npatches_tagg = 20;
+      if (p->beta_t < 0) p->beta_t = -0.005 * sigma + 2.05;
+      break;
+    case FLT2:
+      if (p->npatches_x < 0) p->npatches_x = (int)(0.5 * sigma + 10.);
+      if (p->beta_x < 0) p->beta_x = 0.004 * sigma + 0.21;
+      if (p->npatches_t < 0) p->npatches_t = (int)(5 > sigma ? 5 : sigma);
+      if (p->npatches_tagg < 0) p->npatches_tagg = 1;
+      if (p->beta_t < 0) p->beta_t = 0.014 * sigma + 1.38;
+      break;
+    case SMO1:
+      if (p->npatches_x < 0) p->npatches_x = 0;
+      if (p->beta_x < 0) p->beta_x = 0;
+      if (p->npatches_t < 0) {
+        const float v = 3 * sigma - 15;
+        p->npatches_t = (int)(5 > v ? 5 : v);
+      }
+      if (p->npatches_tagg < 0) p->npatches_tagg = p->npatches_t;
+      if (p->beta_t < 0) {
+        const double v = -0.14 * sigma + 8.0;
+        p->beta_t = 1.0 > v ? 1.0 : v;
+      }
+      break;
+  }
+}
+
+static void frame_call(int smoother, float *out, float *cur, float *prev, float *basic, int w,
+                       int h, int ch, float sigma, const struct nlkalman_params *prms) {
+  nlk_ctx *c = ctx();
+  const size_t n = (size_t)w * h * ch;
+  float *d_cur = upload(c, cur, n), *d_prev = upload(c, prev, n), *d_basic = upload(c, basic, n);
+  void *d_out = NULL;
+  if (nlk_dev_alloc(c, &d_out, n * sizeof(float))) die("frame", c);
+  const int rc = smoother
+                     ? nlk_dev_smooth_frame(c, (float *)d_out, d_cur, d_prev, d_basic, w, h, ch, sigma, prms)
+                     : nlk_dev_filter_frame(c, (float *)d_out, d_cur, d_prev, d_basic, w, h, ch, sigma, prms);
+  if (rc || nlk_d2h(c, out, d_out, n * sizeof(float)))
+    die(smoother ? "nlkalman_smooth_frame" : "nlkalman_filter_frame", c);
+  nlk_dev_free(c, d_cur);
+  if (d_prev) nlk_dev_free(c, d_prev);
+  if (d_basic) nlk_dev_free(c, d_basic);
+  nlk_dev_free(c, d_out);
+}
+
+/* reference: src/nlkalman.c:518-951 */
+void nlkalman_filter_frame(float *deno1, float *nisy1, float *deno0, float *bsic1, int w, int h,
+                           int ch, float sigma, const struct nlkalman_params prms, int frame) {
+  (void)frame;
+  frame_call(0, deno1, nisy1, deno0, bsic1, w, h, ch, sigma, &prms);
+}
+
+/* reference: src/nlkalman.c:1409-1865 */
+void nlkalman_smooth_frame(float *smoo1, float *filt1, float *smoo0, float *bsic1, int w, int h,
+                           int ch, float sigma, const struct nlkalman_params prms, int frame) {
+  (void)frame;
+  frame_call(1, smoo1, filt1, smoo0, bsic1, w, h, ch, sigma, &prms);
+}

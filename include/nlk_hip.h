@@ -1,0 +1,110 @@
+/* nlk_hip.h — thin C-ABI over the hand-written HIP (gfx950) kernels.
+ *
+ * This is the boundary a maintainer of the reference would bind to replace the
+ * body of its three frame functions and its three image helpers. Plain
+ * pointers and sizes only; every entry point returns 0 on success or a
+ * negative NLK_E* code, with a message retrievable by nlk_last_error().
+ * Device pointers are ordinary HIP device addresses (hipMalloc / a torch
+ * tensor's data_ptr()); images keep the reference's HWC interleaved float32
+ * layout, index (x + y*w)*ch + c (reference: src/nlkalman.c:555-560).
+ *
+ * What each entry point replaces in the reference:
+ *   nlk_dev_rgb2opp / nlk_dev_opp2rgb   src/nlkalman.c:92-130
+ *   nlk_dev_warp_bicubic                src/nlkalman.c:29-88
+ *   nlk_dev_filter_frame                src/nlkalman.c:518-951  (nlkalman_filter_frame)
+ *   nlk_dev_smooth_frame                src/nlkalman.c:1409-1865 (nlkalman_smooth_frame)
+ *   nlk_dev_frame_accumulate/_normalize the same two functions split at
+ *                                       src/nlkalman.c:939 / :1853 so that row
+ *                                       strips can exchange accumulator halos
+ */
+#ifndef NLK_HIP_H
+#define NLK_HIP_H
+
+#include <stddef.h>
+#include "nlkalman.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  NLK_OK = 0,
+  NLK_ENODEV = -1,   /* no HIP device / device index out of range */
+  NLK_EHIP = -2,     /* a HIP runtime call failed */
+  NLK_EINVAL = -3,   /* bad argument (NULL image, non-positive size, ...) */
+  NLK_EUNSUP = -4,   /* parameter combination the kernels do not cover */
+  NLK_ENOMEM = -5
+};
+
+typedef struct nlk_ctx nlk_ctx; /* one per (process, device): stream + scratch */
+
+/* per-kernel device time of the last frame call, milliseconds (HIP events on
+ * the context's stream; filled only when profiling was enabled) */
+struct nlk_timings {
+  float layout_ms;    /* HWC -> planar copies + validity map */
+  float match_ms;     /* block matching + k-NN selection */
+  float commit_ms;    /* processed-mask replay */
+  float group_ms;     /* DCT + statistics + shrinkage + IDCT + aggregation */
+  float normalize_ms; /* accumulator normalisation */
+  float total_ms;
+};
+
+int nlk_device_count(void);
+int nlk_ctx_create(nlk_ctx **ctx, int device);
+void nlk_ctx_destroy(nlk_ctx *ctx);
+const char *nlk_last_error(const nlk_ctx *ctx); /* ctx may be NULL: last global error */
+int nlk_ctx_set_profiling(nlk_ctx *ctx, int on);
+int nlk_ctx_get_timings(const nlk_ctx *ctx, struct nlk_timings *t);
+/* run the context's work on an externally owned hipStream_t (NULL = own stream) */
+int nlk_ctx_set_stream(nlk_ctx *ctx, void *hip_stream);
+void *nlk_ctx_get_stream(nlk_ctx *ctx);
+
+/* device memory + transfers (so that C callers need no HIP headers) */
+int nlk_dev_alloc(nlk_ctx *ctx, void **dptr, size_t bytes);
+int nlk_dev_free(nlk_ctx *ctx, void *dptr);
+int nlk_h2d(nlk_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int nlk_d2h(nlk_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int nlk_d2d(nlk_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);
+int nlk_sync(nlk_ctx *ctx);
+
+/* image helpers on device-resident HWC images (asynchronous on the ctx stream) */
+int nlk_dev_rgb2opp(nlk_ctx *ctx, float *im, int w, int h, int ch);
+int nlk_dev_opp2rgb(nlk_ctx *ctx, float *im, int w, int h, int ch);
+int nlk_dev_warp_bicubic(nlk_ctx *ctx, float *imw, const float *im,
+                         const float *of, const float *msk, int w, int h, int ch);
+
+/* whole-frame hot path on device-resident images; deno0/bsic1 may be NULL */
+int nlk_dev_filter_frame(nlk_ctx *ctx, float *deno1, const float *nisy1,
+                         const float *deno0, const float *bsic1, int w, int h,
+                         int ch, float sigma, const struct nlkalman_params *prms);
+int nlk_dev_smooth_frame(nlk_ctx *ctx, float *smoo1, const float *filt1,
+                         const float *smoo0, const float *bsic1, int w, int h,
+                         int ch, float sigma, const struct nlkalman_params *prms);
+
+/* Row-strip form used by the multi-GPU driver. The images are a strip of the
+ * frame (h rows) that already contains the search halo; targets are the patch
+ * grid rows whose first image row is oy + j*step, j in [0, ngy). `acc` is a
+ * planar accumulator of (ch+1) planes of h*w floats (ch weighted sums, then
+ * the weights); it is ADDED to, so the caller zeroes it and may add the halo
+ * rows received from its neighbours before normalising.
+ * smoother != 0 selects the nlkalman_smooth_frame statistics and gain. */
+int nlk_dev_frame_accumulate(nlk_ctx *ctx, float *acc, const float *cur,
+                             const float *prev, const float *basic, int w, int h,
+                             int ch, float sigma,
+                             const struct nlkalman_params *prms, int oy, int ngy,
+                             int smoother);
+/* out[y][x][c] = acc_c / acc_w where acc_w > 1e-6, else cur (rows [y0, y1)) */
+int nlk_dev_frame_normalize(nlk_ctx *ctx, float *out, const float *acc,
+                            const float *cur, int w, int h, int ch, int y0, int y1);
+
+/* per-target records of the last frame call, copied to host (tests only):
+ * active[ngrid] (1 = processed), nsel/np0/nagg[ngrid], topk[ngrid*kmax] and
+ * gcoords[ngrid*gmax] packed as x | y << 16. Any pointer may be NULL. */
+int nlk_ctx_read_records(nlk_ctx *ctx, int *ngrid, int *kmax, int *gmax,
+                         unsigned char *active, int *nsel, int *np0, int *nagg,
+                         unsigned int *topk, unsigned int *gcoords);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NLK_HIP_H */
