@@ -107,16 +107,20 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
       acc[m] = 0.f;
     }
     const int tq = (py - ry0) * rwp + (px - rx0);
+    // one rounding per subtract, multiply and add (no FMA contraction): the
+    // CPU restatement is built with -ffp-contract=off and must rank identically
     for (int hy = 0; hy < g.psz; ++hy)
       for (int hx = 0; hx < g.psz; ++hx) {
         const int o = hy * rwp + hx;
         for (int c = 0; c < g.ch; ++c) {
+#pragma clang fp contract(off)
           const float tv = tile[c * plane + tq + o];
 #pragma unroll
           for (int m = 0; m < MAXM; ++m) {
             if (m * 64 < n) {  // wave-uniform
-              const float e = __fsub_rn(tile[c * plane + cq[m] + o], tv);
-              acc[m] = __fadd_rn(acc[m], __fmul_rn(e, e));
+              const float e = tile[c * plane + cq[m] + o] - tv;
+              const float e2 = e * e;
+              acc[m] = acc[m] + e2;
             }
           }
         }

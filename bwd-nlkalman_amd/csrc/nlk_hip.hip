@@ -38,8 +38,12 @@ struct nlk_ctx {
   int tabs_psz = 0;
   NlkGeom last{};
   bool have_last = false;
+  // profiling: one set of NEV events per frame call, read back (and averaged)
+  // only by nlk_ctx_get_timings, so the timed loop never synchronises
+  static constexpr int NEV = 7, MAXSETS = 512;
   bool profiling = false;
-  hipEvent_t ev[6] = {};
+  hipEvent_t* ev = nullptr;  // [MAXSETS][NEV], created lazily
+  int nsets = 0;             // completed + current
   nlk_timings tm{};
 };
 
@@ -189,8 +193,15 @@ int check_images(nlk_ctx* c, const void* out, const void* cur, int w, int h, int
   return NLK_OK;
 }
 
+// event i of the current frame call; event 0 opens a new set
 void mark(nlk_ctx* c, int i) {
-  if (c->profiling) hipEventRecord(c->ev[i], c->stream);
+  if (!c->profiling) return;
+  if (i == 0) {
+    if (c->nsets >= nlk_ctx::MAXSETS) return;
+    c->nsets++;
+  }
+  if (c->nsets < 1 || c->nsets > nlk_ctx::MAXSETS) return;
+  (void)hipEventRecord(c->ev[(c->nsets - 1) * nlk_ctx::NEV + i], c->stream);
 }
 
 }  // namespace
@@ -221,7 +232,6 @@ int nlk_ctx_create(nlk_ctx** out, int device) {
     return fail(nullptr, NLK_EHIP, "cannot create a stream on device %d", device);
   }
   c->stream = c->own_stream;
-  for (auto& e : c->ev) hipEventCreate(&e);
   *out = c;
   return NLK_OK;
 }
@@ -234,20 +244,47 @@ void nlk_ctx_destroy(nlk_ctx* c) {
                  &c->tinfo, &c->gcoords, &c->marks, &c->active, &c->acc, &c->tabs};
   for (Buf* b : bufs)
     if (b->p) hipFree(b->p);
-  for (auto& e : c->ev) hipEventDestroy(e);
-  hipStreamDestroy(c->own_stream);
+  if (c->ev) {
+    for (int i = 0; i < nlk_ctx::MAXSETS * nlk_ctx::NEV; ++i) (void)hipEventDestroy(c->ev[i]);
+    free(c->ev);
+  }
+  (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
 
 int nlk_ctx_set_profiling(nlk_ctx* c, int on) {
   if (!c) return NLK_EINVAL;
+  if (on && !c->ev) {
+    const int n = nlk_ctx::MAXSETS * nlk_ctx::NEV;
+    c->ev = (hipEvent_t*)calloc(n, sizeof(hipEvent_t));
+    if (!c->ev) return fail(c, NLK_ENOMEM, "event pool");
+    for (int i = 0; i < n; ++i) HIPCHK(c, hipEventCreate(&c->ev[i]));
+  }
   c->profiling = on != 0;
+  c->nsets = 0;  // (re)start averaging
   return NLK_OK;
 }
 
-int nlk_ctx_get_timings(const nlk_ctx* c, struct nlk_timings* t) {
+// averages over every frame call recorded since profiling was switched on
+int nlk_ctx_get_timings(nlk_ctx* c, struct nlk_timings* t) {
   if (!c || !t) return NLK_EINVAL;
-  *t = c->tm;
+  memset(t, 0, sizeof *t);
+  if (!c->ev || c->nsets == 0) return NLK_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int s = 0; s < c->nsets; ++s) {
+    hipEvent_t* e = c->ev + s * nlk_ctx::NEV;
+    const int a[6] = {0, 1, 2, 3, 5, 0}, b[6] = {1, 2, 3, 4, 6, 6};
+    for (int i = 0; i < 6; ++i) {
+      float ms = 0.f;
+      HIPCHK(c, hipEventElapsedTime(&ms, e[a[i]], e[b[i]]));
+      acc[i] += ms;
+    }
+  }
+  float* dst[6] = {&t->layout_ms, &t->match_ms, &t->commit_ms, &t->group_ms, &t->normalize_ms,
+                   &t->total_ms};
+  for (int i = 0; i < 6; ++i) *dst[i] = (float)(acc[i] / c->nsets);
+  c->tm = *t;
   return NLK_OK;
 }
 
@@ -435,9 +472,11 @@ int nlk_dev_frame_normalize(nlk_ctx* c, float* out, const float* acc, const floa
   int rc = check_images(c, out, cur, w, h, ch);
   if (rc) return rc;
   if (!acc || y0 < 0 || y1 > h || y0 > y1) return fail(c, NLK_EINVAL, "bad normalise range");
+  mark(c, 5);
   hipLaunchKernelGGL(k_normalize, dim3(2048), dim3(256), 0, c->stream, out, acc, cur, w, h, ch,
                      y0, y1);
   HIPCHK(c, hipGetLastError());
+  mark(c, 6);
   return NLK_OK;
 }
 
@@ -458,16 +497,7 @@ static int run_frame(nlk_ctx* c, float* out, const float* cur, const float* prev
                                 ngy, smoother);
   if (rc) return rc;
   rc = nlk_dev_frame_normalize(c, out, (const float*)c->acc.p, cur, w, h, ch, 0, h);
-  if (rc) return rc;
-  mark(c, 5);
-  if (c->profiling) {
-    HIPCHK(c, hipEventSynchronize(c->ev[5]));
-    float* dst[5] = {&c->tm.layout_ms, &c->tm.match_ms, &c->tm.commit_ms, &c->tm.group_ms,
-                     &c->tm.normalize_ms};
-    for (int i = 0; i < 5; ++i) hipEventElapsedTime(dst[i], c->ev[i], c->ev[i + 1]);
-    hipEventElapsedTime(&c->tm.total_ms, c->ev[0], c->ev[5]);
-  }
-  return NLK_OK;
+  return rc;
 }
 
 int nlk_dev_filter_frame(nlk_ctx* c, float* deno1, const float* nisy1, const float* deno0,

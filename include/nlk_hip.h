@@ -38,8 +38,8 @@ enum {
 
 typedef struct nlk_ctx nlk_ctx; /* one per (process, device): stream + scratch */
 
-/* per-kernel device time of the last frame call, milliseconds (HIP events on
- * the context's stream; filled only when profiling was enabled) */
+/* per-kernel device time of a frame call, milliseconds (HIP events recorded on
+ * the context's stream around each kernel; only when profiling is enabled) */
 struct nlk_timings {
   float layout_ms;    /* HWC -> planar copies + validity map */
   float match_ms;     /* block matching + k-NN selection */
@@ -54,7 +54,8 @@ int nlk_ctx_create(nlk_ctx **ctx, int device);
 void nlk_ctx_destroy(nlk_ctx *ctx);
 const char *nlk_last_error(const nlk_ctx *ctx); /* ctx may be NULL: last global error */
 int nlk_ctx_set_profiling(nlk_ctx *ctx, int on);
-int nlk_ctx_get_timings(const nlk_ctx *ctx, struct nlk_timings *t);
+/* mean over the frame calls made since nlk_ctx_set_profiling(ctx, 1); synchronises */
+int nlk_ctx_get_timings(nlk_ctx *ctx, struct nlk_timings *t);
 /* run the context's work on an externally owned hipStream_t (NULL = own stream) */
 int nlk_ctx_set_stream(nlk_ctx *ctx, void *hip_stream);
 void *nlk_ctx_get_stream(nlk_ctx *ctx);

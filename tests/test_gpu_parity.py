@@ -1,0 +1,201 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI libraries,
+against the CPU oracle on the same seeded inputs and against the committed
+golden fixtures.
+
+Tolerance (0..255 scale, opponent colour space): max-abs 2e-3, RMSE 2e-4 per
+stage — ten times the path's own FP noise floor of 2e-4 / 2.5e-5,
+and |dPSNR| <= 0.02 dB (BASELINE.json). Integer records (k-NN lists, group
+coordinates, np0, processed-mask decisions) must match EXACTLY."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _to_o(O, p):
+    return O.Params(*[getattr(p, k) for k, _ in p._fields_])
+
+
+def _dev_frame(ctx, smoother, cur, prev, basic, sigma, p):
+    h, w, ch = cur.shape
+    d = [ctx.upload(a) if a is not None else None for a in (cur, prev, basic)]
+    d_out = ctx.alloc(cur.nbytes)
+    fn = ctx.smooth_frame if smoother else ctx.filter_frame
+    fn(d_out, d[0], d[1], d[2], w, h, ch, sigma, p)
+    out = ctx.download(d_out, cur.shape)
+    rec = ctx.read_records()
+    for x in d + [d_out]:
+        if x:
+            ctx.free(x)
+    return out, rec
+
+
+def _check_records(rec, tr, what):
+    act_o, act_g = tr["active"].astype(bool), rec["active"].astype(bool)
+    assert np.array_equal(act_o, act_g), f"{what}: processed-mask decisions differ"
+    a = act_o
+    for f in ("nsel", "np0", "nagg"):
+        assert np.array_equal(tr[f][a], rec[f][a]), f"{what}: {f} differs"
+    k = tr["topk"].shape[1]
+    col = np.arange(k)[None, :]
+    live = a[:, None] & (col < tr["nsel"][:, None])
+    assert np.array_equal(tr["topk"][live], rec["topk"][:, :k].astype(np.int64)[live]), f"{what}: k-NN lists differ"
+    g = tr["gcoords"].shape[1]
+    col = np.arange(g)[None, :]
+    live = a[:, None] & (col < tr["nagg"][:, None])
+    assert np.array_equal(tr["gcoords"][live], rec["gcoords"][:, :g].astype(np.int64)[live]), f"{what}: group members differ"
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_pipeline_stagewise_vs_oracle_and_golden(built, O, name):
+    """Every stage of the 2-frame flt1 -> flt2 -> smo1 pipeline, through the
+    drop-in C API (libnlkalman.so), fed the oracle's previous-stage outputs."""
+    ref = cases.run_chain(O, name)
+    got = cases.run_chain_stagewise(built, ref, name)
+    for k in ("f1_0", "f2_0", "w1", "w2", "f1_1", "f2_1", "ws", "s1_0", "rgb_f2_1"):
+        cases.assert_close(got[k], ref[k], f"{name}/{k}")
+    with np.load(os.path.join(GOLD, name + ".npz")) as g:
+        for k in g.files:
+            cases.assert_close(got[k], g[k], f"golden {name}/{k}")
+
+
+@pytest.mark.parametrize("name", ["rgb96x64_s20", "gray70x53_ragged"])
+def test_pipeline_end_to_end_psnr(built, O, name):
+    """Free-running GPU pipeline (its own outputs feed the next stage)."""
+    ref, got = cases.run_chain(O, name), cases.run_chain(built, name)
+    clean = cases.inputs(name)["clean1"]
+    d = cases.synth.psnr(got["rgb_f2_1"], clean) - cases.synth.psnr(ref["rgb_f2_1"], clean)
+    assert abs(d) <= 0.02, d
+    cases.assert_close(got["s1_0"], ref["s1_0"], "s1_0 end-to-end", maxabs=5e-3, rmse=5e-4)
+
+
+@pytest.mark.parametrize("name,mode", [("rgb96x64_s20", "x"), ("rgb96x64_s20", "t"),
+                                       ("gray64_s20", "t2"), ("rgb84x60_p12_s40", "t"),
+                                       ("rgb72x48_s40", "s"), ("rgb40x40_p4", "x")])
+def test_integer_records_exact(ctx, built, O, name, mode):
+    """k-NN lists, group membership, np0 and mask decisions, bit for bit."""
+    I = cases.inputs(name)
+    s, over = I["sigma"], I["over"]
+    ref = cases.run_chain(O, name)
+    o0, o1 = O.rgb2opp(I["n0"]), O.rgb2opp(I["n1"])
+    if mode == "x":
+        p, args, smo = built.default_params(s, built.FLT1, **over), (o0, None, None), False
+    elif mode == "t":
+        p, args, smo = built.default_params(s, built.FLT1, **over), (o1, ref["w1"], None), False
+    elif mode == "t2":
+        p, args, smo = built.default_params(s, built.FLT2, **over), (o1, ref["w2"], ref["f1_1"]), False
+    else:
+        p, args, smo = built.default_params(s, built.SMO1), (ref["f2_0"], ref["ws"], None), True
+    fn = O.smooth_frame if smo else O.filter_frame
+    r, tr = fn(*args, s, _to_o(O, p), trace=True)
+    g, rec = _dev_frame(ctx, smo, *args, s, p)
+    _check_records(rec, tr, f"{name}/{mode}")
+    cases.assert_close(g, r, f"{name}/{mode}")
+
+
+def test_edge_cases(ctx, built, O):
+    rng = np.random.default_rng(5)
+    p = built.default_params(20.0, built.FLT1)
+    po = _to_o(O, p)
+    # single target, window = 1 candidate, k clamps to 1
+    im = rng.uniform(0, 255, (8, 8, 1)).astype(np.float32)
+    g, rec = _dev_frame(ctx, False, im, None, None, 20.0, p)
+    cases.assert_close(g, O.filter_frame(im, None, None, 20.0, po), "8x8")
+    # all-NaN previous frame: spatial branch everywhere, mask never marked
+    im = rng.uniform(0, 255, (20, 16, 3)).astype(np.float32)
+    prev = np.full_like(im, np.nan)
+    r, tr = O.filter_frame(im, prev, None, 20.0, po, trace=True)
+    g, rec = _dev_frame(ctx, False, im, prev, None, 20.0, p)
+    _check_records(rec, tr, "all-NaN prev")
+    cases.assert_close(g, r, "all-NaN prev")
+    ps = built.default_params(20.0, built.SMO1)
+    g, _ = _dev_frame(ctx, True, im, prev, None, 20.0, ps)
+    cases.assert_close(g, O.smooth_frame(im, prev, None, 20.0, _to_o(O, ps)), "smoother pass-through")
+    # flat image: every distance ties at zero -> raster tie-break must match
+    flat = np.full((24, 24, 1), 100.0, np.float32)
+    r, tr = O.filter_frame(flat, None, None, 20.0, po, trace=True)
+    g, rec = _dev_frame(ctx, False, flat, None, None, 20.0, p)
+    _check_records(rec, tr, "flat")
+    cases.assert_close(g, r, "flat")
+    # single NaN pixel in the previous frame + odd sizes + other patch sizes
+    for psz, (w, h, ch) in [(6, (37, 29, 1)), (10, (45, 33, 3)), (16, (50, 40, 1)), (8, (33, 47, 3))]:
+        im = rng.uniform(0, 255, (h, w, ch)).astype(np.float32)
+        prev = im + rng.normal(0, 5, im.shape).astype(np.float32)
+        prev[h // 2, w // 2, 0] = np.nan
+        pp = built.default_params(20.0, built.FLT1, patch_sz=psz, search_sz_x=6 if psz == 6 else 10)
+        r, tr = O.filter_frame(im, prev, None, 20.0, _to_o(O, pp), trace=True)
+        g, rec = _dev_frame(ctx, False, im, prev, None, 20.0, pp)
+        _check_records(rec, tr, f"psz{psz}")
+        cases.assert_close(g, r, f"psz{psz}")
+
+
+def test_unsupported_parameters_fail_loudly(ctx, built):
+    im = np.zeros((32, 32, 1), np.float32)
+    d, o = ctx.upload(im), ctx.alloc(im.nbytes)
+    with pytest.raises(built.NlkError, match="not supported"):
+        ctx.filter_frame(o, d, None, None, 32, 32, 1, 20.0, built.default_params(20.0, 0, patch_sz=7))
+    with pytest.raises(built.NlkError, match="reach"):
+        ctx.filter_frame(o, d, None, None, 32, 32, 1, 20.0,
+                         built.default_params(20.0, 0, patch_sz=4, search_sz_x=10))
+    ctx.free(d)
+    ctx.free(o)
+
+
+def test_strip_accumulate_equals_whole_frame(ctx, built):
+    """Row-strip form: accumulating the grid rows in two calls into one
+    accumulator, then normalising, reproduces the whole-frame call when the
+    processed-mask cannot couple the strips (FLT2: npatches_tagg = 1)."""
+    I = cases.inputs("rgb96x64_s20")
+    s = I["sigma"]
+    w, h, ch = I["w"], I["h"], I["ch"]
+    o1 = built.rgb2opp(I["n1"])
+    p = built.default_params(s, built.FLT2)
+    whole = built.filter_frame(o1, None, o1, s, p)
+    d_cur = ctx.upload(o1)
+    acc = ctx.upload(np.zeros((ch + 1, h, w), np.float32))
+    d_out = ctx.alloc(o1.nbytes)
+    step = p.patch_sz // 2
+    ngy = (h - p.patch_sz) // step + 1
+    half = ngy // 2
+    ctx.frame_accumulate(acc, d_cur, None, d_cur, w, h, ch, s, p, 0, half)
+    ctx.frame_accumulate(acc, d_cur, None, d_cur, w, h, ch, s, p, half * step, ngy - half)
+    ctx.frame_normalize(d_out, acc, d_cur, w, h, ch, 0, h)
+    got = ctx.download(d_out, o1.shape)
+    cases.assert_close(got, whole, "two strips vs whole")
+    for x in (d_cur, acc, d_out):
+        ctx.free(x)
+
+
+def test_full_size_1080p_against_oracle(ctx, built, O, synth):
+    """BASELINE.json configs[1] at full size: 1920x1080 RGB sigma=20 FLT1
+    temporal. The serial oracle needs ~25 s; mask decisions must be identical,
+    pixels within tolerance (a handful of 1e-6-threshold flips allowed)."""
+    w, h, ch, sigma = 1920, 1080, 3, 20.0
+    n0, n1, c1 = synth.noisy_pair(w, h, ch, sigma, 1)
+    o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+    p = built.default_params(sigma, built.FLT1)
+    prev, _ = _dev_frame(ctx, False, o0, None, None, sigma, p)
+    g, rec = _dev_frame(ctx, False, o1, prev, None, sigma, p)
+    r, tr = O.filter_frame(o1, prev, None, sigma, _to_o(O, p), trace=True)
+    assert np.array_equal(tr["active"].astype(bool), rec["active"].astype(bool))
+    assert 0.2 < 1 - tr["active"].mean() < 0.4          # ~30 % of targets are skipped
+    _check_records(rec, tr, "1080p")
+    cases.assert_close(g, r, "1080p", flips=40)
+    dpsnr = synth.psnr(built.opp2rgb(g), c1) - synth.psnr(O.opp2rgb(r), c1)
+    assert abs(dpsnr) <= 0.02
+    # size-independent property: a DC offset on every input shifts the output by it
+    off = np.float32(16.0)
+    prev2 = prev.copy()
+    prev2[..., 0] += off
+    o2 = o1.copy()
+    o2[..., 0] += off
+    g2, _ = _dev_frame(ctx, False, o2, prev2, None, sigma, p)
+    d = np.abs(g2[..., 0] - g[..., 0] - off)
+    # (adding the offset re-rounds the pixels, so a few near-tied k-NN ranks flip: quantiles)
+    assert np.quantile(d, 0.9999) < 2e-2
+    assert np.quantile(np.abs(g2[..., 1:] - g[..., 1:]), 0.9999) < 2e-2
