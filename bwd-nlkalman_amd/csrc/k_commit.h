@@ -5,44 +5,93 @@
 // In the reference a target is skipped when an EARLIER, non-skipped target's
 // group contained it. Whether a target is skipped therefore depends only on
 // integer records (group coordinates, np0) that the matching kernel already
-// produced for every target, not on any filtered pixel. A group reaches at most
-// R = max(wsz)/step grid cells, so the serial order can be replayed as a
+// produced for every target, not on any filtered pixel. A marking group
+// reaches at most R grid cells, so the serial order can be replayed as a
 // wavefront: target (i, j) is decided at time i + (R+1)*j, when every target
 // that can mark it has already been decided. One workgroup, one thread per
-// grid row, one barrier per time step; the mask lives in LDS as one bit per
-// grid target (only grid-aligned coordinates are ever tested).
+// grid row (RPT rows when the grid has more than 1024 rows), one barrier per
+// time step.
+//
+// The mask lives in LDS as one bit per grid target (only grid-aligned
+// coordinates are ever tested). Only FORWARD marks (targets later in raster
+// order) are applied: a bit is then only ever set by targets decided before
+// its owner, so the final bit array IS the skip decision and nothing is
+// written to HBM inside the loop.
 #pragma once
 #include "nlk_common.h"
 
+template <int RPT>  // grid rows per thread: row j = threadIdx.x + r * blockDim.x
 __global__ void __launch_bounds__(1024)
 k_mask_commit(const uint64_t* __restrict__ marks, uint8_t* __restrict__ active, int ngx,
               int ngy, int R) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   uint32_t* bits = (uint32_t*)smem;
-  const int nwords = (ngx * ngy + 31) / 32;
+  const int ntot = ngx * ngy;
+  const int nwords = (ntot + 31) / 32;
   for (int i = threadIdx.x; i < nwords; i += blockDim.x) bits[i] = 0;
   __syncthreads();
   const int side = 2 * R + 1;
-  const int nsteps = ngx + (R + 1) * (ngy - 1);
-  for (int s = 0; s < nsteps; ++s) {
-    for (int j = threadIdx.x; j < ngy; j += blockDim.x) {
-      const int i = s - (R + 1) * j;
-      if (i < 0 || i >= ngx) continue;
-      const int t = j * ngx + i;
-      const int done = (bits[t >> 5] >> (t & 31)) & 1;
-      active[t] = !done;
-      if (done) continue;
-      uint64_t m = marks[t];
-      while (m) {
-        const int b = __ffsll((unsigned long long)m) - 1;
-        m &= m - 1;
-        const int dj = b / side - R, di = b - (b / side) * side - R;
-        const int jj = j + dj, ii = i + di;
-        if (jj < 0 || jj >= ngy || ii < 0 || ii >= ngx) continue;
-        const int tt = jj * ngx + ii;
-        atomicOr(&bits[tt >> 5], 1u << (tt & 31));
+  const int skew = R + 1;
+  const int nsteps = ngx + skew * (ngy - 1);
+  auto fetch = [&](int j, int s) -> uint64_t {
+    const int i = s - skew * j;
+    return (j < ngy && i >= 0 && i < ngx) ? marks[(size_t)j * ngx + i] : 0ull;
+  };
+  // decide the targets of time step s; m = their mark words
+  auto decide = [&](int s, const uint64_t (&mw)[RPT]) {
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const int j = threadIdx.x + r * blockDim.x;
+      const int i = s - skew * j;
+      if (j < ngy && i >= 0 && i < ngx) {
+        const int t = j * ngx + i;
+        const bool done = (bits[t >> 5] >> (t & 31)) & 1u;
+        if (!done) {
+          uint64_t m = mw[r];
+          while (m) {
+            const int b = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            const int dj = b / side - R, di = b - (b / side) * side - R;
+            const int jj = j + dj, ii = i + di;
+            // forward marks only; a member outside this strip's rows is not a target here
+            if ((dj > 0 || (dj == 0 && di > 0)) && jj < ngy && ii >= 0 && ii < ngx) {
+              const int tt = jj * ngx + ii;
+              atomicOr(&bits[tt >> 5], 1u << (tt & 31));
+            }
+          }
+        }
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): LDS atomics issued; loads stay in flight
+    __builtin_amdgcn_s_barrier();
+  };
+  // The mark words of a row are consumed one per step. They are streamed in
+  // phases of S steps: while phase p is decided from registers A, the loads of
+  // phase p+1 into B are in flight, so no HBM latency sits between barriers.
+  constexpr int S = 16;
+  uint64_t A[RPT][S], B[RPT][S];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r)
+#pragma unroll
+    for (int e = 0; e < S; ++e) A[r][e] = fetch(threadIdx.x + r * blockDim.x, e);
+  for (int s0 = 0; s0 < nsteps; s0 += S) {
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+#pragma unroll
+      for (int e = 0; e < S; ++e) B[r][e] = fetch(threadIdx.x + r * blockDim.x, s0 + S + e);
+#pragma unroll
+    for (int e = 0; e < S; ++e) {
+      uint64_t mw[RPT];
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) mw[r] = A[r][e];
+      decide(s0 + e, mw);
+    }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+#pragma unroll
+      for (int e = 0; e < S; ++e) A[r][e] = B[r][e];
   }
+  __syncthreads();
+  for (int t = threadIdx.x; t < ntot; t += blockDim.x)
+    active[t] = !((bits[t >> 5] >> (t & 31)) & 1u);
 }

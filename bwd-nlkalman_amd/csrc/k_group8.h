@@ -1,0 +1,390 @@
+// k_group8.h — group processing for 8x8 patches, the register/DPP fast path
+// (reference: src/nlkalman.c:713-932 filter, :1603-1845 smoother).
+//
+// Layout. A wavefront processes one target at a time. Lane l = 16*c + 8*sel + u
+// holds ROW u of one 8x8 plane in 8 registers: channel c, sel = 0 the matching
+// image / the patch being filtered, sel = 1 the previous frame. (Lanes with
+// c >= CH idle.) With this layout
+//   * the row pass of the separable DCT is pure register arithmetic
+//     (even/odd split, 8 adds + 32 FMAs for 8 outputs),
+//   * the column pass crosses only the 8 lanes of a plane: lane u needs
+//     T[u ^ k], k = 0..7, which are the quad_perm / row_half_mirror DPP
+//     patterns, so it is 1 v_mov_dpp + 1 v_mul + 7 v_fmac per register, no LDS,
+//   * every DCT coefficient stays in the same (lane, register) for all
+//     candidates, so the Welford statistics, gains and shrinkage are
+//     lane-local; the only other cross-lane traffic is the partner exchange
+//     img <-> prev (lane ^ 8, DPP row_ror:8) for the transition variance.
+// Group members are re-transformed once the gains are known (two members per
+// step in the filter: one in the sel = 0 lanes, one in the sel = 1 lanes).
+//
+// Aggregation. A workgroup (4 wavefronts) owns a tile of 16 x 4 targets and
+// accumulates every weighted patch of its groups into an LDS tile (ch value
+// planes + 1 weight plane, covering the tile plus the search halo) with LDS
+// float atomics; the tile is flushed once with coalesced global float atomics,
+// skipping untouched entries. This cuts the HBM atomic traffic by ~16x compared
+// with one global atomic per patch pixel (MI355X global float atomics run at a
+// fixed ~1.3 TB/s of added bytes, which would otherwise bound the kernel).
+#pragma once
+#include "nlk_common.h"
+
+constexpr float NLK_C8[8][8] = {
+    {0.353553385f, 0.353553385f, 0.353553385f, 0.353553385f, 0.353553385f, 0.353553385f, 0.353553385f, 0.353553385f},
+    {0.490392625f, 0.415734798f, 0.277785122f, 0.0975451618f, -0.0975451618f, -0.277785122f, -0.415734798f, -0.490392625f},
+    {0.461939752f, 0.191341713f, -0.191341713f, -0.461939752f, -0.461939752f, -0.191341713f, 0.191341713f, 0.461939752f},
+    {0.415734798f, -0.0975451618f, -0.490392625f, -0.277785122f, 0.277785122f, 0.490392625f, 0.0975451618f, -0.415734798f},
+    {0.353553385f, -0.353553385f, -0.353553385f, 0.353553385f, 0.353553385f, -0.353553385f, -0.353553385f, 0.353553385f},
+    {0.277785122f, -0.490392625f, 0.0975451618f, 0.415734798f, -0.415734798f, -0.0975451618f, 0.490392625f, -0.277785122f},
+    {0.191341713f, -0.461939752f, 0.461939752f, -0.191341713f, -0.191341713f, 0.461939752f, -0.461939752f, 0.191341713f},
+    {0.0975451618f, -0.277785122f, 0.415734798f, -0.490392625f, 0.490392625f, -0.415734798f, 0.277785122f, -0.0975451618f},
+};
+
+struct NlkGTile {
+  int tgx, tgy, ntx, nty;
+  int rwp, rh_max;  // LDS accumulator region: row stride / rows
+  int wmax;         // reach of a group around its target
+};
+
+typedef float nlk_f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int CTRL>
+__device__ __forceinline__ float nlk_dpp(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+#define NLK_DPP_XOR1 0xB1   // quad_perm [1,0,3,2]
+#define NLK_DPP_XOR2 0x4E   // quad_perm [2,3,0,1]
+#define NLK_DPP_XOR3 0x1B   // quad_perm [3,2,1,0]
+#define NLK_DPP_HMIRROR 0x141  // lane u <- lane u ^ 7 inside each group of 8
+#define NLK_DPP_ROR8 0x128     // lane l <- lane l ^ 8 inside each row of 16
+
+// forward 1-D DCT-II of 8 registers (even/odd split)
+__device__ __forceinline__ void nlk_dct8_fwd(float (&p)[8]) {
+  float s[4], d[4], y[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { s[i] = p[i] + p[7 - i]; d[i] = p[i] - p[7 - i]; }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float* z = (k & 1) ? d : s;
+    float a = NLK_C8[k][0] * z[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) a = fmaf(NLK_C8[k][i], z[i], a);
+    y[k] = a;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) p[k] = y[k];
+}
+
+// inverse (DCT-III): x[i] = sum_k C[k][i] y[k]
+__device__ __forceinline__ void nlk_dct8_inv(float (&y)[8]) {
+  float E[4], O[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float e = NLK_C8[0][i] * y[0], o = NLK_C8[1][i] * y[1];
+#pragma unroll
+    for (int k = 2; k < 8; k += 2) { e = fmaf(NLK_C8[k][i], y[k], e); o = fmaf(NLK_C8[k + 1][i], y[k + 1], o); }
+    E[i] = e; O[i] = o;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { y[i] = E[i] + O[i]; y[7 - i] = E[i] - O[i]; }
+}
+
+// Column pass across the 8 lanes of a plane, four registers at a time:
+//   p_i[u] <- sum_k ck[k] * p_i[u ^ k]
+// hipcc (ROCm 7.2) does not fold update_dpp into the consuming FMA on gfx950, so
+// the DPP forms are written out: per register 1 v_mov_dpp (u ^ 7), 1 v_mul and
+// 7 v_fmac (6 of them DPP). The s_nop at both ends covers the "VALU write ->
+// DPP read, 2 wait states" hazard against the surrounding compiler code, which
+// does not see inside an asm statement.
+#define NLK_QP1 "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+#define NLK_QP2 "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+#define NLK_QP3 "quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf"
+#define NLK_HM "row_half_mirror row_mask:0xf bank_mask:0xf"
+
+__device__ __forceinline__ void nlk_col8x4(float& p0, float& p1, float& p2, float& p3,
+                                           const float (&ck)[8]) {
+  float y0, y1, y2, y3, m0, m1, m2, m3;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mov_b32_dpp %4, %8 " NLK_HM "\n\t"
+      "v_mov_b32_dpp %5, %9 " NLK_HM "\n\t"
+      "v_mov_b32_dpp %6, %10 " NLK_HM "\n\t"
+      "v_mov_b32_dpp %7, %11 " NLK_HM "\n\t"
+      "v_mul_f32 %0, %12, %8\n\t"
+      "v_mul_f32 %1, %12, %9\n\t"
+      "v_mul_f32 %2, %12, %10\n\t"
+      "v_mul_f32 %3, %12, %11\n\t"
+      "v_fmac_f32_dpp %0, %8, %13 " NLK_QP1 "\n\t"
+      "v_fmac_f32_dpp %1, %9, %13 " NLK_QP1 "\n\t"
+      "v_fmac_f32_dpp %2, %10, %13 " NLK_QP1 "\n\t"
+      "v_fmac_f32_dpp %3, %11, %13 " NLK_QP1 "\n\t"
+      "v_fmac_f32_dpp %0, %8, %14 " NLK_QP2 "\n\t"
+      "v_fmac_f32_dpp %1, %9, %14 " NLK_QP2 "\n\t"
+      "v_fmac_f32_dpp %2, %10, %14 " NLK_QP2 "\n\t"
+      "v_fmac_f32_dpp %3, %11, %14 " NLK_QP2 "\n\t"
+      "v_fmac_f32_dpp %0, %8, %15 " NLK_QP3 "\n\t"
+      "v_fmac_f32_dpp %1, %9, %15 " NLK_QP3 "\n\t"
+      "v_fmac_f32_dpp %2, %10, %15 " NLK_QP3 "\n\t"
+      "v_fmac_f32_dpp %3, %11, %15 " NLK_QP3 "\n\t"
+      "v_fmac_f32 %0, %4, %19\n\t"
+      "v_fmac_f32 %1, %5, %19\n\t"
+      "v_fmac_f32 %2, %6, %19\n\t"
+      "v_fmac_f32 %3, %7, %19\n\t"
+      "v_fmac_f32_dpp %0, %4, %18 " NLK_QP1 "\n\t"
+      "v_fmac_f32_dpp %1, %5, %18 " NLK_QP1 "\n\t"
+      "v_fmac_f32_dpp %2, %6, %18 " NLK_QP1 "\n\t"
+      "v_fmac_f32_dpp %3, %7, %18 " NLK_QP1 "\n\t"
+      "v_fmac_f32_dpp %0, %4, %17 " NLK_QP2 "\n\t"
+      "v_fmac_f32_dpp %1, %5, %17 " NLK_QP2 "\n\t"
+      "v_fmac_f32_dpp %2, %6, %17 " NLK_QP2 "\n\t"
+      "v_fmac_f32_dpp %3, %7, %17 " NLK_QP2 "\n\t"
+      "v_fmac_f32_dpp %0, %4, %16 " NLK_QP3 "\n\t"
+      "v_fmac_f32_dpp %1, %5, %16 " NLK_QP3 "\n\t"
+      "v_fmac_f32_dpp %2, %6, %16 " NLK_QP3 "\n\t"
+      "v_fmac_f32_dpp %3, %7, %16 " NLK_QP3 "\n\t"
+      "s_nop 1"
+      : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3), "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3)
+      : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(ck[0]), "v"(ck[1]), "v"(ck[2]), "v"(ck[3]),
+        "v"(ck[4]), "v"(ck[5]), "v"(ck[6]), "v"(ck[7]));
+  p0 = y0; p1 = y1; p2 = y2; p3 = y3;
+}
+
+__device__ __forceinline__ void nlk_dct8x8_fwd(float (&p)[8], const float (&ck)[8]) {
+  nlk_dct8_fwd(p);
+  nlk_col8x4(p[0], p[1], p[2], p[3], ck);
+  nlk_col8x4(p[4], p[5], p[6], p[7], ck);
+}
+__device__ __forceinline__ void nlk_dct8x8_inv(float (&p)[8], const float (&cik)[8]) {
+  nlk_col8x4(p[0], p[1], p[2], p[3], cik);
+  nlk_col8x4(p[4], p[5], p[6], p[7], cik);
+  nlk_dct8_inv(p);
+}
+
+__device__ __forceinline__ void nlk_load_row8(const float* __restrict__ p, float (&dst)[8]) {
+  const nlk_f4u a = *reinterpret_cast<const nlk_f4u*>(p);
+  const nlk_f4u b = *reinterpret_cast<const nlk_f4u*>(p + 4);
+  dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
+  dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
+}
+
+__device__ __forceinline__ float nlk_wave_sum8(float v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <int CH, bool SMO>
+__global__ void __launch_bounds__(256)
+k_group8(const float* __restrict__ img,   // matching / statistics image (planar)
+         const float* __restrict__ cur,   // image whose patches are filtered
+         const float* __restrict__ prev,  // previous output or nullptr
+         const uint8_t* __restrict__ vmap, NlkGeom g, NlkGTile tl,
+         const uint32_t* __restrict__ topk, const NlkTarget* __restrict__ tinfo,
+         const uint32_t* __restrict__ gcoords, const uint8_t* __restrict__ active,
+         const float* __restrict__ basis,   // [8][8] orthonormal DCT-II
+         const float* __restrict__ window,  // [8][8] aggregation window
+         float* __restrict__ acc) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [(CH+1)][rh_max][rwp]
+  constexpr int PSZ = 8, step = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile_x = blockIdx.x % tl.ntx, tile_y = blockIdx.x / tl.ntx;
+  const int gx0 = tile_x * tl.tgx, gy0 = tile_y * tl.tgy;
+  const int cx = min(tl.tgx, g.ngx - gx0), cy = min(tl.tgy, g.ngy - gy0);
+  const int rx0 = max(gx0 * step - tl.wmax, 0);
+  const int rx1 = min((gx0 + cx - 1) * step + tl.wmax + PSZ, g.w);
+  const int ry0 = max(g.oy + gy0 * step - tl.wmax, 0);
+  const int ry1 = min(g.oy + (gy0 + cy - 1) * step + tl.wmax + PSZ, g.h);
+  const int rw = rx1 - rx0, rh = ry1 - ry0;
+  const int rwp = tl.rwp, plane = rwp * tl.rh_max;
+  for (int i = threadIdx.x; i < (CH + 1) * plane; i += 256) smem[i] = 0.f;
+  __syncthreads();
+
+  // lane role
+  const int u = lane & 7, sel = (lane >> 3) & 1, c = lane >> 4;
+  const bool lane_on = c < CH;
+  const int cc = lane_on ? c : 0;
+  float ck[8], cik[8], wrow[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    ck[k] = basis[u * 8 + (u ^ k)];
+    cik[k] = basis[(u ^ k) * 8 + u];
+    wrow[k] = window[u * 8 + k];
+  }
+  const size_t npix = (size_t)g.w * g.h;
+  const float* img_c = img + cc * npix + (size_t)u * g.w;
+  const float* cur_c = cur + cc * npix + (size_t)u * g.w;
+  const float* prev_c = prev ? prev + cc * npix + (size_t)u * g.w : nullptr;
+  const float* src_c = g.have_basic ? cur_c : img_c;  // patches that get filtered
+  const float s2 = g.sigma2;
+
+  for (int tt = wave; tt < cx * cy; tt += 4) {
+    const int ty = tt / cx, tx = tt - ty * cx;
+    const int gx = gx0 + tx, gy = gy0 + ty;
+    const size_t t = (size_t)gy * g.ngx + gx;
+    if (!active[t]) continue;
+    const NlkTarget info = tinfo[t];
+    const int nagg = info.nagg;
+    if (nagg == 0) continue;
+    const bool prev_p = info.flags & 1;
+    const int k = info.nsel;
+
+    // ---------------- pass A: statistics over the k kept candidates
+    float mean[8], var[8], v01[8], m0[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) mean[r] = var[r] = v01[r] = m0[r] = 0.f;
+    int np0 = 0, np1 = 0;
+    float x[8], nxt[8];
+    bool vnext = false;
+    auto gatherA = [&](int i, float (&dst)[8], bool& v) {
+      const uint32_t q = topk[t * g.kmax + i];
+      const int org = nlk_y(q) * g.w + nlk_x(q);
+      v = prev_p && vmap[org];
+      if (lane_on && (sel == 0 || v)) nlk_load_row8((sel ? prev_c : img_c) + org, dst);
+      else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) dst[r] = 0.f;
+      }
+    };
+    if (k > 0) gatherA(0, nxt, vnext);
+    for (int i = 0; i < k; ++i) {
+      const bool v = vnext;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) x[r] = nxt[r];
+      if (i + 1 < k) gatherA(i + 1, nxt, vnext);
+      nlk_dct8x8_fwd(x, ck);
+      np1++;
+      if (v) np0++;
+      const float inv = sel ? (v ? 1.f / (float)np0 : 0.f) : 1.f / (float)np1;
+      const bool in_group = v && np0 <= g.ntagg;
+      const bool upd = lane_on && (sel == 0 || v);
+      float part[8];  // partner plane's coefficient (all lanes take part in the DPP)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) part[r] = nlk_dpp<NLK_DPP_ROR8>(x[r]);
+      if (upd) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const float d = x[r] - mean[r];
+          mean[r] = fmaf(d, inv, mean[r]);
+          var[r] = fmaf(d, x[r] - mean[r], var[r]);
+        }
+        if (sel) {  // previous-frame lanes (reference: :769-783, smoother :1659-1667)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const float tr = x[r] - part[r];
+            v01[r] = fmaf(tr, tr, v01[r]);
+          }
+          if (!SMO && in_group) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) m0[r] = fmaf(x[r] - m0[r], inv, m0[r]);
+          }
+        }
+      }
+    }
+
+    // ---------------- gains (reference: :799-811, :859-904; smoother :1683-1776)
+    // owner lanes hold the statistics the gain is made of: the previous-frame
+    // lanes when np0 > 0 (Kalman / smoother), the image lanes otherwise (Wiener)
+    const bool own = lane_on && (sel == (np0 > 0 ? 1 : 0));
+    float gain[8], mu[8];
+    float part_sum = 0.f;
+    {
+      const float in1 = np1 ? 1.f / (float)np1 : 0.f;
+      const float in0 = np0 ? 1.f / (float)np0 : 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float vn = var[r] * (sel ? in0 : in1);    // V0 (sel=1) or V1 (sel=0)
+        const float v01n = v01[r] * in0;
+        const float v1p = nlk_dpp<NLK_DPP_ROR8>(vn);    // V1 seen from the previous-frame lanes
+        float a, term, m;
+        if (SMO) {
+          a = v1p / (v1p + g.beta_t * v01n);
+          const float pv = vn - g.beta_t * v01n;
+          term = (1 - a * a) * v1p + a * a * (pv > 0.f ? pv : 0.f);
+          m = 0.f;
+        } else if (np0 > 0) {
+          const float d = v01n - (g.have_basic ? 0.f : s2);
+          const float v = vn + (0.f > d ? 0.f : d);
+          a = v / (v + g.beta_t * s2);
+          term = (1 - a * a) * v + a * a * s2;
+          m = m0[r];
+        } else {
+          const float d = vn - (g.have_basic ? 0.f : s2);
+          const float v = 0.f > d ? 0.f : d;
+          a = v / (v + g.beta_x * s2);
+          term = a * v;
+          m = mean[r];
+        }
+        if (own) part_sum += term;
+        // make gain and mean available in both lane groups of the channel
+        const float a_o = nlk_dpp<NLK_DPP_ROR8>(a), m_o = nlk_dpp<NLK_DPP_ROR8>(m);
+        gain[r] = own ? a : a_o;
+        mu[r] = own ? m : m_o;
+      }
+    }
+    // the reference adds the same per-coefficient terms once per group member
+    float vp = nlk_wave_sum8(part_sum) * (float)nagg;
+    const bool passthrough = SMO && np0 == 0;  // reference: :1795-1804
+    if (passthrough) vp = 0.f;
+    const float wgt = 1.f / (vp > 1e-6f ? vp : 1e-6f);
+
+    // ---------------- pass B: shrink, invert and aggregate the group members
+    if (!SMO) {
+      for (int n0 = 0; n0 < nagg; n0 += 2) {
+        const int n = n0 + sel;
+        const bool has = lane_on && n < nagg;
+        const uint32_t q = gcoords[t * g.gstride + (has ? n : n0)];
+        const int qx = nlk_x(q), qy = nlk_y(q);
+        if (has) nlk_load_row8(src_c + qy * g.w + qx, x);
+        nlk_dct8x8_fwd(x, ck);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = gain[r] * x[r] + (1 - gain[r]) * mu[r];
+        nlk_dct8x8_inv(x, cik);
+        if (has) {
+          float* dst = smem + cc * plane + (qy - ry0 + u) * rwp + (qx - rx0);
+          float* dw = smem + CH * plane + (qy - ry0 + u) * rwp + (qx - rx0);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const float ww = wgt * wrow[r];
+            atomicAdd(dst + r, ww * x[r]);
+            if (c == 0) atomicAdd(dw + r, ww);
+          }
+        }
+      }
+    } else {
+      for (int n = 0; n < nagg; ++n) {
+        const uint32_t q = gcoords[t * g.gstride + n];
+        const int qx = nlk_x(q), qy = nlk_y(q);
+        const bool ld = lane_on && (sel == 0 || !passthrough);
+        if (ld) nlk_load_row8((sel ? prev_c : src_c) + qy * g.w + qx, x);
+        if (!passthrough) {
+          nlk_dct8x8_fwd(x, ck);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const float y0 = nlk_dpp<NLK_DPP_ROR8>(x[r]);  // previous-frame coefficient
+            x[r] = (1 - gain[r]) * x[r] + gain[r] * y0;    // reference: :1775
+          }
+          nlk_dct8x8_inv(x, cik);
+        }
+        if (lane_on && sel == 0) {
+          float* dst = smem + cc * plane + (qy - ry0 + u) * rwp + (qx - rx0);
+          float* dw = smem + CH * plane + (qy - ry0 + u) * rwp + (qx - rx0);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const float ww = wgt * wrow[r];
+            atomicAdd(dst + r, ww * x[r]);
+            if (c == 0) atomicAdd(dw + r, ww);
+          }
+        }
+      }
+    }
+  }
+
+  // ---------------- flush the tile accumulator (coalesced rows, skip untouched)
+  __syncthreads();
+  for (int p = 0; p <= CH; ++p)
+    for (int y = wave; y < rh; y += 4) {
+      const float* srow = smem + p * plane + y * rwp;
+      float* drow = acc + (size_t)p * npix + (size_t)(ry0 + y) * g.w + rx0;
+      for (int xx = lane; xx < rw; xx += 64) {
+        const float v = srow[xx];
+        if (v != 0.f) unsafeAtomicAdd(drow + xx, v);
+      }
+    }
+}

@@ -5,11 +5,18 @@
 // One workgroup owns a tile of TGX x TGY grid targets and stages the part of
 // the matching image those targets can reach (patches + search halo) in LDS,
 // planar per channel, with coalesced row reads from HBM. One wavefront
-// processes one target at a time: lane = candidate. The squared distance is
-// accumulated in the reference's element order (hy, hx, c) with one rounding
-// per multiply and per add, so that the ranking is reproducible bit for bit by
-// the CPU oracle. Selection is by rank counting on the (distance, window index)
-// key, which is exactly a stable ascending sort's prefix.
+// processes one target at a time: lane = candidate (lane + 64*m for the m-th
+// round). The squared distance is accumulated in the reference's element order
+// (hy, hx, c) with one rounding per subtract, multiply and add, so that the
+// ranking is reproducible bit for bit by the CPU restatement. The LDS row
+// stride is chosen so that the 64 candidate reads of a wavefront are
+// bank-conflict free for the dominant window width.
+//
+// Selection = exact k smallest under the (distance, window index) order, which
+// is the prefix of the reference's stable ascending sort: a 32-step bitwise
+// radix select on the float bits finds the k-th distance in registers
+// (ballot + popcount, no LDS), ties are cut in window order, and only the k
+// survivors are ranked against each other to produce the sorted list.
 #pragma once
 #include "nlk_common.h"
 
@@ -17,10 +24,10 @@
 #define NLK_BM_WAVES (NLK_BM_THREADS / 64)
 
 struct NlkTile {
-  int tgx, tgy;      // targets per tile
-  int ntx, nty;      // tiles
-  int rw_max, rh_max; // LDS region capacity (floats per row / rows)
-  int ncand_max;     // capacity of the per-wave distance / selection arrays
+  int tgx, tgy;       // targets per tile
+  int ntx, nty;       // tiles
+  int rwp, rh_max;    // LDS region: padded row stride (floats) / rows
+  int ksel_max;       // capacity of the per-wave survivor arrays
 };
 
 __device__ inline uint64_t nlk_wave_or(uint64_t v) {
@@ -32,7 +39,110 @@ __device__ inline uint64_t nlk_wave_or(uint64_t v) {
   return v;
 }
 
-template <int MAXM>
+__device__ inline void nlk_wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Distances + selection for one target whose window holds n <= 64*M candidates.
+// Leaves the k kept candidates, sorted, in sel[0..k).
+template <int PSZ, int CH, int M>
+__device__ inline void nlk_match_target(const float* __restrict__ tile, int plane, int rwp,
+                                        int tq, int cbase, int nwx, int n, int k, int x0, int y0,
+                                        uint32_t* __restrict__ skey, uint32_t* __restrict__ sidx,
+                                        uint32_t* __restrict__ sel, int lane) {
+  int cq[M];
+  float acc[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int i = min(lane + 64 * m, n - 1);
+    const int wy = i / nwx, wx = i - wy * nwx;
+    cq[m] = cbase + wy * rwp + wx;
+    acc[m] = 0.f;
+  }
+#pragma unroll 1
+  for (int hy = 0; hy < PSZ; ++hy) {
+#pragma clang fp contract(off)
+    const float* trow = tile + tq + hy * rwp;
+#pragma unroll
+    for (int hx = 0; hx < PSZ; ++hx)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const float tv = trow[c * plane + hx];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          const float e = tile[c * plane + cq[m] + hy * rwp + hx] - tv;
+          const float e2 = e * e;
+          acc[m] = acc[m] + e2;
+        }
+      }
+  }
+  uint32_t key[M];
+  bool ok[M];
+  const float norm = (float)(PSZ * PSZ * CH);
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const float q = acc[m] / norm;  // IEEE division (reference: src/nlkalman.c:701)
+    key[m] = __float_as_uint(q > 0.f ? q : 0.f);
+    ok[m] = lane + 64 * m < n;
+  }
+
+  // --- k-th smallest distance by bitwise radix select (keys are >= +0: uint order)
+  uint32_t prefix = 0;
+  int kk = k;
+#pragma unroll 1
+  for (int b = 31; b >= 0; --b) {
+    const uint32_t hi = (b == 31) ? 0u : (0xFFFFFFFFu << (b + 1));
+    int cnt0 = 0;
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+      cnt0 += __popcll(__ballot(ok[m] && (key[m] & hi) == prefix && !((key[m] >> b) & 1u)));
+    if (kk > cnt0) {
+      prefix |= 1u << b;
+      kk -= cnt0;
+    }
+  }
+  // prefix = k-th smallest key; kk = how many of the keys equal to it are kept
+  // (in window order, i.e. by ascending candidate index)
+  int ntie = 0, npos = 0;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const bool eq = ok[m] && key[m] == prefix;
+    const uint64_t be = __ballot(eq);
+    const int my_tie = ntie + __popcll(be & lt_mask);
+    ntie += __popcll(be);
+    const bool keep = ok[m] && (key[m] < prefix || (eq && my_tie < kk));
+    const uint64_t bk = __ballot(keep);
+    if (keep) {
+      const int pos = npos + __popcll(bk & lt_mask);
+      skey[pos] = key[m];
+      sidx[pos] = lane + 64 * m;
+    }
+    npos += __popcll(bk);
+  }
+  nlk_wave_lds_fence();
+
+  // --- rank the k survivors among themselves
+  for (int base = 0; base < k; base += 64) {
+    const int p = base + lane;
+    const uint32_t mk = p < k ? skey[p] : 0xFFFFFFFFu;
+    const uint32_t mi = p < k ? sidx[p] : 0xFFFFFFFFu;
+    int rank = 0;
+    for (int j = 0; j < k; ++j) {
+      const uint32_t kj = skey[j], ij = sidx[j];
+      rank += (kj < mk) || (kj == mk && ij < mi);
+    }
+    if (p < k) {
+      const int wy = mi / nwx, wx = mi - wy * nwx;
+      sel[rank] = nlk_pack_xy(x0 + wx, y0 + wy);
+    }
+  }
+  nlk_wave_lds_fence();
+}
+
+template <int PSZ, int CH, int MAXM>
 __global__ void __launch_bounds__(NLK_BM_THREADS)
 k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGeom g,
           NlkTile tl, uint32_t* __restrict__ topk, NlkTarget* __restrict__ tinfo,
@@ -44,38 +154,42 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
   const int cx = min(tl.tgx, g.ngx - gx0), cy = min(tl.tgy, g.ngy - gy0);
   const int wmax = g.smoother ? g.wsz_t
                               : (g.have_prev ? max(g.wsz_x, g.wsz_t) : g.wsz_x);
+  constexpr int step = PSZ / 2;
 
   // image region reachable from this tile
-  const int rx0 = max(gx0 * g.step - wmax, 0);
-  const int rx1 = min((gx0 + cx - 1) * g.step + wmax + g.psz, g.w);
-  const int ry0 = max(g.oy + gy0 * g.step - wmax, 0);
-  const int ry1 = min(g.oy + (gy0 + cy - 1) * g.step + wmax + g.psz, g.h);
+  const int rx0 = max(gx0 * step - wmax, 0);
+  const int rx1 = min((gx0 + cx - 1) * step + wmax + PSZ, g.w);
+  const int ry0 = max(g.oy + gy0 * step - wmax, 0);
+  const int ry1 = min(g.oy + (gy0 + cy - 1) * step + wmax + PSZ, g.h);
   const int rw = rx1 - rx0, rh = ry1 - ry0;
-  const int rwp = tl.rw_max;  // padded row stride (odd)
+  const int rwp = tl.rwp;
   const int plane = rwp * tl.rh_max;
 
-  float* tile = smem;                                   // [ch][rh_max][rwp]
-  uint32_t* dist_all = (uint32_t*)(tile + g.ch * plane); // [waves][ncand_max]
-  uint32_t* sel_all = dist_all + NLK_BM_WAVES * tl.ncand_max;
-  uint32_t* grp_all = sel_all + NLK_BM_WAVES * tl.ncand_max; // [waves][gstride]
+  float* tile = smem;                                  // [CH][rh_max][rwp]
+  uint32_t* skey_all = (uint32_t*)(tile + CH * plane);  // [waves][ksel_max]
+  uint32_t* sidx_all = skey_all + NLK_BM_WAVES * tl.ksel_max;
+  uint32_t* sel_all = sidx_all + NLK_BM_WAVES * tl.ksel_max;
+  uint32_t* grp_all = sel_all + NLK_BM_WAVES * tl.ksel_max;  // [waves][gstride]
 
   const size_t npix = (size_t)g.w * g.h;
-  for (int c = 0; c < g.ch; ++c)
-    for (int i = threadIdx.x; i < rw * rh; i += NLK_BM_THREADS) {
-      const int y = i / rw, x = i - y * rw;
-      tile[c * plane + y * rwp + x] = img[c * npix + (size_t)(ry0 + y) * g.w + rx0 + x];
+  for (int y = wave; y < rh; y += NLK_BM_WAVES)
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const float* src = img + c * npix + (size_t)(ry0 + y) * g.w + rx0;
+      float* dst = tile + c * plane + y * rwp;
+      for (int x = lane; x < rw; x += 64) dst[x] = src[x];
     }
   __syncthreads();
 
-  uint32_t* dl = dist_all + wave * tl.ncand_max;
-  uint32_t* sel = sel_all + wave * tl.ncand_max;
+  uint32_t* skey = skey_all + wave * tl.ksel_max;
+  uint32_t* sidx = sidx_all + wave * tl.ksel_max;
+  uint32_t* sel = sel_all + wave * tl.ksel_max;
   uint32_t* grp = grp_all + wave * g.gstride;
-  const float norm = (float)g.psz * g.psz * g.ch;
 
   for (int tt = wave; tt < cx * cy; tt += NLK_BM_WAVES) {
     const int ty = tt / cx, tx = tt - ty * cx;
     const int gx = gx0 + tx, gy = gy0 + ty;
-    const int px = gx * g.step, py = g.oy + gy * g.step;
+    const int px = gx * step, py = g.oy + gy * step;
     const size_t t = (size_t)gy * g.ngx + gx;
     const int prev_p = g.have_prev ? vmap[(size_t)py * g.w + px] : 0;
     int k = prev_p ? g.npt : g.npx;
@@ -91,73 +205,21 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
       continue;
     }
     const int wsz = (g.smoother || prev_p) ? g.wsz_t : g.wsz_x;
-    const int x0 = max(px - wsz, 0), x1 = min(px + wsz, g.w - g.psz) + 1;
-    const int y0 = max(py - wsz, 0), y1 = min(py + wsz, g.h - g.psz) + 1;
+    const int x0 = max(px - wsz, 0), x1 = min(px + wsz, g.w - PSZ) + 1;
+    const int y0 = max(py - wsz, 0), y1 = min(py + wsz, g.h - PSZ) + 1;
     const int nwx = x1 - x0, n = nwx * (y1 - y0);
     k = min(k, n);
-
-    // --- distances: lane owns candidates lane, lane+64, ...
-    int cq[MAXM];    // LDS offset of the candidate's origin inside a plane
-    float acc[MAXM];
-#pragma unroll
-    for (int m = 0; m < MAXM; ++m) {
-      const int i = min(lane + 64 * m, n - 1);
-      const int wy = i / nwx, wx = i - wy * nwx;
-      cq[m] = (y0 + wy - ry0) * rwp + (x0 + wx - rx0);
-      acc[m] = 0.f;
-    }
     const int tq = (py - ry0) * rwp + (px - rx0);
-    // one rounding per subtract, multiply and add (no FMA contraction): the
-    // CPU restatement is built with -ffp-contract=off and must rank identically
-    for (int hy = 0; hy < g.psz; ++hy)
-      for (int hx = 0; hx < g.psz; ++hx) {
-        const int o = hy * rwp + hx;
-        for (int c = 0; c < g.ch; ++c) {
-#pragma clang fp contract(off)
-          const float tv = tile[c * plane + tq + o];
-#pragma unroll
-          for (int m = 0; m < MAXM; ++m) {
-            if (m * 64 < n) {  // wave-uniform
-              const float e = tile[c * plane + cq[m] + o] - tv;
-              const float e2 = e * e;
-              acc[m] = acc[m] + e2;
-            }
-          }
-        }
-      }
-    uint32_t dk[MAXM];
-#pragma unroll
-    for (int m = 0; m < MAXM; ++m) {
-      const float q = __fdiv_rn(acc[m], norm);
-      dk[m] = __float_as_uint(q > 0.f ? q : 0.f);
-      if (lane + 64 * m < n) dl[lane + 64 * m] = dk[m];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): LDS writes of this wave landed
-    __builtin_amdgcn_wave_barrier();
-
-    // --- rank of every candidate under the (distance, index) order
-    int rank[MAXM];
-#pragma unroll
-    for (int m = 0; m < MAXM; ++m) rank[m] = 0;
-    for (int j = 0; j < n; ++j) {
-      const uint32_t dj = dl[j];
-#pragma unroll
-      for (int m = 0; m < MAXM; ++m)
-        if (m * 64 < n)
-          rank[m] += (dj < dk[m]) || (dj == dk[m] && j < lane + 64 * m);
-    }
-#pragma unroll
-    for (int m = 0; m < MAXM; ++m) {
-      const int i = lane + 64 * m;
-      if (i < n && rank[m] < k) {
-        const int wy = i / nwx, wx = i - wy * nwx;
-        sel[rank[m]] = nlk_pack_xy(x0 + wx, y0 + wy);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
+    const int cbase = (y0 - ry0) * rwp + (x0 - rx0);
+    if (n <= 128)
+      nlk_match_target<PSZ, CH, 2>(tile, plane, rwp, tq, cbase, nwx, n, k, x0, y0, skey, sidx,
+                                   sel, lane);
+    else if (MAXM <= 7 || n <= 448)
+      nlk_match_target<PSZ, CH, (MAXM < 7 ? MAXM : 7)>(tile, plane, rwp, tq, cbase, nwx, n, k,
+                                                       x0, y0, skey, sidx, sel, lane);
+    else
+      nlk_match_target<PSZ, CH, MAXM>(tile, plane, rwp, tq, cbase, nwx, n, k, x0, y0, skey,
+                                      sidx, sel, lane);
 
     // --- group membership: the first ntagg kept candidates that have a valid
     // previous patch, or (none valid) the first ntagg kept candidates
@@ -176,9 +238,7 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
       if (v && slot < g.ntagg) grp[slot] = q;
       np0 += __popcll(b);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
+    nlk_wave_lds_fence();
 
     int nagg, mark;
     if (g.smoother) {
@@ -196,8 +256,8 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
         const uint32_t q = np0 ? grp[i] : sel[i];
         gcoords[t * g.gstride + i] = q;
         const int dx = nlk_x(q) - px, dy = nlk_y(q) - py;
-        if (mark && dx % g.step == 0 && dy % g.step == 0) {
-          const int di = dx / g.step, dj = dy / g.step;
+        if (mark && dx % step == 0 && dy % step == 0) {
+          const int di = dx / step, dj = dy / step;
           mbits |= 1ull << ((dj + g.R) * side + di + g.R);
         }
       }

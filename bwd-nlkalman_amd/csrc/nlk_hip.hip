@@ -15,6 +15,7 @@
 #include "k_commit.h"
 #include "k_frame.h"
 #include "k_group.h"
+#include "k_group8.h"
 #include "k_match.h"
 #include "nlk_common.h"
 
@@ -151,17 +152,49 @@ int launch_group_ch(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
   return fail(c, NLK_EUNSUP, "patch size %d not supported (4, 6, 8, 10, 12, 16)", g.psz);
 }
 
+template <int CH, bool SMO>
+int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
+                    const float* prev, float* acc) {
+  NlkGTile tl{};
+  tl.tgx = 16; tl.tgy = 4;
+  tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
+  tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
+  tl.wmax = g.smoother ? g.wsz_t : (g.have_prev ? max(g.wsz_x, g.wsz_t) : g.wsz_x);
+  tl.rwp = ((tl.tgx - 1) * g.step + 2 * tl.wmax + g.psz) | 1;
+  tl.rh_max = (tl.tgy - 1) * g.step + 2 * tl.wmax + g.psz;
+  const size_t lds = sizeof(float) * (size_t)(CH + 1) * tl.rwp * tl.rh_max;
+  if (lds > 160 * 1024) return fail(c, NLK_EUNSUP, "aggregation tile needs %zu bytes of LDS", lds);
+  auto kern = k_group8<CH, SMO>;
+  HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+  const float* basis = (const float*)c->tabs.p;
+  hipLaunchKernelGGL(kern, dim3(tl.ntx * tl.nty), dim3(256), lds, c->stream, img, cur, prev,
+                     (const uint8_t*)c->vmap.p, g, tl, (const uint32_t*)c->topk.p,
+                     (const NlkTarget*)c->tinfo.p, (const uint32_t*)c->gcoords.p,
+                     (const uint8_t*)c->active.p, basis, basis + 64, acc);
+  HIPCHK(c, hipGetLastError());
+  return NLK_OK;
+}
+
 int launch_group(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
                  const float* prev, float* acc) {
+  if (g.psz == 8 && !getenv("NLK_GENERIC_GROUP")) {  // register/DPP fast path
+    if (g.ch == 1)
+      return g.smoother ? launch_group8_t<1, true>(c, g, img, cur, prev, acc)
+                        : launch_group8_t<1, false>(c, g, img, cur, prev, acc);
+    if (g.ch == 3)
+      return g.smoother ? launch_group8_t<3, true>(c, g, img, cur, prev, acc)
+                        : launch_group8_t<3, false>(c, g, img, cur, prev, acc);
+  }
   if (g.ch == 1) return launch_group_ch<1>(c, g, img, cur, prev, acc);
   if (g.ch == 3) return launch_group_ch<3>(c, g, img, cur, prev, acc);
   return fail(c, NLK_EUNSUP, "%d channels not supported (1 or 3)", g.ch);
 }
 
-template <int MAXM>
+template <int PSZ, int CH, int MAXM>
 int launch_match_t(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds,
                    const float* img) {
-  auto kern = k_bm_topk<MAXM>;
+  auto kern = k_bm_topk<PSZ, CH, MAXM>;
   HIPCHK(c, hipFuncSetAttribute((const void*)kern,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(tl.ntx * tl.nty), dim3(NLK_BM_THREADS), lds, c->stream, img,
@@ -169,6 +202,35 @@ int launch_match_t(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds,
                      (NlkTarget*)c->tinfo.p, (uint32_t*)c->gcoords.p, (uint64_t*)c->marks.p);
   HIPCHK(c, hipGetLastError());
   return NLK_OK;
+}
+
+template <int PSZ, int CH>
+int launch_match_m(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds,
+                   const float* img, int maxm) {
+  if (maxm <= 2) return launch_match_t<PSZ, CH, 2>(c, g, tl, lds, img);
+  if (maxm <= 7) return launch_match_t<PSZ, CH, 7>(c, g, tl, lds, img);
+  return launch_match_t<PSZ, CH, 16>(c, g, tl, lds, img);
+}
+
+template <int CH>
+int launch_match_ch(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds,
+                    const float* img, int maxm) {
+  switch (g.psz) {
+    case 4: return launch_match_m<4, CH>(c, g, tl, lds, img, maxm);
+    case 6: return launch_match_m<6, CH>(c, g, tl, lds, img, maxm);
+    case 8: return launch_match_m<8, CH>(c, g, tl, lds, img, maxm);
+    case 10: return launch_match_m<10, CH>(c, g, tl, lds, img, maxm);
+    case 12: return launch_match_m<12, CH>(c, g, tl, lds, img, maxm);
+    case 16: return launch_match_m<16, CH>(c, g, tl, lds, img, maxm);
+  }
+  return fail(c, NLK_EUNSUP, "patch size %d not supported (4, 6, 8, 10, 12, 16)", g.psz);
+}
+
+int launch_match(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds, const float* img,
+                 int maxm) {
+  if (g.ch == 1) return launch_match_ch<1>(c, g, tl, lds, img, maxm);
+  if (g.ch == 3) return launch_match_ch<3>(c, g, tl, lds, img, maxm);
+  return fail(c, NLK_EUNSUP, "%d channels not supported (1 or 3)", g.ch);
 }
 
 int to_planar(nlk_ctx* c, Buf& dst, const float* src, int npix, int ch, const float** out) {
@@ -390,10 +452,14 @@ int nlk_dev_frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const flo
   g.sigma2 = sigma * sigma;
   g.beta_x = P->beta_x; g.beta_t = P->beta_t;
   const int wmax = g.smoother ? g.wsz_t : (g.have_prev ? max(g.wsz_x, g.wsz_t) : g.wsz_x);
-  g.R = wmax / g.step;
+  // reach (in grid cells) of the groups that mark the processed-mask: in a
+  // temporal frame only groups with a valid previous patch mark (reference: :931)
+  // and those searched with the temporal radius (reference: :637)
+  const int wmark = (g.smoother || g.have_prev) ? g.wsz_t : g.wsz_x;
+  g.R = wmark / g.step;
   if (g.R > 3)
     return fail(c, NLK_EUNSUP, "search radius %d with patch size %d: group reach %d grid cells > 3",
-                wmax, g.psz, g.R);
+                wmark, g.psz, g.R);
   const int ncand = (2 * wmax + 1) * (2 * wmax + 1);
   if (ncand > 64 * 16) return fail(c, NLK_EUNSUP, "search radius %d too large (max 15)", wmax);
   g.kmax = max(max(g.npx, g.npt), 1);
@@ -432,28 +498,34 @@ int nlk_dev_frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const flo
   tl.tgx = 16; tl.tgy = 4;
   tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
   tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
-  tl.rw_max = ((tl.tgx - 1) * g.step + 2 * wmax + g.psz) | 1;
+  // LDS row stride = window width (mod 32): candidate i of a window then sits
+  // on bank i mod 32, so a wavefront's 64 candidate reads are conflict free
+  {
+    const int need = (tl.tgx - 1) * g.step + 2 * wmax + g.psz;
+    const int wdom = 2 * ((g.smoother || g.have_prev) ? g.wsz_t : g.wsz_x) + 1;
+    tl.rwp = need + ((wdom - need) % 32 + 32) % 32;
+  }
   tl.rh_max = (tl.tgy - 1) * g.step + 2 * wmax + g.psz;
-  tl.ncand_max = ncand;
-  const size_t lds = sizeof(float) * ((size_t)ch * tl.rw_max * tl.rh_max +
-                                      (size_t)NLK_BM_WAVES * (2 * ncand + ntagg_alloc));
+  tl.ksel_max = g.kmax;
+  const size_t lds = sizeof(float) * ((size_t)ch * tl.rwp * tl.rh_max +
+                                      (size_t)NLK_BM_WAVES * (3 * tl.ksel_max + ntagg_alloc));
   if (lds > 160 * 1024)
     return fail(c, NLK_EUNSUP, "matching tile needs %zu bytes of LDS (> 160 KiB)", lds);
-  const int maxm = (ncand + 63) / 64;
-  if (maxm <= 2) rc = launch_match_t<2>(c, g, tl, lds, img_match);
-  else if (maxm <= 7) rc = launch_match_t<7>(c, g, tl, lds, img_match);
-  else rc = launch_match_t<16>(c, g, tl, lds, img_match);
+  rc = launch_match(c, g, tl, lds, img_match, (ncand + 63) / 64);
   if (rc) return rc;
   mark(c, 2);
 
   // ---- processed-mask replay
   {
+    const int rpt = (g.ngy + 1023) / 1024;
     const int threads = min(1024, ((g.ngy + 63) / 64) * 64);
     const size_t bits = sizeof(uint32_t) * ((size_t)(ngrid + 31) / 32);
-    if (bits > 160 * 1024) return fail(c, NLK_EUNSUP, "patch grid too large for the mask replay");
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_mask_commit,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bits));
-    hipLaunchKernelGGL(k_mask_commit, dim3(1), dim3(threads), bits, c->stream,
+    if (bits > 160 * 1024 || rpt > 4)
+      return fail(c, NLK_EUNSUP, "patch grid %dx%d too large for the mask replay", g.ngx, g.ngy);
+    auto kern = rpt == 1 ? k_mask_commit<1> : (rpt == 2 ? k_mask_commit<2> : k_mask_commit<4>);
+    HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)bits));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(threads), bits, c->stream,
                        (const uint64_t*)c->marks.p, (uint8_t*)c->active.p, g.ngx, g.ngy, g.R);
     HIPCHK(c, hipGetLastError());
   }
