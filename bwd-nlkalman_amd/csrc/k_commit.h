@@ -27,7 +27,8 @@ k_mask_commit(const uint64_t* __restrict__ marks, uint8_t* __restrict__ active, 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   uint32_t* bits = (uint32_t*)smem;
   const int ntot = ngx * ngy;
-  const int nwords = (ntot + 31) / 32;
+  // + a tail: marks aimed below the last grid row (strip mode) land in padding
+  const int nwords = (ntot + (R + 1) * ngx + 63) / 32 + 1;
   for (int i = threadIdx.x; i < nwords; i += blockDim.x) bits[i] = 0;
   __syncthreads();
   const int side = 2 * R + 1;
@@ -37,7 +38,21 @@ k_mask_commit(const uint64_t* __restrict__ marks, uint8_t* __restrict__ active, 
     const int i = s - skew * j;
     return (j < ngy && i >= 0 && i < ngx) ? marks[(size_t)j * ngx + i] : 0ull;
   };
-  // decide the targets of time step s; m = their mark words
+  // Decide the targets of time step s; mw = their mark words. Bit
+  // (dj+R)*side + (di+R) of a mark word stands for the grid neighbour (di, dj);
+  // the raster-forward neighbours are exactly the bits above the centre bit. Each
+  // forward row of (up to) `side` neighbours is OR-ed into the bit array with at
+  // most two 32-bit LDS atomics: no per-bit loop, no division.
+  const int centre = R * side + R;
+  const uint32_t rowmask = (1u << side) - 1u;
+  auto or_bits = [&](int pos, uint32_t mask) {  // bits[pos ...] |= mask
+    if (!mask) return;
+    const int wd = pos >> 5, sh = pos & 31;
+    const uint32_t lo = mask << sh;
+    const uint32_t hi = sh ? (mask >> (32 - sh)) : 0u;
+    if (lo) atomicOr(&bits[wd], lo);
+    if (hi) atomicOr(&bits[wd + 1], hi);
+  };
   auto decide = [&](int s, const uint64_t (&mw)[RPT]) {
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
@@ -47,18 +62,10 @@ k_mask_commit(const uint64_t* __restrict__ marks, uint8_t* __restrict__ active, 
         const int t = j * ngx + i;
         const bool done = (bits[t >> 5] >> (t & 31)) & 1u;
         if (!done) {
-          uint64_t m = mw[r];
-          while (m) {
-            const int b = __ffsll((unsigned long long)m) - 1;
-            m &= m - 1;
-            const int dj = b / side - R, di = b - (b / side) * side - R;
-            const int jj = j + dj, ii = i + di;
-            // forward marks only; a member outside this strip's rows is not a target here
-            if ((dj > 0 || (dj == 0 && di > 0)) && jj < ngy && ii >= 0 && ii < ngx) {
-              const int tt = jj * ngx + ii;
-              atomicOr(&bits[tt >> 5], 1u << (tt & 31));
-            }
-          }
+          const uint64_t fwd = mw[r] >> (centre + 1);
+          or_bits(t + 1, (uint32_t)fwd & ((1u << R) - 1u));        // same row, di = 1..R
+          for (int dj = 1; dj <= R; ++dj)                            // rows below, di = -R..R
+            or_bits(t + dj * ngx - R, (uint32_t)(fwd >> (R + (dj - 1) * side)) & rowmask);
         }
       }
     }

@@ -17,13 +17,15 @@
 // Group members are re-transformed once the gains are known (two members per
 // step in the filter: one in the sel = 0 lanes, one in the sel = 1 lanes).
 //
-// Aggregation. A workgroup (4 wavefronts) owns a tile of 16 x 4 targets and
-// accumulates every weighted patch of its groups into an LDS tile (ch value
-// planes + 1 weight plane, covering the tile plus the search halo) with LDS
-// float atomics; the tile is flushed once with coalesced global float atomics,
-// skipping untouched entries. This cuts the HBM atomic traffic by ~16x compared
-// with one global atomic per patch pixel (MI355X global float atomics run at a
-// fixed ~1.3 TB/s of added bytes, which would otherwise bound the kernel).
+// Aggregation. A workgroup is ONE wavefront that owns a tile of 4 x 4 targets
+// and a private LDS accumulator tile (ch value planes + 1 weight plane, covering
+// the tile plus the search halo). Being private, the tile is updated with plain
+// ds_read / add / ds_write (LDS float atomics retire about one lane per clock on
+// gfx950 and made an earlier, shared-tile version of this kernel LDS-bound: see
+// profiles/). The tile is flushed once with coalesced global float atomics,
+// skipping untouched entries, which cuts the HBM atomic traffic ~10x compared
+// with one global atomic per patch pixel (global float atomics run at a fixed
+// ~1.3 TB/s of added bytes on MI355X and would otherwise bound the kernel).
 #pragma once
 #include "nlk_common.h"
 
@@ -41,7 +43,7 @@ constexpr float NLK_C8[8][8] = {
 struct NlkGTile {
   int tgx, tgy, ntx, nty;
   int rwp, rh_max;  // LDS accumulator region: row stride / rows
-  int wmax;         // reach of a group around its target
+  int wmax;         // halo of the LDS tile around its targets (groups reaching further spill to HBM atomics)
 };
 
 typedef float nlk_f4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -171,7 +173,7 @@ __device__ __forceinline__ float nlk_wave_sum8(float v) {
 }
 
 template <int CH, bool SMO>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 k_group8(const float* __restrict__ img,   // matching / statistics image (planar)
          const float* __restrict__ cur,   // image whose patches are filtered
          const float* __restrict__ prev,  // previous output or nullptr
@@ -183,7 +185,7 @@ k_group8(const float* __restrict__ img,   // matching / statistics image (planar
          float* __restrict__ acc) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [(CH+1)][rh_max][rwp]
   constexpr int PSZ = 8, step = 4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x;
   const int tile_x = blockIdx.x % tl.ntx, tile_y = blockIdx.x / tl.ntx;
   const int gx0 = tile_x * tl.tgx, gy0 = tile_y * tl.tgy;
   const int cx = min(tl.tgx, g.ngx - gx0), cy = min(tl.tgy, g.ngy - gy0);
@@ -193,7 +195,7 @@ k_group8(const float* __restrict__ img,   // matching / statistics image (planar
   const int ry1 = min(g.oy + (gy0 + cy - 1) * step + tl.wmax + PSZ, g.h);
   const int rw = rx1 - rx0, rh = ry1 - ry0;
   const int rwp = tl.rwp, plane = rwp * tl.rh_max;
-  for (int i = threadIdx.x; i < (CH + 1) * plane; i += 256) smem[i] = 0.f;
+  for (int i = lane; i < (CH + 1) * plane; i += 64) smem[i] = 0.f;
   __syncthreads();
 
   // lane role
@@ -214,16 +216,49 @@ k_group8(const float* __restrict__ img,   // matching / statistics image (planar
   const float* src_c = g.have_basic ? cur_c : img_c;  // patches that get filtered
   const float s2 = g.sigma2;
 
-  for (int tt = wave; tt < cx * cy; tt += 4) {
+  // per-tile records: lane tt holds the record of target tt, read back with
+  // v_readlane so that no HBM latency sits in the target loop
+  int rec_act = 0, rec_nsel = 0, rec_nagg = 0, rec_flags = 0;
+  if (lane < cx * cy) {
+    const int ty = lane / cx, tx = lane - ty * cx;
+    const size_t t = (size_t)(gy0 + ty) * g.ngx + gx0 + tx;
+    rec_act = active[t];
+    const NlkTarget info = tinfo[t];
+    rec_nsel = info.nsel; rec_nagg = info.nagg; rec_flags = info.flags;
+  }
+
+  for (int tt = 0; tt < cx * cy; ++tt) {
+    if (!__builtin_amdgcn_readlane(rec_act, tt)) continue;
+    const int nagg = __builtin_amdgcn_readlane(rec_nagg, tt);
+    if (nagg == 0) continue;
     const int ty = tt / cx, tx = tt - ty * cx;
     const int gx = gx0 + tx, gy = gy0 + ty;
     const size_t t = (size_t)gy * g.ngx + gx;
-    if (!active[t]) continue;
-    const NlkTarget info = tinfo[t];
-    const int nagg = info.nagg;
-    if (nagg == 0) continue;
-    const bool prev_p = info.flags & 1;
-    const int k = info.nsel;
+    const bool prev_p = __builtin_amdgcn_readlane(rec_flags, tt) & 1;
+    const int k = __builtin_amdgcn_readlane(rec_nsel, tt);
+
+    // candidate / member lists of this target: one entry per lane (two rounds),
+    // fetched once; the loops below read them with v_readlane
+    uint32_t qreg[2], greg[2];
+    uint64_t vbits[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int i = lane + 64 * m;
+      qreg[m] = i < k ? topk[t * g.kmax + i] : 0u;
+      greg[m] = i < nagg ? gcoords[t * g.gstride + i] : 0u;
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int i = lane + 64 * m;
+      const int org = nlk_y(qreg[m]) * g.w + nlk_x(qreg[m]);
+      vbits[m] = __ballot(prev_p && i < k && vmap[org]);
+    }
+    auto cand = [&](int i) -> uint32_t {
+      return i < 64 ? __builtin_amdgcn_readlane(qreg[0], i) : __builtin_amdgcn_readlane(qreg[1], i - 64);
+    };
+    auto member = [&](int i) -> uint32_t {
+      return i < 64 ? __builtin_amdgcn_readlane(greg[0], i) : __builtin_amdgcn_readlane(greg[1], i - 64);
+    };
 
     // ---------------- pass A: statistics over the k kept candidates
     float mean[8], var[8], v01[8], m0[8];
@@ -233,9 +268,9 @@ k_group8(const float* __restrict__ img,   // matching / statistics image (planar
     float x[8], nxt[8];
     bool vnext = false;
     auto gatherA = [&](int i, float (&dst)[8], bool& v) {
-      const uint32_t q = topk[t * g.kmax + i];
+      const uint32_t q = cand(i);
       const int org = nlk_y(q) * g.w + nlk_x(q);
-      v = prev_p && vmap[org];
+      v = (vbits[i >> 6] >> (i & 63)) & 1ull;
       if (lane_on && (sel == 0 || v)) nlk_load_row8((sel ? prev_c : img_c) + org, dst);
       else {
 #pragma unroll
@@ -251,7 +286,7 @@ k_group8(const float* __restrict__ img,   // matching / statistics image (planar
       nlk_dct8x8_fwd(x, ck);
       np1++;
       if (v) np0++;
-      const float inv = sel ? (v ? 1.f / (float)np0 : 0.f) : 1.f / (float)np1;
+      const float inv = sel ? (v ? __builtin_amdgcn_rcpf((float)np0) : 0.f) : __builtin_amdgcn_rcpf((float)np1);
       const bool in_group = v && np0 <= g.ntagg;
       const bool upd = lane_on && (sel == 0 || v);
       float part[8];  // partner plane's coefficient (all lanes take part in the DPP)
@@ -325,31 +360,52 @@ k_group8(const float* __restrict__ img,   // matching / statistics image (planar
     const float wgt = 1.f / (vp > 1e-6f ? vp : 1e-6f);
 
     // ---------------- pass B: shrink, invert and aggregate the group members
+    // A member inside the LDS tile (the rule) is added with LDS atomics; a
+    // member of a far-reaching group that leaves it goes straight to HBM.
+    auto add_patch = [&](int qx, int qy, const float (&px8)[8]) {
+      const int lx = qx - rx0, ly = qy - ry0;
+      if (lx >= 0 && ly >= 0 && lx + PSZ <= rw && ly + PSZ <= rh) {
+        float* dst = smem + cc * plane + (ly + u) * rwp + lx;
+        float* dw = smem + CH * plane + (ly + u) * rwp + lx;
+        float o[8], ow[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { o[r] = dst[r]; if (c == 0) ow[r] = dw[r]; }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const float ww = wgt * wrow[r];
+          dst[r] = o[r] + ww * px8[r];
+          if (c == 0) dw[r] = ow[r] + ww;
+        }
+      } else {
+        float* dst = acc + (size_t)cc * npix + (size_t)(qy + u) * g.w + qx;
+        float* dw = acc + (size_t)CH * npix + (size_t)(qy + u) * g.w + qx;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const float ww = wgt * wrow[r];
+          unsafeAtomicAdd(dst + r, ww * px8[r]);
+          if (c == 0) unsafeAtomicAdd(dw + r, ww);
+        }
+      }
+    };
     if (!SMO) {
       for (int n0 = 0; n0 < nagg; n0 += 2) {
         const int n = n0 + sel;
         const bool has = lane_on && n < nagg;
-        const uint32_t q = gcoords[t * g.gstride + (has ? n : n0)];
+        const uint32_t qa = member(n0), qb = member(min(n0 + 1, nagg - 1));
+        const uint32_t q = sel ? qb : qa;
         const int qx = nlk_x(q), qy = nlk_y(q);
         if (has) nlk_load_row8(src_c + qy * g.w + qx, x);
         nlk_dct8x8_fwd(x, ck);
 #pragma unroll
         for (int r = 0; r < 8; ++r) x[r] = gain[r] * x[r] + (1 - gain[r]) * mu[r];
         nlk_dct8x8_inv(x, cik);
-        if (has) {
-          float* dst = smem + cc * plane + (qy - ry0 + u) * rwp + (qx - rx0);
-          float* dw = smem + CH * plane + (qy - ry0 + u) * rwp + (qx - rx0);
-#pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            const float ww = wgt * wrow[r];
-            atomicAdd(dst + r, ww * x[r]);
-            if (c == 0) atomicAdd(dw + r, ww);
-          }
-        }
+        // the two members of a step may overlap: update the tile one after the other
+        if (has && sel == 0) add_patch(qx, qy, x);
+        if (has && sel == 1) add_patch(qx, qy, x);
       }
     } else {
       for (int n = 0; n < nagg; ++n) {
-        const uint32_t q = gcoords[t * g.gstride + n];
+        const uint32_t q = member(n);
         const int qx = nlk_x(q), qy = nlk_y(q);
         const bool ld = lane_on && (sel == 0 || !passthrough);
         if (ld) nlk_load_row8((sel ? prev_c : src_c) + qy * g.w + qx, x);
@@ -362,16 +418,7 @@ k_group8(const float* __restrict__ img,   // matching / statistics image (planar
           }
           nlk_dct8x8_inv(x, cik);
         }
-        if (lane_on && sel == 0) {
-          float* dst = smem + cc * plane + (qy - ry0 + u) * rwp + (qx - rx0);
-          float* dw = smem + CH * plane + (qy - ry0 + u) * rwp + (qx - rx0);
-#pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            const float ww = wgt * wrow[r];
-            atomicAdd(dst + r, ww * x[r]);
-            if (c == 0) atomicAdd(dw + r, ww);
-          }
-        }
+        if (lane_on && sel == 0) add_patch(qx, qy, x);
       }
     }
   }
@@ -379,7 +426,7 @@ k_group8(const float* __restrict__ img,   // matching / statistics image (planar
   // ---------------- flush the tile accumulator (coalesced rows, skip untouched)
   __syncthreads();
   for (int p = 0; p <= CH; ++p)
-    for (int y = wave; y < rh; y += 4) {
+    for (int y = 0; y < rh; ++y) {
       const float* srow = smem + p * plane + y * rwp;
       float* drow = acc + (size_t)p * npix + (size_t)(ry0 + y) * g.w + rx0;
       for (int xx = lane; xx < rw; xx += 64) {

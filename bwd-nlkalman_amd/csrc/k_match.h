@@ -28,6 +28,7 @@ struct NlkTile {
   int ntx, nty;       // tiles
   int rwp, rh_max;    // LDS region: padded row stride (floats) / rows
   int ksel_max;       // capacity of the per-wave survivor arrays
+  int halo;           // search halo held in LDS (windows reaching further read HBM/L2)
 };
 
 __device__ inline uint64_t nlk_wave_or(uint64_t v) {
@@ -148,15 +149,18 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
           NlkTile tl, uint32_t* __restrict__ topk, NlkTarget* __restrict__ tinfo,
           uint32_t* __restrict__ gcoords, uint64_t* __restrict__ marks) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: makes per-target addresses uniform
   const int tile_x = blockIdx.x % tl.ntx, tile_y = blockIdx.x / tl.ntx;
   const int gx0 = tile_x * tl.tgx, gy0 = tile_y * tl.tgy;
   const int cx = min(tl.tgx, g.ngx - gx0), cy = min(tl.tgy, g.ngy - gy0);
-  const int wmax = g.smoother ? g.wsz_t
-                              : (g.have_prev ? max(g.wsz_x, g.wsz_t) : g.wsz_x);
+  const int wmax = tl.halo;
   constexpr int step = PSZ / 2;
 
-  // image region reachable from this tile
+  // image region staged in LDS: the tile's patches + the halo of the dominant
+  // window. (In a temporal frame the few targets without a valid previous patch
+  // search a wider window, reference: src/nlkalman.c:637; they read the image
+  // through L2 instead.)
   const int rx0 = max(gx0 * step - wmax, 0);
   const int rx1 = min((gx0 + cx - 1) * step + wmax + PSZ, g.w);
   const int ry0 = max(g.oy + gy0 * step - wmax, 0);
@@ -172,15 +176,40 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
   uint32_t* grp_all = sel_all + NLK_BM_WAVES * tl.ksel_max;  // [waves][gstride]
 
   const size_t npix = (size_t)g.w * g.h;
-  for (int y = wave; y < rh; y += NLK_BM_WAVES)
+  // stage the region: 8 rows per wavefront in flight (loads first, then the LDS
+  // stores), so the HBM/L2 latency is paid once per batch, not once per row
+  {
+    const int nrows = CH * rh;  // rows of all channel planes; region width <= 128
+    for (int r0 = wave; r0 < nrows; r0 += NLK_BM_WAVES * 8) {
+      float v0[8], v1[8];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const float* src = img + c * npix + (size_t)(ry0 + y) * g.w + rx0;
-      float* dst = tile + c * plane + y * rwp;
-      for (int x = lane; x < rw; x += 64) dst[x] = src[x];
+      for (int j = 0; j < 8; ++j) {
+        const int r = min(r0 + NLK_BM_WAVES * j, nrows - 1);
+        const int c = r / rh, y = r - c * rh;
+        const float* src = img + c * npix + (size_t)(ry0 + y) * g.w + rx0;
+        v0[j] = lane < rw ? src[lane] : 0.f;
+        v1[j] = lane + 64 < rw ? src[lane + 64] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = r0 + NLK_BM_WAVES * j;
+        if (r < nrows) {
+          const int c = r / rh, y = r - c * rh;
+          float* dst = tile + c * plane + y * rwp;
+          if (lane < rw) dst[lane] = v0[j];
+          if (lane + 64 < rw) dst[lane + 64] = v1[j];
+        }
+      }
     }
+  }
   __syncthreads();
 
+  // prev_p of the tile's targets: lane tt holds target tt's flag
+  int rec_prev = 0;
+  if (g.have_prev && lane < cx * cy) {
+    const int ty = lane / cx, tx = lane - ty * cx;
+    rec_prev = vmap[(size_t)(g.oy + (gy0 + ty) * step) * g.w + (gx0 + tx) * step];
+  }
   uint32_t* skey = skey_all + wave * tl.ksel_max;
   uint32_t* sidx = sidx_all + wave * tl.ksel_max;
   uint32_t* sel = sel_all + wave * tl.ksel_max;
@@ -191,7 +220,7 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
     const int gx = gx0 + tx, gy = gy0 + ty;
     const int px = gx * step, py = g.oy + gy * step;
     const size_t t = (size_t)gy * g.ngx + gx;
-    const int prev_p = g.have_prev ? vmap[(size_t)py * g.w + px] : 0;
+    const int prev_p = __builtin_amdgcn_readlane(rec_prev, tt);
     int k = prev_p ? g.npt : g.npx;
     NlkTarget info = {0, 0, 0, prev_p};
     if (k <= 1) {
@@ -209,17 +238,31 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
     const int y0 = max(py - wsz, 0), y1 = min(py + wsz, g.h - PSZ) + 1;
     const int nwx = x1 - x0, n = nwx * (y1 - y0);
     k = min(k, n);
-    const int tq = (py - ry0) * rwp + (px - rx0);
-    const int cbase = (y0 - ry0) * rwp + (x0 - rx0);
-    if (n <= 128)
-      nlk_match_target<PSZ, CH, 2>(tile, plane, rwp, tq, cbase, nwx, n, k, x0, y0, skey, sidx,
-                                   sel, lane);
-    else if (MAXM <= 7 || n <= 448)
-      nlk_match_target<PSZ, CH, (MAXM < 7 ? MAXM : 7)>(tile, plane, rwp, tq, cbase, nwx, n, k,
-                                                       x0, y0, skey, sidx, sel, lane);
-    else
-      nlk_match_target<PSZ, CH, MAXM>(tile, plane, rwp, tq, cbase, nwx, n, k, x0, y0, skey,
-                                      sidx, sel, lane);
+    const bool in_lds = x0 >= rx0 && x1 - 1 + PSZ <= rx1 && y0 >= ry0 && y1 - 1 + PSZ <= ry1;
+    if (in_lds) {
+      const int tq = (py - ry0) * rwp + (px - rx0);
+      const int cbase = (y0 - ry0) * rwp + (x0 - rx0);
+      if (n <= 128)
+        nlk_match_target<PSZ, CH, 2>(tile, plane, rwp, tq, cbase, nwx, n, k, x0, y0, skey, sidx,
+                                     sel, lane);
+      else if (MAXM <= 7 || n <= 448)
+        nlk_match_target<PSZ, CH, (MAXM < 7 ? MAXM : 7)>(tile, plane, rwp, tq, cbase, nwx, n, k,
+                                                         x0, y0, skey, sidx, sel, lane);
+      else
+        nlk_match_target<PSZ, CH, MAXM>(tile, plane, rwp, tq, cbase, nwx, n, k, x0, y0, skey,
+                                        sidx, sel, lane);
+    } else {  // window leaves the LDS region: same arithmetic on the image itself
+      const int tq = py * g.w + px, cbase = y0 * g.w + x0;
+      if (n <= 128)
+        nlk_match_target<PSZ, CH, 2>(img, (int)npix, g.w, tq, cbase, nwx, n, k, x0, y0, skey,
+                                     sidx, sel, lane);
+      else if (MAXM <= 7 || n <= 448)
+        nlk_match_target<PSZ, CH, (MAXM < 7 ? MAXM : 7)>(img, (int)npix, g.w, tq, cbase, nwx, n,
+                                                         k, x0, y0, skey, sidx, sel, lane);
+      else
+        nlk_match_target<PSZ, CH, MAXM>(img, (int)npix, g.w, tq, cbase, nwx, n, k, x0, y0, skey,
+                                        sidx, sel, lane);
+    }
 
     // --- group membership: the first ntagg kept candidates that have a valid
     // previous patch, or (none valid) the first ntagg kept candidates

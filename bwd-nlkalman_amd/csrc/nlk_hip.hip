@@ -156,10 +156,12 @@ template <int CH, bool SMO>
 int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
                     const float* prev, float* acc) {
   NlkGTile tl{};
-  tl.tgx = 16; tl.tgy = 4;
+  tl.tgx = 4; tl.tgy = 4;
   tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
   tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
-  tl.wmax = g.smoother ? g.wsz_t : (g.have_prev ? max(g.wsz_x, g.wsz_t) : g.wsz_x);
+  // LDS tile halo = reach of the dominant kind of group; the rare spatial-branch
+  // groups of a temporal frame that reach further fall back to HBM atomics
+  tl.wmax = (g.smoother || g.have_prev) ? g.wsz_t : g.wsz_x;
   tl.rwp = ((tl.tgx - 1) * g.step + 2 * tl.wmax + g.psz) | 1;
   tl.rh_max = (tl.tgy - 1) * g.step + 2 * tl.wmax + g.psz;
   const size_t lds = sizeof(float) * (size_t)(CH + 1) * tl.rwp * tl.rh_max;
@@ -168,7 +170,7 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
   HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
   const float* basis = (const float*)c->tabs.p;
-  hipLaunchKernelGGL(kern, dim3(tl.ntx * tl.nty), dim3(256), lds, c->stream, img, cur, prev,
+  hipLaunchKernelGGL(kern, dim3(tl.ntx * tl.nty), dim3(64), lds, c->stream, img, cur, prev,
                      (const uint8_t*)c->vmap.p, g, tl, (const uint32_t*)c->topk.p,
                      (const NlkTarget*)c->tinfo.p, (const uint32_t*)c->gcoords.p,
                      (const uint8_t*)c->active.p, basis, basis + 64, acc);
@@ -178,7 +180,8 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
 
 int launch_group(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
                  const float* prev, float* acc) {
-  if (g.psz == 8 && !getenv("NLK_GENERIC_GROUP")) {  // register/DPP fast path
+  // register/DPP fast path (its per-lane candidate lists hold up to 128 entries)
+  if (g.psz == 8 && g.kmax <= 128 && g.gstride <= 128 && !getenv("NLK_GENERIC_GROUP")) {
     if (g.ch == 1)
       return g.smoother ? launch_group8_t<1, true>(c, g, img, cur, prev, acc)
                         : launch_group8_t<1, false>(c, g, img, cur, prev, acc);
@@ -495,17 +498,19 @@ int nlk_dev_frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const flo
   // ---- block matching + selection
   const float* img_match = basic ? img_basic : img_cur;
   NlkTile tl{};
-  tl.tgx = 16; tl.tgy = 4;
+  tl.tgx = 8; tl.tgy = 4;
   tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
   tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
-  // LDS row stride = window width (mod 32): candidate i of a window then sits
-  // on bank i mod 32, so a wavefront's 64 candidate reads are conflict free
+  // LDS holds the halo of the dominant window; its row stride = window width
+  // (mod 32): candidate i of a window then sits on bank i mod 32, so a
+  // wavefront's 64 candidate reads are conflict free
+  tl.halo = (g.smoother || g.have_prev) ? g.wsz_t : g.wsz_x;
   {
-    const int need = (tl.tgx - 1) * g.step + 2 * wmax + g.psz;
-    const int wdom = 2 * ((g.smoother || g.have_prev) ? g.wsz_t : g.wsz_x) + 1;
+    const int need = (tl.tgx - 1) * g.step + 2 * tl.halo + g.psz;
+    const int wdom = 2 * tl.halo + 1;
     tl.rwp = need + ((wdom - need) % 32 + 32) % 32;
   }
-  tl.rh_max = (tl.tgy - 1) * g.step + 2 * wmax + g.psz;
+  tl.rh_max = (tl.tgy - 1) * g.step + 2 * tl.halo + g.psz;
   tl.ksel_max = g.kmax;
   const size_t lds = sizeof(float) * ((size_t)ch * tl.rwp * tl.rh_max +
                                       (size_t)NLK_BM_WAVES * (3 * tl.ksel_max + ntagg_alloc));
@@ -519,7 +524,7 @@ int nlk_dev_frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const flo
   {
     const int rpt = (g.ngy + 1023) / 1024;
     const int threads = min(1024, ((g.ngy + 63) / 64) * 64);
-    const size_t bits = sizeof(uint32_t) * ((size_t)(ngrid + 31) / 32);
+    const size_t bits = sizeof(uint32_t) * ((size_t)(ngrid + (g.R + 1) * g.ngx + 63) / 32 + 1);
     if (bits > 160 * 1024 || rpt > 4)
       return fail(c, NLK_EUNSUP, "patch grid %dx%d too large for the mask replay", g.ngx, g.ngy);
     auto kern = rpt == 1 ? k_mask_commit<1> : (rpt == 2 ? k_mask_commit<2> : k_mask_commit<4>);
