@@ -1,0 +1,27 @@
+/* cli_args.h — command-line parser with the flag grammar the reference's CLIs
+ * expose through lib/argparse (reference: lib/argparse/argparse.c:80-105 value
+ * parsing, :138-187 option matching, :210-268 parse loop, :276-366 usage text):
+ *   --name value | --name=value | -x value | -xvalue, integers via strtol(.., 0),
+ *   floats via strtof, last occurrence wins, `--` ends the options, non-option
+ *   arguments are ignored, unknown option => message + usage + exit(1),
+ *   -h/--help => usage + exit(0).
+ * Own implementation (table driven); nothing of lib/argparse is reused. */
+#ifndef NLK_CLI_ARGS_H
+#define NLK_CLI_ARGS_H
+
+enum cli_type { CLI_END, CLI_GROUP, CLI_STRING, CLI_INT, CLI_FLOAT };
+
+struct cli_option {
+  enum cli_type type;
+  char short_name;        /* 0 = none */
+  const char *long_name;  /* NULL for a group header: `help` is the title */
+  void *value;            /* const char** / int* / float* */
+  const char *help;
+};
+
+/* parses argv (skipping argv[0]); exits on -h, unknown options and bad values */
+void cli_parse(const struct cli_option *opts, const char *prog, const char *description,
+               int argc, const char **argv);
+void cli_usage(const struct cli_option *opts, const char *prog, const char *description);
+
+#endif

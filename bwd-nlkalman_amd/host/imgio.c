@@ -1,0 +1,416 @@
+/* imgio.c — see imgio.h. Own code: TIFF/PNG/PFM/FLO codecs written from the
+ * public format specifications (TIFF 6.0 + BigTIFF, PNG 1.2, PFM, Middlebury
+ * .flo); zlib's uncompress() is reached through dlopen for Deflate/PNG. */
+#include "imgio.h"
+
+#include <dlfcn.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+
+static float *fail(const char *path, const char *why) {
+  fprintf(stderr, "imgio: %s: %s\n", path, why);
+  return NULL;
+}
+
+static unsigned char *slurp(const char *path, size_t *n) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return NULL;
+  fseek(f, 0, SEEK_END);
+  long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  unsigned char *b = malloc(sz > 0 ? (size_t)sz : 1);
+  if (b && fread(b, 1, (size_t)sz, f) != (size_t)sz) { free(b); b = NULL; }
+  fclose(f);
+  *n = (size_t)sz;
+  return b;
+}
+
+/* ------------------------------------------------------------------- zlib */
+typedef int (*uncompress_fn)(unsigned char *, unsigned long *, const unsigned char *, unsigned long);
+static int z_uncompress(unsigned char *dst, size_t *dlen, const unsigned char *src, size_t slen) {
+  static uncompress_fn fn = NULL;
+  if (!fn) {
+    void *h = dlopen("libz.so.1", RTLD_NOW);
+    if (!h) h = dlopen("libz.so", RTLD_NOW);
+    if (h) fn = (uncompress_fn)dlsym(h, "uncompress");
+    if (!fn) { fprintf(stderr, "imgio: zlib (libz.so.1) not found\n"); return -1; }
+  }
+  unsigned long n = *dlen;
+  int rc = fn(dst, &n, src, slen);
+  *dlen = n;
+  return rc == 0 || rc == -5 /* Z_BUF_ERROR with full output is fine for us */ ? 0 : -1;
+}
+
+/* -------------------------------------------------------------------- PFM */
+static float *read_pfm(const char *path, const unsigned char *b, size_t n, int *w, int *h, int *ch) {
+  int c = b[1] == 'F' ? 3 : 1, pos = 0;
+  double scale;
+  if (sscanf((const char *)b + 2, "%d %d %lf%n", w, h, &scale, &pos) != 3) return fail(path, "bad PFM header");
+  size_t off = 2 + pos + 1; /* one whitespace byte after the scale */
+  size_t cnt = (size_t)*w * *h * c;
+  if (off + cnt * 4 > n) return fail(path, "truncated PFM");
+  float *d = malloc(cnt * 4);
+  memcpy(d, b + off, cnt * 4);
+  if (scale > 0) /* big-endian samples */
+    for (size_t i = 0; i < cnt; ++i) {
+      unsigned char *p = (unsigned char *)&d[i], t;
+      t = p[0]; p[0] = p[3]; p[3] = t; t = p[1]; p[1] = p[2]; p[2] = t;
+    }
+  *ch = c;
+  return d; /* top row first, no flip (reference: lib/iio/iio.c:2049-2071) */
+}
+
+/* -------------------------------------------------------------------- FLO */
+static float *read_flo(const char *path, const unsigned char *b, size_t n, int *w, int *h, int *ch) {
+  int32_t ww, hh;
+  memcpy(&ww, b + 4, 4);
+  memcpy(&hh, b + 8, 4);
+  size_t cnt = (size_t)ww * hh * 2;
+  if (ww <= 0 || hh <= 0 || 12 + cnt * 4 > n) return fail(path, "bad .flo");
+  float *d = malloc(cnt * 4);
+  memcpy(d, b + 12, cnt * 4);
+  *w = ww; *h = hh; *ch = 2;
+  return d;
+}
+
+/* ------------------------------------------------------------------- TIFF */
+typedef struct { const unsigned char *b; size_t n; int le, big; } tif_t;
+static uint64_t rd(const tif_t *t, size_t off, int bytes) {
+  uint64_t v = 0;
+  if (off + bytes > t->n) return 0;
+  for (int i = 0; i < bytes; ++i)
+    v |= (uint64_t)t->b[off + (t->le ? i : bytes - 1 - i)] << (8 * i);
+  return v;
+}
+static const int tif_tsz[] = {0, 1, 1, 2, 4, 8, 1, 1, 2, 4, 8, 4, 8, 4, 0, 0, 8, 8, 8};
+
+/* value j of an IFD entry located at `e` */
+static uint64_t tif_val(const tif_t *t, size_t e, uint64_t j) {
+  const int type = (int)rd(t, e + 2, 2);
+  const uint64_t cnt = rd(t, e + 4, t->big ? 8 : 4);
+  const int ts = type < 19 ? tif_tsz[type] : 0;
+  const size_t field = e + (t->big ? 12 : 8), fsz = t->big ? 8 : 4;
+  const size_t base = (cnt * ts <= fsz) ? field : (size_t)rd(t, field, (int)fsz);
+  return j < cnt ? rd(t, base + j * ts, ts) : 0;
+}
+
+static size_t lzw_decode(const unsigned char *s, size_t n, unsigned char *d, size_t cap) {
+  /* TIFF LZW: MSB-first codes, 9..12 bits, early change, 256 = clear, 257 = end */
+  static uint16_t prefix[4096];
+  static unsigned char suffix[4096], stack[4096];
+  size_t out = 0, bitpos = 0;
+  int width = 9, next = 258, prev = -1;
+  for (;;) {
+    if ((bitpos + width + 7) / 8 > n + 1) break;
+    uint32_t code = 0;
+    for (int i = 0; i < width; ++i) {
+      const size_t bp = bitpos + i;
+      const int bit = bp / 8 < n ? (s[bp / 8] >> (7 - bp % 8)) & 1 : 0;
+      code = (code << 1) | bit;
+    }
+    bitpos += width;
+    if (code == 257) break;
+    if (code == 256) { width = 9; next = 258; prev = -1; continue; }
+    int sp = 0, c = (int)code;
+    if (prev < 0) {
+      if (out < cap) d[out++] = (unsigned char)c;
+      prev = c;
+      continue;
+    }
+    if (c >= next) { /* KwKwK */
+      int p = prev;
+      while (p >= 258) p = prefix[p];
+      stack[sp++] = (unsigned char)p;
+      c = prev;
+    }
+    while (c >= 258) { stack[sp++] = suffix[c]; c = prefix[c]; }
+    stack[sp++] = (unsigned char)c;
+    const unsigned char first = (unsigned char)c;
+    while (sp > 0 && out < cap) d[out++] = stack[--sp];
+    if (next < 4096) {
+      prefix[next] = (uint16_t)prev;
+      suffix[next] = first;
+      next++;
+      if (next == 511 || next == 1023 || next == 2047) width++;
+    }
+    prev = (int)code;
+    if (out >= cap) break;
+  }
+  return out;
+}
+
+static size_t packbits_decode(const unsigned char *s, size_t n, unsigned char *d, size_t cap) {
+  size_t i = 0, o = 0;
+  while (i < n && o < cap) {
+    int c = (signed char)s[i++];
+    if (c >= 0) { for (int k = 0; k <= c && i < n && o < cap; ++k) d[o++] = s[i++]; }
+    else if (c != -128) { for (int k = 0; k <= -c && o < cap; ++k) d[o++] = s[i]; i++; }
+  }
+  return o;
+}
+
+static float *read_tiff(const char *path, const unsigned char *b, size_t n, int *w, int *h, int *ch) {
+  tif_t t = {b, n, b[0] == 'I', 0};
+  const int magic = (int)rd(&t, 2, 2);
+  if (magic == 43) t.big = 1;
+  else if (magic != 42) return fail(path, "not a TIFF");
+  size_t ifd = (size_t)(t.big ? rd(&t, 8, 8) : rd(&t, 4, 4));
+  const uint64_t nent = t.big ? rd(&t, ifd, 8) : rd(&t, ifd, 2);
+  const size_t e0 = ifd + (t.big ? 8 : 2), esz = t.big ? 20 : 12;
+  uint64_t W = 0, H = 0, bps = 1, comp = 1, spp = 1, rps = 0, planar = 1, fmt = 1, pred = 1;
+  size_t e_off = 0, e_cnt = 0;
+  for (uint64_t i = 0; i < nent; ++i) {
+    const size_t e = e0 + i * esz;
+    switch ((int)rd(&t, e, 2)) {
+      case 256: W = tif_val(&t, e, 0); break;
+      case 257: H = tif_val(&t, e, 0); break;
+      case 258: bps = tif_val(&t, e, 0); break;
+      case 259: comp = tif_val(&t, e, 0); break;
+      case 273: e_off = e; break;
+      case 277: spp = tif_val(&t, e, 0); break;
+      case 278: rps = tif_val(&t, e, 0); break;
+      case 279: e_cnt = e; break;
+      case 284: planar = tif_val(&t, e, 0); break;
+      case 317: pred = tif_val(&t, e, 0); break;
+      case 339: fmt = tif_val(&t, e, 0); break;
+      case 322: case 324: return fail(path, "tiled TIFF not supported");
+    }
+  }
+  if (!W || !H || !e_off || !e_cnt) return fail(path, "incomplete TIFF directory");
+  if (!rps || rps > H) rps = H;
+  if (bps != 8 && bps != 16 && bps != 32 && bps != 64) return fail(path, "unsupported bits per sample");
+  const int bytes = (int)bps / 8;
+  const uint64_t planes = planar == 2 ? spp : 1, cpp = planar == 2 ? 1 : spp; /* comps per pixel in a strip */
+  const uint64_t spp_strips = (H + rps - 1) / rps;
+  float *out = malloc((size_t)W * H * spp * sizeof(float));
+  unsigned char *raw = malloc((size_t)W * rps * cpp * bytes + 16);
+  for (uint64_t pl = 0; pl < planes; ++pl)
+    for (uint64_t s = 0; s < spp_strips; ++s) {
+      const uint64_t idx = pl * spp_strips + s;
+      const size_t off = (size_t)tif_val(&t, e_off, idx), cnt = (size_t)tif_val(&t, e_cnt, idx);
+      const uint64_t rows = (s + 1) * rps <= H ? rps : H - s * rps;
+      const size_t want = (size_t)W * rows * cpp * bytes;
+      if (off + cnt > n) { free(out); free(raw); return fail(path, "strip outside the file"); }
+      size_t got = want;
+      if (comp == 1) memcpy(raw, b + off, cnt < want ? cnt : want);
+      else if (comp == 5) got = lzw_decode(b + off, cnt, raw, want);
+      else if (comp == 32773) got = packbits_decode(b + off, cnt, raw, want);
+      else if (comp == 8 || comp == 32946) { if (z_uncompress(raw, &got, b + off, cnt)) got = 0; }
+      else { free(out); free(raw); return fail(path, "unsupported TIFF compression"); }
+      if (got < want) { free(out); free(raw); return fail(path, "short strip"); }
+      if (pred == 2 && bytes <= 4 && fmt != 3) /* horizontal differencing */
+        for (uint64_t r = 0; r < rows; ++r)
+          for (uint64_t x = cpp; x < W * cpp; ++x) {
+            unsigned char *p = raw + (r * W * cpp + x) * bytes, *q = p - cpp * bytes;
+            if (bytes == 1) p[0] += q[0];
+            else {
+              uint32_t a = 0, c2 = 0;
+              for (int k = 0; k < bytes; ++k) { a |= (uint32_t)p[t.le ? k : bytes - 1 - k] << (8 * k); c2 |= (uint32_t)q[t.le ? k : bytes - 1 - k] << (8 * k); }
+              a += c2;
+              for (int k = 0; k < bytes; ++k) p[t.le ? k : bytes - 1 - k] = (unsigned char)(a >> (8 * k));
+            }
+          }
+      for (uint64_t r = 0; r < rows; ++r)
+        for (uint64_t x = 0; x < W; ++x)
+          for (uint64_t c = 0; c < cpp; ++c) {
+            const unsigned char *p = raw + ((r * W + x) * cpp + c) * bytes;
+            uint64_t v = 0;
+            for (int k = 0; k < bytes; ++k) v |= (uint64_t)p[t.le ? k : bytes - 1 - k] << (8 * k);
+            float f;
+            if (fmt == 3) {
+              if (bytes == 4) { uint32_t u = (uint32_t)v; memcpy(&f, &u, 4); }
+              else { double dd; memcpy(&dd, &v, 8); f = (float)dd; }
+            } else if (fmt == 2) {
+              f = bytes == 1 ? (float)(int8_t)v : bytes == 2 ? (float)(int16_t)v : bytes == 4 ? (float)(int32_t)v : (float)(int64_t)v;
+            } else f = (float)v;
+            out[((s * rps + r) * W + x) * spp + (planar == 2 ? pl : c)] = f;
+          }
+    }
+  free(raw);
+  *w = (int)W; *h = (int)H; *ch = (int)spp;
+  return out;
+}
+
+/* -------------------------------------------------------------------- PNG */
+static uint32_t be32(const unsigned char *p) { return (uint32_t)p[0] << 24 | p[1] << 16 | p[2] << 8 | p[3]; }
+static float *read_png(const char *path, const unsigned char *b, size_t n, int *w, int *h, int *ch) {
+  size_t pos = 8, zlen = 0;
+  uint32_t W = 0, H = 0;
+  int depth = 0, ctype = 0, interlace = 0, npal = 0;
+  unsigned char *z = malloc(n), pal[256 * 3];
+  while (pos + 12 <= n) {
+    const uint32_t len = be32(b + pos);
+    const unsigned char *ty = b + pos + 4, *dat = b + pos + 8;
+    if (pos + 12 + len > n) break;
+    if (!memcmp(ty, "IHDR", 4)) { W = be32(dat); H = be32(dat + 4); depth = dat[8]; ctype = dat[9]; interlace = dat[12]; }
+    else if (!memcmp(ty, "PLTE", 4)) { npal = len / 3; memcpy(pal, dat, len > 768 ? 768 : len); }
+    else if (!memcmp(ty, "IDAT", 4)) { memcpy(z + zlen, dat, len); zlen += len; }
+    else if (!memcmp(ty, "IEND", 4)) break;
+    pos += 12 + len;
+  }
+  (void)npal;
+  if (!W || !H || interlace || (depth != 8 && depth != 16)) { free(z); return fail(path, "unsupported PNG (need 8/16-bit, non-interlaced)"); }
+  const int comps = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : 4;
+  const int bpp = comps * depth / 8;
+  const size_t stride = (size_t)W * bpp;
+  size_t rawlen = (stride + 1) * H;
+  unsigned char *raw = malloc(rawlen);
+  if (z_uncompress(raw, &rawlen, z, zlen) || rawlen < (stride + 1) * H) { free(z); free(raw); return fail(path, "PNG inflate failed"); }
+  free(z);
+  for (uint32_t y = 0; y < H; ++y) { /* undo the per-row filters */
+    unsigned char *cur = raw + y * (stride + 1) + 1, *up = y ? cur - (stride + 1) : NULL;
+    const int ft = cur[-1];
+    for (size_t i = 0; i < stride; ++i) {
+      const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, bb = up ? up[i] : 0, c = (up && i >= (size_t)bpp) ? up[i - bpp] : 0;
+      int add = 0;
+      if (ft == 1) add = a;
+      else if (ft == 2) add = bb;
+      else if (ft == 3) add = (a + bb) / 2;
+      else if (ft == 4) { const int p = a + bb - c, pa = abs(p - a), pb = abs(p - bb), pc = abs(p - c); add = (pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c); }
+      cur[i] = (unsigned char)(cur[i] + add);
+    }
+  }
+  const int och = ctype == 3 ? 3 : comps;
+  float *out = malloc((size_t)W * H * och * sizeof(float));
+  for (uint32_t y = 0; y < H; ++y)
+    for (uint32_t x = 0; x < W; ++x)
+      for (int c = 0; c < och; ++c) {
+        const unsigned char *p = raw + y * (stride + 1) + 1 + (size_t)x * bpp;
+        float v;
+        if (ctype == 3) v = pal[p[0] * 3 + c];
+        else v = depth == 8 ? p[c] : (float)(p[2 * c] << 8 | p[2 * c + 1]);
+        out[((size_t)y * W + x) * och + c] = v;
+      }
+  free(raw);
+  *w = (int)W; *h = (int)H; *ch = och;
+  return out;
+}
+
+float *img_read(const char *path, int *w, int *h, int *ch) {
+  if (!path) return NULL;
+  size_t n;
+  unsigned char *b = slurp(path, &n);
+  if (!b) return fail(path, "cannot open");
+  float *d = NULL;
+  if (n >= 12 && !memcmp(b, "PIEH", 4)) d = read_flo(path, b, n, w, h, ch);
+  else if (n >= 8 && ((b[0] == 'I' && b[1] == 'I') || (b[0] == 'M' && b[1] == 'M'))) d = read_tiff(path, b, n, w, h, ch);
+  else if (n >= 8 && !memcmp(b, "\x89PNG\r\n\x1a\n", 8)) d = read_png(path, b, n, w, h, ch);
+  else if (n >= 8 && b[0] == 'P' && (b[1] == 'f' || b[1] == 'F')) d = read_pfm(path, b, n, w, h, ch);
+  else fail(path, "unknown image format (supported: TIFF, PNG, PFM, FLO)");
+  free(b);
+  return d;
+}
+
+/* ------------------------------------------------------------------ write */
+static void put(unsigned char **p, uint64_t v, int bytes) { for (int i = 0; i < bytes; ++i) *(*p)++ = (unsigned char)(v >> (8 * i)); }
+
+static int write_tiff(const char *path, const float *d, int w, int h, int ch) {
+  const size_t cnt = (size_t)w * h * ch;
+  int as_bytes = 1; /* the reference's writer stores 8 bits when every sample is an integer in [0,255] */
+  for (size_t i = 0; i < cnt && as_bytes; ++i) as_bytes = d[i] >= 0 && d[i] <= 255 && d[i] == floorf(d[i]);
+  const int bytes = as_bytes ? 1 : 4;
+  const uint64_t datalen = (uint64_t)cnt * bytes;
+  const int big = datalen > 0xF0000000ull;
+  FILE *f = fopen(path, "wb");
+  if (!f) return -1;
+  unsigned char hdr[512], *p = hdr;
+  const int nent = 10, esz = big ? 20 : 12;
+  const uint64_t ifd_off = big ? 16 : 8;
+  const uint64_t bps_off = ifd_off + (big ? 8 : 2) + (uint64_t)nent * esz + (big ? 8 : 4);
+  const uint64_t data_off = bps_off + 16;
+  put(&p, 0x4949, 2);
+  if (big) { put(&p, 43, 2); put(&p, 8, 2); put(&p, 0, 2); put(&p, ifd_off, 8); put(&p, nent, 8); }
+  else { put(&p, 42, 2); put(&p, ifd_off, 4); put(&p, nent, 2); }
+#define ENT(tag, type, count, val) do { put(&p, tag, 2); put(&p, type, 2); put(&p, count, big ? 8 : 4); put(&p, val, big ? 8 : 4); } while (0)
+  const int ltype = big ? 16 : 4;
+  ENT(256, 4, 1, (uint64_t)w);
+  ENT(257, 4, 1, (uint64_t)h);
+  if (ch <= (big ? 4 : 2)) { uint64_t v = 0; for (int c = 0; c < ch; ++c) v |= (uint64_t)(8 * bytes) << (16 * c); ENT(258, 3, (uint64_t)ch, v); }
+  else ENT(258, 3, (uint64_t)ch, bps_off);
+  ENT(259, 3, 1, 1);                        /* no compression */
+  ENT(262, 3, 1, ch >= 3 ? 2 : 1);          /* RGB / min-is-black (reference: lib/iio/iio.c:3000-3020) */
+  ENT(273, ltype, 1, data_off);
+  ENT(277, 3, 1, (uint64_t)ch);
+  ENT(278, 4, 1, (uint64_t)h);
+  ENT(279, ltype, 1, datalen);
+  ENT(339, 3, 1, as_bytes ? 1 : 3);         /* sample format: uint / IEEE float */
+  put(&p, 0, big ? 8 : 4);                  /* no next IFD */
+  for (int c = 0; c < 8; ++c) put(&p, c < ch ? 8 * bytes : 0, 2);
+  fwrite(hdr, 1, (size_t)data_off, f);
+  if (as_bytes) { for (size_t i = 0; i < cnt; ++i) fputc((int)d[i], f); }
+  else fwrite(d, 4, cnt, f);
+  return fclose(f);
+}
+
+static uint32_t crc_table[256];
+static uint32_t crc32_upd(uint32_t c, const unsigned char *b, size_t n) {
+  if (!crc_table[1]) for (uint32_t i = 0; i < 256; ++i) { uint32_t k = i; for (int j = 0; j < 8; ++j) k = k & 1 ? 0xEDB88320u ^ (k >> 1) : k >> 1; crc_table[i] = k; }
+  c = ~c;
+  for (size_t i = 0; i < n; ++i) c = crc_table[(c ^ b[i]) & 255] ^ (c >> 8);
+  return ~c;
+}
+static void png_chunk(FILE *f, const char *ty, const unsigned char *d, uint32_t n) {
+  unsigned char l[4] = {(unsigned char)(n >> 24), (unsigned char)(n >> 16), (unsigned char)(n >> 8), (unsigned char)n};
+  fwrite(l, 1, 4, f); fwrite(ty, 1, 4, f); if (n) fwrite(d, 1, n, f);
+  uint32_t c = crc32_upd(crc32_upd(0, (const unsigned char *)ty, 4), d, n);
+  unsigned char cc[4] = {(unsigned char)(c >> 24), (unsigned char)(c >> 16), (unsigned char)(c >> 8), (unsigned char)c};
+  fwrite(cc, 1, 4, f);
+}
+static int write_png(const char *path, const float *d, int w, int h, int ch) {
+  if (ch < 1 || ch > 4) return -1;
+  FILE *f = fopen(path, "wb");
+  if (!f) return -1;
+  static const int ct[5] = {0, 0, 4, 2, 6};
+  const size_t stride = (size_t)w * ch + 1, rawn = stride * h;
+  /* zlib stream of stored (uncompressed) deflate blocks */
+  unsigned char *raw = malloc(rawn), *z = malloc(rawn + rawn / 65535 * 5 + 16), *q = z;
+  for (int y = 0; y < h; ++y) {
+    raw[y * stride] = 0;
+    for (size_t i = 0; i < (size_t)w * ch; ++i) { float v = d[(size_t)y * w * ch + i]; raw[y * stride + 1 + i] = (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v); }
+  }
+  *q++ = 0x78; *q++ = 0x01;
+  uint32_t a = 1, b2 = 0;
+  for (size_t o = 0; o < rawn;) {
+    const size_t k = rawn - o > 65535 ? 65535 : rawn - o;
+    *q++ = o + k == rawn; *q++ = k & 255; *q++ = k >> 8; *q++ = ~k & 255; *q++ = (~k >> 8) & 255;
+    memcpy(q, raw + o, k); q += k;
+    for (size_t i = 0; i < k; ++i) { a = (a + raw[o + i]) % 65521; b2 = (b2 + a) % 65521; }
+    o += k;
+  }
+  const uint32_t ad = b2 << 16 | a;
+  *q++ = ad >> 24; *q++ = ad >> 16; *q++ = ad >> 8; *q++ = ad;
+  fwrite("\x89PNG\r\n\x1a\n", 1, 8, f);
+  unsigned char ih[13] = {(unsigned char)(w >> 24), (unsigned char)(w >> 16), (unsigned char)(w >> 8), (unsigned char)w,
+                          (unsigned char)(h >> 24), (unsigned char)(h >> 16), (unsigned char)(h >> 8), (unsigned char)h,
+                          8, (unsigned char)ct[ch], 0, 0, 0};
+  png_chunk(f, "IHDR", ih, 13);
+  png_chunk(f, "IDAT", z, (uint32_t)(q - z));
+  png_chunk(f, "IEND", NULL, 0);
+  free(raw); free(z);
+  return fclose(f);
+}
+
+int img_write(const char *path, const float *d, int w, int h, int ch) {
+  const char *ext = strrchr(path, '.');
+  if (ext && (!strcasecmp(ext, ".tif") || !strcasecmp(ext, ".tiff"))) return write_tiff(path, d, w, h, ch);
+  if (ext && !strcasecmp(ext, ".png")) return write_png(path, d, w, h, ch);
+  FILE *f = fopen(path, "wb");
+  if (!f) return -1;
+  if (ext && !strcasecmp(ext, ".flo") && ch == 2) {
+    const int32_t wh[2] = {w, h};
+    fwrite("PIEH", 1, 4, f);
+    fwrite(wh, 4, 2, f);
+  } else if (ext && !strcasecmp(ext, ".pfm") && (ch == 1 || ch == 3)) {
+    fprintf(f, "P%c\n%d %d\n-1\n", ch == 3 ? 'F' : 'f', w, h);
+  } else {
+    fclose(f);
+    fprintf(stderr, "imgio: %s: cannot write %d channels in this format (use .tif)\n", path, ch);
+    return -1;
+  }
+  fwrite(d, 4, (size_t)w * h * ch, f);
+  return fclose(f);
+}

@@ -597,10 +597,14 @@ static void smooth_target(const frame_ctx *f, scratch_t *s, int px, int py, int 
   aggregate(f, s, nagg, vp, np0 ? 1 : 0); /* reference: :1844 */
 }
 
+/* oy/ngy: first image row and number of patch-grid rows to process (a whole
+ * frame is oy = 0, ngy = (h - psz)/step + 1). acc != NULL selects the row-strip
+ * form: nothing is normalised, the weighted sums and weights are ADDED to the
+ * planar accumulator acc[(ch+1)][h][w] (mirror of nlk_dev_frame_accumulate). */
 static void run_frame(float *out, const float *cur, const float *prev,
                       const float *basic, int w, int h, int ch, float sigma,
                       const nlko_params *P, int nthreads, nlko_trace *tr,
-                      int smoother) {
+                      int smoother, int oy, int ngy, float *acc) {
   frame_ctx f;
   memset(&f, 0, sizeof f);
   f.w = w; f.h = h; f.ch = ch;
@@ -624,7 +628,7 @@ static void run_frame(float *out, const float *cur, const float *prev,
   nlko_dct_basis(f.C, f.psz);
   memset(out, 0, sizeof(float) * (size_t)w * h * ch);
   f.ngx = (w - f.psz) / f.step + 1;
-  f.ngy = (h - f.psz) / f.step + 1;
+  f.ngy = ngy;
 #ifdef _OPENMP
   if (nthreads < 1) nthreads = 1;
   if (nthreads > 100) nthreads = 100; /* the reference aborts above 100 (:165) */
@@ -642,7 +646,7 @@ static void run_frame(float *out, const float *cur, const float *prev,
 #pragma omp for schedule(static)
     for (int gy = 0; gy < f.ngy; ++gy)
       for (int gx = 0; gx < f.ngx; ++gx) {
-        const int px = gx * f.step, py = gy * f.step;
+        const int px = gx * f.step, py = oy + gy * f.step;
         int m;
 #pragma omp atomic read
         m = f.mask[px + (long)py * w];
@@ -656,6 +660,13 @@ static void run_frame(float *out, const float *cur, const float *prev,
     scratch_free(&s);
   }
 
+  if (acc) {
+    const long npix = (long)w * h;
+    for (long i = 0; i < npix; ++i) {
+      for (int c = 0; c < ch; ++c) acc[c * npix + i] += out[i * ch + c];
+      acc[ch * npix + i] += f.aggr[i];
+    }
+  } else
   /* normalisation with the absolute 1e-6 threshold (reference: :939-942, :1853-1856) */
   for (long i = 0; i < (long)w * h; ++i)
     for (int c = 0; c < ch; ++c) {
@@ -670,14 +681,34 @@ static void run_frame(float *out, const float *cur, const float *prev,
 void nlko_filter_frame(float *deno1, const float *nisy1, const float *deno0,
                        const float *bsic1, int w, int h, int ch, float sigma,
                        const nlko_params *P, int nthreads, nlko_trace *tr) {
-  run_frame(deno1, nisy1, deno0, bsic1, w, h, ch, sigma, P, nthreads, tr, 0);
+  run_frame(deno1, nisy1, deno0, bsic1, w, h, ch, sigma, P, nthreads, tr, 0, 0,
+            (h - P->patch_sz) / (P->patch_sz / 2) + 1, NULL);
 }
 
 /* reference: src/nlkalman.c:1409-1865 */
 void nlko_smooth_frame(float *smoo1, const float *filt1, const float *smoo0,
                        const float *bsic1, int w, int h, int ch, float sigma,
                        const nlko_params *P, int nthreads, nlko_trace *tr) {
-  run_frame(smoo1, filt1, smoo0, bsic1, w, h, ch, sigma, P, nthreads, tr, 1);
+  run_frame(smoo1, filt1, smoo0, bsic1, w, h, ch, sigma, P, nthreads, tr, 1, 0,
+            (h - P->patch_sz) / (P->patch_sz / 2) + 1, NULL);
+}
+
+/* row-strip form (mirror of nlk_dev_frame_accumulate / _normalize in include/nlk_hip.h) */
+void nlko_frame_accumulate(float *acc, const float *cur, const float *prev,
+                           const float *basic, int w, int h, int ch, float sigma,
+                           const nlko_params *P, int oy, int ngy, int smoother) {
+  float *tmp = malloc(sizeof(float) * (size_t)w * h * ch);
+  run_frame(tmp, cur, prev, basic, w, h, ch, sigma, P, 1, NULL, smoother, oy, ngy, acc);
+  free(tmp);
+}
+
+void nlko_frame_normalize(float *out, const float *acc, const float *cur, int w, int h,
+                          int ch, int y0, int y1) {
+  const long npix = (long)w * h;
+  for (long i = (long)y0 * w; i < (long)y1 * w; ++i)
+    for (int c = 0; c < ch; ++c)
+      out[i * ch + c] = acc[ch * npix + i] > 1e-6 ? acc[c * npix + i] / acc[ch * npix + i]
+                                                  : cur[i * ch + c];
 }
 
 int nlko_max_threads(void) {

@@ -39,5 +39,10 @@ void nlko_filter_frame(float *deno1, const float *nisy1, const float *deno0,
 void nlko_smooth_frame(float *smoo1, const float *filt1, const float *smoo0,
                        const float *bsic1, int w, int h, int ch, float sigma,
                        const nlko_params *P, int nthreads, nlko_trace *tr);
+void nlko_frame_accumulate(float *acc, const float *cur, const float *prev,
+                           const float *basic, int w, int h, int ch, float sigma,
+                           const nlko_params *P, int oy, int ngy, int smoother);
+void nlko_frame_normalize(float *out, const float *acc, const float *cur, int w, int h,
+                          int ch, int y0, int y1);
 int nlko_max_threads(void);
 #endif

@@ -63,6 +63,9 @@ def lib():
         for f in (L.nlko_filter_frame, L.nlko_smooth_frame):
             f.argtypes = [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float,
                           C.POINTER(Params), C.c_int, C.POINTER(Trace)]
+        L.nlko_frame_accumulate.argtypes = [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float,
+                                            C.POINTER(Params), C.c_int, C.c_int, C.c_int]
+        L.nlko_frame_normalize.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.nlko_max_threads.restype = C.c_int
         _LIB = L
     return _LIB
@@ -182,6 +185,23 @@ def filter_frame(nisy1, deno0, bsic1, sigma, params, nthreads=1, trace=False):
 def smooth_frame(filt1, smoo0, bsic1, sigma, params, nthreads=1, trace=False):
     return _run(lib().nlko_smooth_frame, filt1, smoo0, bsic1, sigma, params,
                 nthreads, trace)
+
+
+def frame_accumulate(acc, cur, prev, basic, sigma, params, oy, ngy, smoother=False):
+    """Row-strip form: adds into the planar accumulator acc[(ch+1), h, w] in place."""
+    cur, prev, basic = _img(cur), _img(prev), _img(basic)
+    h, w, ch = cur.shape
+    assert acc.dtype == np.float32 and acc.shape == (ch + 1, h, w) and acc.flags.c_contiguous
+    lib().nlko_frame_accumulate(_fp(acc), _fp(cur), _fp(prev), _fp(basic), w, h, ch, float(sigma),
+                                C.byref(params), int(oy), int(ngy), int(smoother))
+
+
+def frame_normalize(acc, cur, y0, y1):
+    cur = _img(cur)
+    h, w, ch = cur.shape
+    out = np.zeros_like(cur)
+    lib().nlko_frame_normalize(_fp(out), _fp(acc), _fp(cur), w, h, ch, int(y0), int(y1))
+    return out
 
 
 def max_threads():
