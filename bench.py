@@ -151,9 +151,16 @@ def main():
         dur = tm[dom + "_ms"] * 1e-3
         gbs = alg_bytes[dom] / world / dur / 1e9 if dur > 0 else 0.0
         tfl = alg_flops[dom] / world / dur / 1e12 if dur > 0 else 0.0
-        roof = {"kernel": "k_group8" if dom == "group" else "k_bm_topk", "bound": "hbm",
+        kname = "k_group8" if dom == "group" else "k_bm_topk"
+        # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs, tools/pmc_run.sh); valid for the single-GPU C2 launch only
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if world == 1 and args.workload == "C2" and os.path.exists(tpath):
+            traffic = json.load(open(tpath))["kernels"].get(kname, {}).get("traffic_bytes")
+        roof = {"kernel": kname, "bound": "hbm",
                 "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs / HBM_PEAK_GBS, 6), "traffic": None,
+                "frac": round(gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "launch_ms": round(tm[dom + "_ms"], 4),
                 "algorithmic_bytes_per_launch": alg_bytes[dom] // world,
                 "valu": {"achieved": round(tfl, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
