@@ -45,29 +45,26 @@ k_mask_commit(const uint64_t* __restrict__ marks, uint8_t* __restrict__ active, 
   // most two 32-bit LDS atomics: no per-bit loop, no division.
   const int centre = R * side + R;
   const uint32_t rowmask = (1u << side) - 1u;
+  // LDS atomics retire about one lane per clock on gfx950, so they are issued
+  // only by the lanes that really have a bit to set.
   auto or_bits = [&](int pos, uint32_t mask) {  // bits[pos ...] |= mask
-    if (!mask) return;
     const int wd = pos >> 5, sh = pos & 31;
-    const uint32_t lo = mask << sh;
-    const uint32_t hi = sh ? (mask >> (32 - sh)) : 0u;
-    if (lo) atomicOr(&bits[wd], lo);
-    if (hi) atomicOr(&bits[wd + 1], hi);
+    const uint64_t m2 = (uint64_t)mask << sh;
+    if ((uint32_t)m2) atomicOr(&bits[wd], (uint32_t)m2);
+    if ((uint32_t)(m2 >> 32)) atomicOr(&bits[wd + 1], (uint32_t)(m2 >> 32));
   };
   auto decide = [&](int s, const uint64_t (&mw)[RPT]) {
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
       const int j = threadIdx.x + r * blockDim.x;
       const int i = s - skew * j;
-      if (j < ngy && i >= 0 && i < ngx) {
-        const int t = j * ngx + i;
-        const bool done = (bits[t >> 5] >> (t & 31)) & 1u;
-        if (!done) {
-          const uint64_t fwd = mw[r] >> (centre + 1);
-          or_bits(t + 1, (uint32_t)fwd & ((1u << R) - 1u));        // same row, di = 1..R
-          for (int dj = 1; dj <= R; ++dj)                            // rows below, di = -R..R
-            or_bits(t + dj * ngx - R, (uint32_t)(fwd >> (R + (dj - 1) * side)) & rowmask);
-        }
-      }
+      const bool in = j < ngy && i >= 0 && i < ngx;
+      const int t = in ? j * ngx + i : 0;
+      const bool done = (bits[t >> 5] >> (t & 31)) & 1u;
+      const uint64_t fwd = (in && !done) ? (mw[r] >> (centre + 1)) : 0ull;
+      or_bits(t + 1, (uint32_t)fwd & ((1u << R) - 1u));          // same row, di = 1..R
+      for (int dj = 1; dj <= R; ++dj)                              // rows below, di = -R..R
+        or_bits(t + dj * ngx - R, (uint32_t)(fwd >> (R + (dj - 1) * side)) & rowmask);
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): LDS atomics issued; loads stay in flight
     __builtin_amdgcn_s_barrier();

@@ -90,28 +90,38 @@ __device__ inline void nlk_match_target(const float* __restrict__ tile, int plan
   }
 
   // --- k-th smallest distance by bitwise radix select (keys are >= +0: uint order)
+  // The set of candidates still matching the prefix is kept as one 64-bit lane
+  // mask per round in scalar registers; per bit only the bit test is vector work.
   uint32_t prefix = 0;
   int kk = k;
+  uint64_t alive[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) alive[m] = __ballot(ok[m]);
 #pragma unroll 1
   for (int b = 31; b >= 0; --b) {
-    const uint32_t hi = (b == 31) ? 0u : (0xFFFFFFFFu << (b + 1));
+    uint64_t one[M];
     int cnt0 = 0;
 #pragma unroll
-    for (int m = 0; m < M; ++m)
-      cnt0 += __popcll(__ballot(ok[m] && (key[m] & hi) == prefix && !((key[m] >> b) & 1u)));
-    if (kk > cnt0) {
+    for (int m = 0; m < M; ++m) {
+      one[m] = __ballot((key[m] >> b) & 1u);
+      cnt0 += __popcll(alive[m] & ~one[m]);
+    }
+    const bool take1 = kk > cnt0;  // the k-th smallest has bit b set
+    if (take1) {
       prefix |= 1u << b;
       kk -= cnt0;
     }
+#pragma unroll
+    for (int m = 0; m < M; ++m) alive[m] &= take1 ? one[m] : ~one[m];
   }
-  // prefix = k-th smallest key; kk = how many of the keys equal to it are kept
-  // (in window order, i.e. by ascending candidate index)
+  // prefix = k-th smallest key (alive = the keys equal to it); kk = how many of
+  // those are kept (in window order, i.e. by ascending candidate index)
   int ntie = 0, npos = 0;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     const bool eq = ok[m] && key[m] == prefix;
-    const uint64_t be = __ballot(eq);
+    const uint64_t be = alive[m];
     const int my_tie = ntie + __popcll(be & lt_mask);
     ntie += __popcll(be);
     const bool keep = ok[m] && (key[m] < prefix || (eq && my_tie < kk));
