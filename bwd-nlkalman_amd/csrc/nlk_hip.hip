@@ -156,7 +156,9 @@ template <int CH, bool SMO>
 int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
                     const float* prev, float* acc) {
   NlkGTile tl{};
-  tl.tgx = 4; tl.tgy = 4;
+  // 4 x 1 targets per wavefront measured best (profiles/README.md); NLK_GTX/NLK_GTY override for experiments
+  tl.tgx = getenv("NLK_GTX") ? atoi(getenv("NLK_GTX")) : 4;
+  tl.tgy = getenv("NLK_GTY") ? atoi(getenv("NLK_GTY")) : 1;
   tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
   tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
   // LDS tile halo = reach of the dominant kind of group; the rare spatial-branch
@@ -498,7 +500,8 @@ int nlk_dev_frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const flo
   // ---- block matching + selection
   const float* img_match = basic ? img_basic : img_cur;
   NlkTile tl{};
-  tl.tgx = 8; tl.tgy = 4;
+  tl.tgx = getenv("NLK_MTX") ? atoi(getenv("NLK_MTX")) : 8;
+  tl.tgy = getenv("NLK_MTY") ? atoi(getenv("NLK_MTY")) : 4;
   tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
   tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
   // LDS holds the halo of the dominant window; its row stride = window width

@@ -171,6 +171,46 @@ def test_strip_accumulate_equals_whole_frame(ctx, built):
         ctx.free(x)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_gpu_strips_match_oracle_strips(ctx, built, O, synth, world):
+    """The row-strip form exactly as the multi-GPU driver uses it (strip + halo
+    images, oy / ngy target rows, halo rows of the accumulator added to the
+    neighbour, per-strip mask replay) on one GPU, against the same procedure
+    on the oracle; temporal FLT1 so that the mask really couples targets."""
+    import importlib
+    strips = importlib.import_module("bwd-nlkalman_amd.strips")
+    w, h, ch, sigma = 64, 96, 3, 20.0
+    n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, 21)
+    o0, o1 = O.rgb2opp(n0), O.rgb2opp(n1)
+    p = built.default_params(sigma, built.FLT1)
+    po = _to_o(O, p)
+    prev = O.filter_frame(o0, None, None, sigma, po)
+    plan = strips.strip_plan(h, p.patch_sz, max(p.search_sz_x, p.search_sz_t), world)
+    step = p.patch_sz // 2
+    acc_g = np.zeros((ch + 1, h, w), np.float32)
+    acc_o = np.zeros((ch + 1, h, w), np.float32)
+    for s in plan:
+        hl = s["Y1"] - s["Y0"]
+        cur_s = np.ascontiguousarray(o1[s["Y0"]:s["Y1"]])
+        prev_s = np.ascontiguousarray(prev[s["Y0"]:s["Y1"]])
+        oy, ngy = s["gy0"] * step - s["Y0"], s["gy1"] - s["gy0"]
+        a = np.zeros((ch + 1, hl, w), np.float32)
+        O.frame_accumulate(a, cur_s, prev_s, None, sigma, po, oy, ngy)
+        acc_o[:, s["Y0"]:s["Y1"]] += a
+        d_cur, d_prev, d_acc = ctx.upload(cur_s), ctx.upload(prev_s), ctx.upload(np.zeros_like(a))
+        ctx.frame_accumulate(d_acc, d_cur, d_prev, None, w, hl, ch, sigma, p, oy, ngy)
+        acc_g[:, s["Y0"]:s["Y1"]] += ctx.download(d_acc, a.shape)
+        for x in (d_cur, d_prev, d_acc):
+            ctx.free(x)
+    want = O.frame_normalize(acc_o, o1, 0, h)
+    d_acc, d_cur, d_out = ctx.upload(acc_g), ctx.upload(o1), ctx.alloc(o1.nbytes)
+    ctx.frame_normalize(d_out, d_acc, d_cur, w, h, ch, 0, h)
+    got = ctx.download(d_out, o1.shape)
+    for x in (d_acc, d_cur, d_out):
+        ctx.free(x)
+    cases.assert_close(got, want, f"{world} strips on the GPU vs on the oracle")
+
+
 def test_full_size_1080p_against_oracle(ctx, built, O, synth):
     """BASELINE.json configs[1] at full size: 1920x1080 RGB sigma=20 FLT1
     temporal. The serial oracle needs ~25 s; mask decisions must be identical,
