@@ -16,6 +16,7 @@
 #include "k_frame.h"
 #include "k_group.h"
 #include "k_group8.h"
+#include "k_group12.h"
 #include "k_match.h"
 #include "nlk_common.h"
 
@@ -152,9 +153,9 @@ int launch_group_ch(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
   return fail(c, NLK_EUNSUP, "patch size %d not supported (4, 6, 8, 10, 12, 16)", g.psz);
 }
 
-template <int CH, bool SMO>
-int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
-                    const float* prev, float* acc) {
+template <int PSZ, int CH, bool SMO>
+int launch_group_fast_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
+                        const float* prev, float* acc) {
   NlkGTile tl{};
   // 4 x 1 targets per wavefront measured best (profiles/README.md); NLK_GTX/NLK_GTY override for experiments
   tl.tgx = getenv("NLK_GTX") ? atoi(getenv("NLK_GTX")) : 4;
@@ -168,14 +169,18 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
   tl.rh_max = (tl.tgy - 1) * g.step + 2 * tl.wmax + g.psz;
   const size_t lds = sizeof(float) * (size_t)(CH + 1) * tl.rwp * tl.rh_max;
   if (lds > 160 * 1024) return fail(c, NLK_EUNSUP, "aggregation tile needs %zu bytes of LDS", lds);
-  auto kern = k_group8<CH, SMO>;
+  void (*kern)(const float*, const float*, const float*, const uint8_t*, NlkGeom, NlkGTile,
+               const uint32_t*, const NlkTarget*, const uint32_t*, const uint8_t*, const float*,
+               const float*, float*);
+  if (PSZ == 8) kern = k_group8<CH, SMO>;
+  else kern = k_group12<CH, SMO>;
   HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
   const float* basis = (const float*)c->tabs.p;
   hipLaunchKernelGGL(kern, dim3(tl.ntx * tl.nty), dim3(64), lds, c->stream, img, cur, prev,
                      (const uint8_t*)c->vmap.p, g, tl, (const uint32_t*)c->topk.p,
                      (const NlkTarget*)c->tinfo.p, (const uint32_t*)c->gcoords.p,
-                     (const uint8_t*)c->active.p, basis, basis + 64, acc);
+                     (const uint8_t*)c->active.p, basis, basis + PSZ * PSZ, acc);
   HIPCHK(c, hipGetLastError());
   return NLK_OK;
 }
@@ -183,13 +188,14 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
 int launch_group(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
                  const float* prev, float* acc) {
   // register/DPP fast path (its per-lane candidate lists hold up to 128 entries)
-  if (g.psz == 8 && g.kmax <= 128 && g.gstride <= 128 && !getenv("NLK_GENERIC_GROUP")) {
-    if (g.ch == 1)
-      return g.smoother ? launch_group8_t<1, true>(c, g, img, cur, prev, acc)
-                        : launch_group8_t<1, false>(c, g, img, cur, prev, acc);
-    if (g.ch == 3)
-      return g.smoother ? launch_group8_t<3, true>(c, g, img, cur, prev, acc)
-                        : launch_group8_t<3, false>(c, g, img, cur, prev, acc);
+  if ((g.psz == 8 || g.psz == 12) && g.kmax <= 128 && g.gstride <= 128 &&
+      !getenv("NLK_GENERIC_GROUP")) {
+#define NLK_FAST(P, C)                                                                    \
+  if (g.psz == P && g.ch == C)                                                            \
+    return g.smoother ? launch_group_fast_t<P, C, true>(c, g, img, cur, prev, acc)        \
+                      : launch_group_fast_t<P, C, false>(c, g, img, cur, prev, acc);
+    NLK_FAST(8, 1) NLK_FAST(8, 3) NLK_FAST(12, 1) NLK_FAST(12, 3)
+#undef NLK_FAST
   }
   if (g.ch == 1) return launch_group_ch<1>(c, g, img, cur, prev, acc);
   if (g.ch == 3) return launch_group_ch<3>(c, g, img, cur, prev, acc);
