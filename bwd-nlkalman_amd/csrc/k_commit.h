@@ -99,3 +99,120 @@ k_mask_commit(const uint64_t* __restrict__ marks, uint8_t* __restrict__ active, 
   for (int t = threadIdx.x; t < ntot; t += blockDim.x)
     active[t] = !((bits[t >> 5] >> (t & 31)) & 1u);
 }
+
+// ---------------------------------------------------------------------------
+// Register-resident variant (patch grids of up to 1024 rows): no LDS mask, no
+// barrier. Lane = grid row; the marks a row receives from the R rows above are
+// 2R+1-bit row masks that travel lane -> lane+1 by DPP (wave_shr:1) and are
+// OR-ed into a small per-lane shift register of pending marks for the next
+// (R+1)^2 columns; a row's own forward marks go into the same register. Only
+// the last R lanes of a wavefront publish their masks through an LDS ring, and
+// the next wavefront (which runs one phase of 16 steps behind) polls a progress
+// word once per phase before consuming them. A step is ~40 instructions instead of an LDS
+// round trip + atomics + workgroup barrier.
+// ---------------------------------------------------------------------------
+#define NLK_CW_RING 64  // steps of edge data kept per wavefront
+
+template <int R>
+__global__ void __launch_bounds__(1024)
+k_mask_commit_wave(const uint64_t* __restrict__ marks, uint8_t* __restrict__ active, int ngx,
+                   int ngy) {
+  constexpr int side = 2 * R + 1, skew = R + 1, centre = R * side + R;
+  constexpr uint32_t rowmask = (1u << side) - 1u;
+  constexpr int S = 16;  // steps per phase: progress is exchanged once per phase
+  __shared__ uint32_t edge[16][NLK_CW_RING][R];  // [wave][step % ring][lane 64-R+e]: packed row masks
+  __shared__ int prog[16];                        // steps published by each wavefront
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int j = threadIdx.x;  // grid row
+  if (lane == 0) prog[wave] = 0;
+  __syncthreads();
+  const int nsteps = ngx + skew * (ngy - 1);
+  auto fetch = [&](int s) -> uint64_t {
+    const int i = s - skew * j;
+    return (j < ngy && i >= 0 && i < ngx) ? marks[(size_t)j * ngx + i] : 0ull;
+  };
+  auto ld_prog = [&](int w) {
+    return __hip_atomic_load(&prog[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  uint64_t A[S], B[S];
+#pragma unroll
+  for (int e = 0; e < S; ++e) A[e] = fetch(e);
+  uint32_t pend = 0;  // bit b: column (current + b) of this row is already marked
+  uint32_t outp = 0;  // row masks this lane produced in the previous step, `side` bits per dj
+  for (int s0 = 0; s0 < nsteps; s0 += S) {
+#pragma unroll
+    for (int e = 0; e < S; ++e) B[e] = fetch(s0 + S + e);
+    // ---- masks the previous wavefront's last R lanes produced in steps s0-1 .. s0+S-2:
+    // wait once per phase until it has published them, then read them in one go
+    uint32_t above[S];
+#pragma unroll
+    for (int e = 0; e < S; ++e) above[e] = 0;
+    if (wave > 0) {
+      while (ld_prog(wave - 1) < min(s0 + S - 1, nsteps)) __builtin_amdgcn_s_sleep(1);
+      if (lane < R) {
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+          const int sp = s0 + e - 1;  // producing step
+          uint32_t acc = 0;
+#pragma unroll
+          for (int dj = lane + 1; dj <= R; ++dj)  // source lane 64 + lane - dj of the previous wavefront
+            if (sp >= 0)
+              acc |= ((edge[wave - 1][sp % NLK_CW_RING][R + lane - dj] >> ((dj - 1) * side)) & rowmask)
+                     << (skew * dj - 1 - R);
+          above[e] = acc;
+        }
+      }
+    }
+    // flow control: the slots written in this phase must have been consumed
+    if (wave + 1 < nwaves)
+      while (ld_prog(wave + 1) < s0 + S - NLK_CW_RING + 1) __builtin_amdgcn_s_sleep(1);
+
+    uint32_t flags[S / 4] = {0, 0, 0, 0};  // decisions of this phase, one byte each
+#pragma unroll
+    for (int e = 0; e < S; ++e) {
+      const int s = s0 + e;
+      // ---- marks produced one step ago by the R rows above (inside this wavefront by DPP)
+      uint32_t sh = outp, inc = above[e];
+#pragma unroll
+      for (int dj = 1; dj <= R; ++dj) {
+        sh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sh, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+        const uint32_t m = (sh >> ((dj - 1) * side)) & rowmask;
+        inc |= (lane >= dj ? m : 0u) << (skew * dj - 1 - R);
+      }
+      pend |= inc;
+      // ---- decide this row's target of step s
+      const int i = s - skew * j;
+      const bool in = j < ngy && i >= 0 && i < ngx;
+      const bool act = in && !(pend & 1u);
+      flags[e / 4] |= (uint32_t)act << (8 * (e % 4));
+      const uint64_t fwd = act ? (A[e] >> (centre + 1)) : 0ull;
+      const uint32_t own = (uint32_t)fwd & ((1u << R) - 1u);   // same row, columns i+1 .. i+R
+      outp = (uint32_t)(fwd >> R) & ((1u << (R * side)) - 1u);  // rows below, side bits per dj
+      pend = (pend >> 1) | own;
+      if (lane >= 64 - R) edge[wave][s % NLK_CW_RING][lane - (64 - R)] = outp;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // this phase's edge words are in LDS
+    if (lane == 63)
+      __hip_atomic_store(&prog[wave], s0 + S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // write the phase's decisions: whole 32-bit words where the 4 columns exist
+    {
+      const int i0 = s0 - skew * j;  // column of step s0 for this row
+      uint8_t* row = active + (size_t)j * ngx;
+#pragma unroll
+      for (int q = 0; q < S / 4; ++q) {
+        const int i = i0 + 4 * q;
+        if (j < ngy && i >= 0 && i + 3 < ngx) {
+          __builtin_memcpy(row + i, &flags[q], 4);
+        } else if (j < ngy) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            if (i + b >= 0 && i + b < ngx) row[i + b] = (uint8_t)(flags[q] >> (8 * b));
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < S; ++e) A[e] = B[e];
+  }
+}

@@ -530,7 +530,16 @@ int nlk_dev_frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const flo
   mark(c, 2);
 
   // ---- processed-mask replay
-  {
+  if (g.R == 0) {
+    // a group cannot reach another grid target: nothing is ever skipped
+    HIPCHK(c, hipMemsetAsync(c->active.p, 1, (size_t)ngrid, c->stream));
+  } else if (g.ngy <= 1024 && !getenv("NLK_COMMIT_LDS")) {
+    const int threads = ((g.ngy + 63) / 64) * 64;
+    auto kern = g.R == 1 ? k_mask_commit_wave<1> : (g.R == 2 ? k_mask_commit_wave<2> : k_mask_commit_wave<3>);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(threads), 0, c->stream, (const uint64_t*)c->marks.p,
+                       (uint8_t*)c->active.p, g.ngx, g.ngy);
+    HIPCHK(c, hipGetLastError());
+  } else {
     const int rpt = (g.ngy + 1023) / 1024;
     const int threads = min(1024, ((g.ngy + 63) / 64) * 64);
     const size_t bits = sizeof(uint32_t) * ((size_t)(ngrid + (g.R + 1) * g.ngx + 63) / 32 + 1);
