@@ -172,8 +172,11 @@ __device__ __forceinline__ float nlk_wave_sum8(float v) {
   return v;
 }
 
+#ifndef NLK_G8_WAVES
+#define NLK_G8_WAVES 4
+#endif
 template <int CH, bool SMO>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, NLK_G8_WAVES)
 k_group8(const float* __restrict__ img,   // matching / statistics image (planar)
          const float* __restrict__ cur,   // image whose patches are filtered
          const float* __restrict__ prev,  // previous output or nullptr
