@@ -239,3 +239,36 @@ def test_full_size_1080p_against_oracle(ctx, built, O, synth):
     # (adding the offset re-rounds the pixels, so a few near-tied k-NN ranks flip: quantiles)
     assert np.quantile(d, 0.9999) < 2e-2
     assert np.quantile(np.abs(g2[..., 1:] - g[..., 1:]), 0.9999) < 2e-2
+
+
+def test_4k_patch12_against_parallel_oracle(ctx, built, O, synth):
+    """BASELINE.json configs[2] geometry (3840x2160 RGB, sigma 40, 12x12 patches),
+    temporal FLT1. With step 6 > temporal radius 5 a group never reaches another
+    grid target, so the processed-mask never fires and the OpenMP oracle is
+    deterministic: full-size comparison in seconds."""
+    w, h, ch, sigma = 3840, 2160, 3, 40.0
+    n0, n1, c1 = synth.noisy_pair(w, h, ch, sigma, 2)
+    o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+    p = built.default_params(sigma, built.FLT1, patch_sz=12)
+    po = _to_o(O, p)
+    prev, _ = _dev_frame(ctx, False, o0, None, None, sigma, p)
+    g, rec = _dev_frame(ctx, False, o1, prev, None, sigma, p)
+    assert rec["active"].all()
+    r = O.filter_frame(o1, prev, None, sigma, po, nthreads=min(O.max_threads(), 100))
+    cases.assert_close(g, r, "4K psz12", flips=160)
+    assert abs(synth.psnr(built.opp2rgb(g), c1) - synth.psnr(O.opp2rgb(r), c1)) <= 0.02
+    assert synth.psnr(built.opp2rgb(g), c1) > synth.psnr(n1, c1) + 8
+
+
+def test_smoother_full_size_1080p(ctx, built, O, synth):
+    """flt2 -> smo1 at 1080p (BASELINE.json configs[4] last stage), serial oracle."""
+    w, h, ch, sigma = 1920, 1080, 3, 20.0
+    n0, n1, c1 = synth.noisy_pair(w, h, ch, sigma, 1)
+    o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+    p1, ps = built.default_params(sigma, built.FLT1), built.default_params(sigma, built.SMO1)
+    f0, _ = _dev_frame(ctx, False, o0, None, None, sigma, p1)
+    f1, _ = _dev_frame(ctx, False, o1, f0, None, sigma, p1)
+    g, rec = _dev_frame(ctx, True, f0, f1, None, sigma, ps)
+    r, tr = O.smooth_frame(f0, f1, None, sigma, _to_o(O, ps), trace=True)
+    _check_records(rec, tr, "smo 1080p")
+    cases.assert_close(g, r, "smo 1080p", flips=40)
