@@ -95,13 +95,19 @@ __device__ inline void nlk_match_target(const float* __restrict__ tile, int plan
   // --- k-th smallest distance by bitwise radix select (keys are >= +0: uint order)
   // The set of candidates still matching the prefix is kept as one 64-bit lane
   // mask per round in scalar registers; per bit only the bit test is vector work.
-  uint32_t prefix = 0;
-  int kk = k;
-  uint64_t alive[M];
+  int kk = k;                    // how many of the still-undecided candidates are wanted
+  uint64_t alive[M], less[M];    // undecided / already known to be among the k smallest
+  int nalive = 0;
 #pragma unroll
-  for (int m = 0; m < M; ++m) alive[m] = __ballot(ok[m]);
+  for (int m = 0; m < M; ++m) {
+    alive[m] = __ballot(ok[m]);
+    less[m] = 0;
+    nalive += __popcll(alive[m]);
+  }
+  // walk the key bits from the top; stop as soon as exactly kk candidates are undecided
+  // (they are then all kept) — typically after ~16 of the 32 bits
 #pragma unroll 1
-  for (int b = 31; b >= 0; --b) {
+  for (int b = 31; b >= 0 && nalive != kk; --b) {
     uint64_t one[M];
     int cnt0 = 0;
 #pragma unroll
@@ -109,25 +115,31 @@ __device__ inline void nlk_match_target(const float* __restrict__ tile, int plan
       one[m] = __ballot((key[m] >> b) & 1u);
       cnt0 += __popcll(alive[m] & ~one[m]);
     }
-    const bool take1 = kk > cnt0;  // the k-th smallest has bit b set
-    if (take1) {
-      prefix |= 1u << b;
-      kk -= cnt0;
-    }
+    if (kk > cnt0) {  // the k-th smallest has bit b set: everything with a 0 here is smaller
 #pragma unroll
-    for (int m = 0; m < M; ++m) alive[m] &= take1 ? one[m] : ~one[m];
+      for (int m = 0; m < M; ++m) {
+        less[m] |= alive[m] & ~one[m];
+        alive[m] &= one[m];
+      }
+      kk -= cnt0;
+      nalive -= cnt0;
+    } else {
+#pragma unroll
+      for (int m = 0; m < M; ++m) alive[m] &= ~one[m];
+      nalive = cnt0;
+    }
   }
-  // prefix = k-th smallest key (alive = the keys equal to it); kk = how many of
-  // those are kept (in window order, i.e. by ascending candidate index)
+  // undecided candidates now either number exactly kk (all kept) or share one key
+  // value, of which the first kk in window order (ascending candidate index) are kept
   int ntie = 0, npos = 0;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
   for (int m = 0; m < M; ++m) {
-    const bool eq = ok[m] && key[m] == prefix;
     const uint64_t be = alive[m];
     const int my_tie = ntie + __popcll(be & lt_mask);
     ntie += __popcll(be);
-    const bool keep = ok[m] && (key[m] < prefix || (eq && my_tie < kk));
+    const bool mine = (be >> lane) & 1ull;
+    const bool keep = ((less[m] >> lane) & 1ull) || (mine && my_tie < kk);
     const uint64_t bk = __ballot(keep);
     if (keep) {
       const int pos = npos + __popcll(bk & lt_mask);
