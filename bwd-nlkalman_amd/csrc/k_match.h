@@ -52,8 +52,8 @@ template <int PSZ, int CH, int M>
 __device__ inline void nlk_match_target(const float* __restrict__ tile, int plane, int rwp,
                                         const float* __restrict__ tgt, int tplane, int trw,
                                         int cbase, int nwx, int n, int k, int x0, int y0,
-                                        uint32_t* __restrict__ skey, uint32_t* __restrict__ sidx,
-                                        uint32_t* __restrict__ sel, int lane) {
+                                        uint64_t* __restrict__ surv, uint32_t* __restrict__ sel,
+                                        int lane) {
   int cq[M];
   float acc[M];
 #pragma unroll
@@ -141,26 +141,22 @@ __device__ inline void nlk_match_target(const float* __restrict__ tile, int plan
     const bool mine = (be >> lane) & 1ull;
     const bool keep = ((less[m] >> lane) & 1ull) || (mine && my_tie < kk);
     const uint64_t bk = __ballot(keep);
-    if (keep) {
+    if (keep) {  // survivors as one 64-bit sort key: distance bits above, window index below
       const int pos = npos + __popcll(bk & lt_mask);
-      skey[pos] = key[m];
-      sidx[pos] = lane + 64 * m;
+      surv[pos] = ((uint64_t)key[m] << 32) | (uint32_t)(lane + 64 * m);
     }
     npos += __popcll(bk);
   }
   nlk_wave_lds_fence();
 
-  // --- rank the k survivors among themselves
+  // --- rank the k survivors among themselves (one 64-bit compare per pair)
   for (int base = 0; base < k; base += 64) {
     const int p = base + lane;
-    const uint32_t mk = p < k ? skey[p] : 0xFFFFFFFFu;
-    const uint32_t mi = p < k ? sidx[p] : 0xFFFFFFFFu;
+    const uint64_t mine = p < k ? surv[p] : ~0ull;
     int rank = 0;
-    for (int j = 0; j < k; ++j) {
-      const uint32_t kj = skey[j], ij = sidx[j];
-      rank += (kj < mk) || (kj == mk && ij < mi);
-    }
+    for (int j = 0; j < k; ++j) rank += surv[j] < mine;
     if (p < k) {
+      const int mi = (int)(uint32_t)mine;
       const int wy = mi / nwx, wx = mi - wy * nwx;
       sel[rank] = nlk_pack_xy(x0 + wx, y0 + wy);
     }
@@ -195,9 +191,9 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
   const int plane = rwp * tl.rh_max;
 
   float* tile = smem;                                  // [CH][rh_max][rwp]
-  uint32_t* skey_all = (uint32_t*)(tile + CH * plane);  // [waves][ksel_max]
-  uint32_t* sidx_all = skey_all + NLK_BM_WAVES * tl.ksel_max;
-  uint32_t* sel_all = sidx_all + NLK_BM_WAVES * tl.ksel_max;
+  // (the tile size is kept even so that the 64-bit survivor array is 8-byte aligned)
+  uint64_t* surv_all = (uint64_t*)(tile + ((CH * plane + 1) & ~1));  // [waves][ksel_max]
+  uint32_t* sel_all = (uint32_t*)(surv_all + NLK_BM_WAVES * tl.ksel_max);
   uint32_t* grp_all = sel_all + NLK_BM_WAVES * tl.ksel_max;  // [waves][gstride]
 
   const size_t npix = (size_t)g.w * g.h;
@@ -235,8 +231,7 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
     const int ty = lane / cx, tx = lane - ty * cx;
     rec_prev = vmap[(size_t)(g.oy + (gy0 + ty) * step) * g.w + (gx0 + tx) * step];
   }
-  uint32_t* skey = skey_all + wave * tl.ksel_max;
-  uint32_t* sidx = sidx_all + wave * tl.ksel_max;
+  uint64_t* surv = surv_all + wave * tl.ksel_max;
   uint32_t* sel = sel_all + wave * tl.ksel_max;
   uint32_t* grp = grp_all + wave * g.gstride;
 
@@ -271,26 +266,26 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
       const float* tl_tgt = tile + (py - ry0) * rwp + (px - rx0);
       if (n <= 128)
         nlk_match_target<PSZ, CH, 2>(tile, plane, rwp, tl_tgt, plane, rwp, cbase, nwx, n, k, x0,
-                                     y0, skey, sidx, sel, lane);
+                                     y0, surv, sel, lane);
       else if (MAXM <= 7 || n <= 448)
         nlk_match_target<PSZ, CH, (MAXM < 7 ? MAXM : 7)>(tile, plane, rwp, tl_tgt, plane, rwp,
-                                                         cbase, nwx, n, k, x0, y0, skey, sidx,
+                                                         cbase, nwx, n, k, x0, y0, surv,
                                                          sel, lane);
       else
         nlk_match_target<PSZ, CH, MAXM>(tile, plane, rwp, tl_tgt, plane, rwp, cbase, nwx, n, k,
-                                        x0, y0, skey, sidx, sel, lane);
+                                        x0, y0, surv, sel, lane);
     } else {  // window leaves the LDS region: same arithmetic on the image itself
       const int cbase = y0 * g.w + x0;
       if (n <= 128)
         nlk_match_target<PSZ, CH, 2>(img, (int)npix, g.w, tgt, (int)npix, g.w, cbase, nwx, n, k,
-                                     x0, y0, skey, sidx, sel, lane);
+                                     x0, y0, surv, sel, lane);
       else if (MAXM <= 7 || n <= 448)
         nlk_match_target<PSZ, CH, (MAXM < 7 ? MAXM : 7)>(img, (int)npix, g.w, tgt, (int)npix, g.w,
-                                                         cbase, nwx, n, k, x0, y0, skey, sidx,
+                                                         cbase, nwx, n, k, x0, y0, surv,
                                                          sel, lane);
       else
         nlk_match_target<PSZ, CH, MAXM>(img, (int)npix, g.w, tgt, (int)npix, g.w, cbase, nwx, n,
-                                        k, x0, y0, skey, sidx, sel, lane);
+                                        k, x0, y0, surv, sel, lane);
     }
 
     // --- group membership: the first ntagg kept candidates that have a valid

@@ -521,7 +521,7 @@ int nlk_dev_frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const flo
   }
   tl.rh_max = (tl.tgy - 1) * g.step + 2 * tl.halo + g.psz;
   tl.ksel_max = g.kmax;
-  const size_t lds = sizeof(float) * ((size_t)ch * tl.rwp * tl.rh_max +
+  const size_t lds = sizeof(float) * ((size_t)ch * tl.rwp * tl.rh_max + 1 +
                                       (size_t)NLK_BM_WAVES * (3 * tl.ksel_max + ntagg_alloc));
   if (lds > 160 * 1024)
     return fail(c, NLK_EUNSUP, "matching tile needs %zu bytes of LDS (> 160 KiB)", lds);
