@@ -292,9 +292,23 @@ k_group8(const float* __restrict__ img,   // matching / statistics image (planar
       const float inv = sel ? (v ? __builtin_amdgcn_rcpf((float)np0) : 0.f) : __builtin_amdgcn_rcpf((float)np1);
       const bool in_group = v && np0 <= g.ntagg;
       const bool upd = lane_on && (sel == 0 || v);
-      float part[8];  // partner plane's coefficient (all lanes take part in the DPP)
-#pragma unroll
-      for (int r = 0; r < 8; ++r) part[r] = nlk_dpp<NLK_DPP_ROR8>(x[r]);
+      // difference to the partner plane's coefficient (all lanes take part in the DPP);
+      // one v_sub_f32_dpp per register (hipcc would emit v_mov_dpp + v_sub)
+      float dif[8];
+      asm volatile(
+          "s_nop 1\n\t"
+          "v_sub_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_sub_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_sub_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_sub_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_sub_f32_dpp %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_sub_f32_dpp %5, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_sub_f32_dpp %6, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_sub_f32_dpp %7, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 1"
+          : "=&v"(dif[0]), "=&v"(dif[1]), "=&v"(dif[2]), "=&v"(dif[3]), "=&v"(dif[4]),
+            "=&v"(dif[5]), "=&v"(dif[6]), "=&v"(dif[7])
+          : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
       if (upd) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -305,8 +319,7 @@ k_group8(const float* __restrict__ img,   // matching / statistics image (planar
         if (sel) {  // previous-frame lanes (reference: :769-783, smoother :1659-1667)
 #pragma unroll
           for (int r = 0; r < 8; ++r) {
-            const float tr = x[r] - part[r];
-            v01[r] = fmaf(tr, tr, v01[r]);
+            v01[r] = fmaf(dif[r], dif[r], v01[r]);
           }
           if (!SMO && in_group) {
 #pragma unroll
@@ -353,7 +366,7 @@ k_group8(const float* __restrict__ img,   // matching / statistics image (planar
         // make gain and mean available in both lane groups of the channel
         const float a_o = nlk_dpp<NLK_DPP_ROR8>(a), m_o = nlk_dpp<NLK_DPP_ROR8>(m);
         gain[r] = own ? a : a_o;
-        mu[r] = own ? m : m_o;
+        mu[r] = (1 - gain[r]) * (own ? m : m_o);  // filter: a*PG + (1-a)*M (reference: :879, :902)
       }
     }
     // the reference adds the same per-coefficient terms once per group member
@@ -400,7 +413,7 @@ k_group8(const float* __restrict__ img,   // matching / statistics image (planar
         if (has) nlk_load_row8(src_c + qy * g.w + qx, x);
         nlk_dct8x8_fwd(x, ck);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) x[r] = gain[r] * x[r] + (1 - gain[r]) * mu[r];
+        for (int r = 0; r < 8; ++r) x[r] = gain[r] * x[r] + mu[r];  // mu already holds (1 - a) * M
         nlk_dct8x8_inv(x, cik);
         // the two members of a step may overlap: update the tile one after the other
         if (has && sel == 0) add_patch(qx, qy, x);
