@@ -133,7 +133,9 @@ k_group12(const float* __restrict__ img, const float* __restrict__ cur,
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [(CH+1)][rh_max][rwp]
   constexpr int PSZ = 12, step = 6;
   const int lane = threadIdx.x;
-  const int tile_x = blockIdx.x % tl.ntx, tile_y = blockIdx.x / tl.ntx;
+  const int tile_id = nlk_xcd_tile(blockIdx.x, tl.ntx * tl.nty);
+  if (tile_id >= tl.ntx * tl.nty) return;
+  const int tile_x = tile_id % tl.ntx, tile_y = tile_id / tl.ntx;
   const int gx0 = tile_x * tl.tgx, gy0 = tile_y * tl.tgy;
   const int cx = min(tl.tgx, g.ngx - gx0), cy = min(tl.tgy, g.ngy - gy0);
   const int rx0 = max(gx0 * step - tl.wmax, 0);

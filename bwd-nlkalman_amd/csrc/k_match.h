@@ -172,7 +172,9 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: makes per-target addresses uniform
-  const int tile_x = blockIdx.x % tl.ntx, tile_y = blockIdx.x / tl.ntx;
+  const int tile_id = nlk_xcd_tile(blockIdx.x, tl.ntx * tl.nty);
+  if (tile_id >= tl.ntx * tl.nty) return;
+  const int tile_x = tile_id % tl.ntx, tile_y = tile_id / tl.ntx;
   const int gx0 = tile_x * tl.tgx, gy0 = tile_y * tl.tgy;
   const int cx = min(tl.tgx, g.ngx - gx0), cy = min(tl.tgy, g.ngy - gy0);
   const int wmax = tl.halo;

@@ -31,3 +31,15 @@ static __host__ __device__ inline uint32_t nlk_pack_xy(int x, int y) {
 }
 static __host__ __device__ inline int nlk_x(uint32_t p) { return (int)(p & 0xffffu); }
 static __host__ __device__ inline int nlk_y(uint32_t p) { return (int)(p >> 16); }
+
+// XCD-aware tile order. Workgroups are dealt round-robin over the 8 XCDs (blocks
+// b and b+8 share an XCD and its L2, MI355X_MICROARCH.md), so block b takes tile
+// (b % 8) * ceil(n/8) + b / 8: every XCD works through one contiguous band of
+// tiles and re-reads of neighbouring rows hit its own L2. The grid is launched
+// with 8 * ceil(n/8) blocks; the mapping is a bijection onto [0, 8*ceil(n/8)),
+// indices >= n have no tile. Only speed depends on the actual placement.
+static __device__ inline int nlk_xcd_tile(int b, int n) {
+  const int per = (n + 7) >> 3;
+  return (b & 7) * per + (b >> 3);
+}
+static inline int nlk_xcd_grid(int n) { return ((n + 7) >> 3) << 3; }

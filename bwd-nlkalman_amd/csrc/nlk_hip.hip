@@ -177,7 +177,7 @@ int launch_group_fast_t(nlk_ctx* c, const NlkGeom& g, const float* img, const fl
   HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
   const float* basis = (const float*)c->tabs.p;
-  hipLaunchKernelGGL(kern, dim3(tl.ntx * tl.nty), dim3(64), lds, c->stream, img, cur, prev,
+  hipLaunchKernelGGL(kern, dim3(nlk_xcd_grid(tl.ntx * tl.nty)), dim3(64), lds, c->stream, img, cur, prev,
                      (const uint8_t*)c->vmap.p, g, tl, (const uint32_t*)c->topk.p,
                      (const NlkTarget*)c->tinfo.p, (const uint32_t*)c->gcoords.p,
                      (const uint8_t*)c->active.p, basis, basis + PSZ * PSZ, acc);
@@ -208,7 +208,7 @@ int launch_match_t(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds,
   auto kern = k_bm_topk<PSZ, CH, MAXM>;
   HIPCHK(c, hipFuncSetAttribute((const void*)kern,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(tl.ntx * tl.nty), dim3(NLK_BM_THREADS), lds, c->stream, img,
+  hipLaunchKernelGGL(kern, dim3(nlk_xcd_grid(tl.ntx * tl.nty)), dim3(NLK_BM_THREADS), lds, c->stream, img,
                      (const uint8_t*)c->vmap.p, g, tl, (uint32_t*)c->topk.p,
                      (NlkTarget*)c->tinfo.p, (uint32_t*)c->gcoords.p, (uint64_t*)c->marks.p);
   HIPCHK(c, hipGetLastError());
