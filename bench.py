@@ -10,7 +10,9 @@ A step = one nlkalman_filter_frame() of one frame with every input already in
 HBM. With N > 1 the frame is split into N row strips of the patch grid (one
 process per GPU, bwd-nlkalman_amd/strips.py): halo rows of the previous
 denoised frame and of the accumulators travel between neighbours by RCCL
-send/recv over xGMI. Total work is fixed, so scaling is "strong".
+send/recv over xGMI, and the per-target mark words are all-gathered so that
+every rank replays the exact serial processed-mask. Total work is fixed, so
+scaling is "strong".
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -121,8 +123,18 @@ def main():
         def normalize(out, acc, cur, y0, y1):
             ctx.frame_normalize(out.data_ptr(), acc.data_ptr(), cur.data_ptr(), w, cur.shape[0],
                                 ch, y0, y1)
+        # exact mode: all-gather of the mark words (RCCL) + whole-grid mask replay on every rank
+        def match(marks, cur, prev, oy, ngy_):
+            return ctx.strip_match(marks.data_ptr(), cur.data_ptr(), prev.data_ptr(), None, w,
+                                   cur.shape[0], ch, sigma, p, oy, ngy_)
+
+        def commit(marks_full, ngx_, ngy_, reach, active_full):
+            ctx.mask_commit(marks_full.data_ptr(), ngx_, ngy_, reach, active_full.data_ptr())
+
+        def group(acc, active):
+            ctx.strip_group(acc.data_ptr(), active.data_ptr())
         sf = strips.StripFrame(rank, world, w, h, ch, psz, max(p.search_sz_x, p.search_sz_t), dev,
-                               accumulate, normalize)
+                               accumulate, normalize, phases=(match, commit, group))
         sf.load(t_n1, t_prev)
         one_step = sf.step
 
@@ -190,8 +202,8 @@ def main():
                                       f"FLT1 temporal (deno0 = spatial FLT1 of frame 0, bsic1=NULL), "
                                       f"patch {psz}, defaults of nlkalman_default_params",
                           "parallelism": f"row strips x{world}" if world > 1 else "single GPU",
-                          "mask_order": "serial-exact" if world == 1
-                          else "per-strip (as the reference's OpenMP row split)"},
+                          "mask_order": "serial-exact" if world == 1 else
+                          "serial-exact (mark words all-gathered, mask replayed on every rank)"},
                "kernels_ms": {k_: round(v, 4) for k_, v in tm.items()},
                "roofline": roof}
         if args.workload == "C5":

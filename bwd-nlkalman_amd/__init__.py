@@ -23,10 +23,11 @@ FLT1, FLT2, SMO1 = 0, 1, 2
 HIP_SYMBOLS = [
     "nlk_device_count", "nlk_ctx_create", "nlk_ctx_destroy", "nlk_last_error",
     "nlk_ctx_set_profiling", "nlk_ctx_get_timings", "nlk_ctx_set_stream",
-    "nlk_ctx_get_stream", "nlk_dev_alloc", "nlk_dev_free", "nlk_h2d", "nlk_d2h",
+    "nlk_ctx_get_stream", "nlk_ctx_use_own_stream", "nlk_dev_alloc", "nlk_dev_free", "nlk_h2d", "nlk_d2h",
     "nlk_d2d", "nlk_sync", "nlk_dev_rgb2opp", "nlk_dev_opp2rgb",
     "nlk_dev_warp_bicubic", "nlk_dev_filter_frame", "nlk_dev_smooth_frame",
     "nlk_dev_frame_accumulate", "nlk_dev_frame_normalize", "nlk_ctx_read_records",
+    "nlk_dev_strip_match", "nlk_dev_mask_commit", "nlk_dev_strip_group",
 ]
 API_SYMBOLS = [
     "rgb2opp", "opp2rgb", "warp_bicubic", "nlkalman_default_params",
@@ -87,6 +88,7 @@ def hip():
         L.nlk_ctx_set_profiling.argtypes = [vp, i]
         L.nlk_ctx_get_timings.argtypes = [vp, C.POINTER(Timings)]
         L.nlk_ctx_set_stream.argtypes = [vp, vp]
+        L.nlk_ctx_use_own_stream.argtypes = [vp]
         L.nlk_ctx_get_stream.argtypes = [vp]
         L.nlk_ctx_get_stream.restype = vp
         L.nlk_dev_alloc.argtypes = [vp, C.POINTER(vp), C.c_size_t]
@@ -102,6 +104,10 @@ def hip():
         L.nlk_dev_frame_accumulate.argtypes = [vp, fp, fp, fp, fp, i, i, i, f,
                                                C.POINTER(Params), i, i, i]
         L.nlk_dev_frame_normalize.argtypes = [vp, fp, fp, fp, i, i, i, i, i]
+        L.nlk_dev_strip_match.argtypes = [vp, fp, fp, fp, i, i, i, f, C.POINTER(Params), i, i, i,
+                                          vp, C.POINTER(i)]
+        L.nlk_dev_mask_commit.argtypes = [vp, vp, i, i, i, vp]
+        L.nlk_dev_strip_group.argtypes = [vp, fp, vp]
         L.nlk_ctx_read_records.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i),
                                            vp, vp, vp, vp, vp, vp]
         _hip = L
@@ -278,6 +284,21 @@ class Context:
         self._chk(self.L.nlk_dev_frame_accumulate(self.h, d_acc, d_cur, d_prev, d_basic, w, h,
                                                   ch, float(sigma), C.byref(params), oy, ngy,
                                                   int(smoother)))
+
+    def strip_match(self, d_marks, d_cur, d_prev, d_basic, w, h, ch, sigma, params, oy, ngy,
+                    smoother=False):
+        """Phase 1 on a strip; returns the marking reach R for mask_commit."""
+        r = C.c_int()
+        self._chk(self.L.nlk_dev_strip_match(self.h, d_cur, d_prev, d_basic, w, h, ch, float(sigma),
+                                             C.byref(params), oy, ngy, int(smoother), d_marks,
+                                             C.byref(r)))
+        return r.value
+
+    def mask_commit(self, d_marks, ngx, ngy, reach, d_active):
+        self._chk(self.L.nlk_dev_mask_commit(self.h, d_marks, ngx, ngy, reach, d_active))
+
+    def strip_group(self, d_acc, d_active):
+        self._chk(self.L.nlk_dev_strip_group(self.h, d_acc, d_active))
 
     def frame_normalize(self, d_out, d_acc, d_cur, w, h, ch, y0, y1):
         self._chk(self.L.nlk_dev_frame_normalize(self.h, d_out, d_acc, d_cur, w, h, ch, y0, y1))

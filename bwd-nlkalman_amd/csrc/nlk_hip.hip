@@ -40,6 +40,7 @@ struct nlk_ctx {
   int tabs_psz = 0;
   NlkGeom last{};
   bool have_last = false;
+  const float *p_match = nullptr, *p_cur = nullptr, *p_prev = nullptr;  // planar images of the last match phase
   // profiling: one set of NEV events per frame call, read back (and averaged)
   // only by nlk_ctx_get_timings, so the timed loop never synchronises
   static constexpr int NEV = 7, MAXSETS = 512;
@@ -121,7 +122,7 @@ int upload_tables(nlk_ctx* c, int psz) {
 
 template <int PSZ, int CH>
 int launch_group_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
-                   const float* prev, float* acc) {
+                   const float* prev, float* acc, const uint8_t* active) {
   const int ngrid = g.ngx * g.ngy;
   const float* basis = (const float*)c->tabs.p;
   const float* window = basis + PSZ * PSZ;
@@ -129,33 +130,33 @@ int launch_group_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float* 
     hipLaunchKernelGGL((k_group<PSZ, CH, true>), dim3(ngrid), dim3(64), 0, c->stream, img,
                        cur, prev, (const uint8_t*)c->vmap.p, g, (const uint32_t*)c->topk.p,
                        (const NlkTarget*)c->tinfo.p, (const uint32_t*)c->gcoords.p,
-                       (const uint8_t*)c->active.p, basis, window, acc);
+                       active, basis, window, acc);
   else
     hipLaunchKernelGGL((k_group<PSZ, CH, false>), dim3(ngrid), dim3(64), 0, c->stream, img,
                        cur, prev, (const uint8_t*)c->vmap.p, g, (const uint32_t*)c->topk.p,
                        (const NlkTarget*)c->tinfo.p, (const uint32_t*)c->gcoords.p,
-                       (const uint8_t*)c->active.p, basis, window, acc);
+                       active, basis, window, acc);
   HIPCHK(c, hipGetLastError());
   return NLK_OK;
 }
 
 template <int CH>
 int launch_group_ch(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
-                    const float* prev, float* acc) {
+                    const float* prev, float* acc, const uint8_t* active) {
   switch (g.psz) {
-    case 4: return launch_group_t<4, CH>(c, g, img, cur, prev, acc);
-    case 6: return launch_group_t<6, CH>(c, g, img, cur, prev, acc);
-    case 8: return launch_group_t<8, CH>(c, g, img, cur, prev, acc);
-    case 10: return launch_group_t<10, CH>(c, g, img, cur, prev, acc);
-    case 12: return launch_group_t<12, CH>(c, g, img, cur, prev, acc);
-    case 16: return launch_group_t<16, CH>(c, g, img, cur, prev, acc);
+    case 4: return launch_group_t<4, CH>(c, g, img, cur, prev, acc, active);
+    case 6: return launch_group_t<6, CH>(c, g, img, cur, prev, acc, active);
+    case 8: return launch_group_t<8, CH>(c, g, img, cur, prev, acc, active);
+    case 10: return launch_group_t<10, CH>(c, g, img, cur, prev, acc, active);
+    case 12: return launch_group_t<12, CH>(c, g, img, cur, prev, acc, active);
+    case 16: return launch_group_t<16, CH>(c, g, img, cur, prev, acc, active);
   }
   return fail(c, NLK_EUNSUP, "patch size %d not supported (4, 6, 8, 10, 12, 16)", g.psz);
 }
 
 template <int PSZ, int CH, bool SMO>
 int launch_group_fast_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
-                        const float* prev, float* acc) {
+                        const float* prev, float* acc, const uint8_t* active) {
   NlkGTile tl{};
   // 4 x 1 targets per wavefront measured best (profiles/README.md); NLK_GTX/NLK_GTY override for experiments
   tl.tgx = getenv("NLK_GTX") ? atoi(getenv("NLK_GTX")) : 4;
@@ -180,25 +181,25 @@ int launch_group_fast_t(nlk_ctx* c, const NlkGeom& g, const float* img, const fl
   hipLaunchKernelGGL(kern, dim3(nlk_xcd_grid(tl.ntx * tl.nty)), dim3(64), lds, c->stream, img, cur, prev,
                      (const uint8_t*)c->vmap.p, g, tl, (const uint32_t*)c->topk.p,
                      (const NlkTarget*)c->tinfo.p, (const uint32_t*)c->gcoords.p,
-                     (const uint8_t*)c->active.p, basis, basis + PSZ * PSZ, acc);
+                     active, basis, basis + PSZ * PSZ, acc);
   HIPCHK(c, hipGetLastError());
   return NLK_OK;
 }
 
 int launch_group(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
-                 const float* prev, float* acc) {
+                 const float* prev, float* acc, const uint8_t* active) {
   // register/DPP fast path (its per-lane candidate lists hold up to 128 entries)
   if ((g.psz == 8 || g.psz == 12) && g.kmax <= 128 && g.gstride <= 128 &&
       !getenv("NLK_GENERIC_GROUP")) {
 #define NLK_FAST(P, C)                                                                    \
   if (g.psz == P && g.ch == C)                                                            \
-    return g.smoother ? launch_group_fast_t<P, C, true>(c, g, img, cur, prev, acc)        \
-                      : launch_group_fast_t<P, C, false>(c, g, img, cur, prev, acc);
+    return g.smoother ? launch_group_fast_t<P, C, true>(c, g, img, cur, prev, acc, active) \
+                      : launch_group_fast_t<P, C, false>(c, g, img, cur, prev, acc, active);
     NLK_FAST(8, 1) NLK_FAST(8, 3) NLK_FAST(12, 1) NLK_FAST(12, 3)
 #undef NLK_FAST
   }
-  if (g.ch == 1) return launch_group_ch<1>(c, g, img, cur, prev, acc);
-  if (g.ch == 3) return launch_group_ch<3>(c, g, img, cur, prev, acc);
+  if (g.ch == 1) return launch_group_ch<1>(c, g, img, cur, prev, acc, active);
+  if (g.ch == 3) return launch_group_ch<3>(c, g, img, cur, prev, acc, active);
   return fail(c, NLK_EUNSUP, "%d channels not supported (1 or 3)", g.ch);
 }
 
@@ -363,7 +364,13 @@ int nlk_ctx_get_timings(nlk_ctx* c, struct nlk_timings* t) {
 
 int nlk_ctx_set_stream(nlk_ctx* c, void* s) {
   if (!c) return NLK_EINVAL;
-  c->stream = s ? (hipStream_t)s : c->own_stream;
+  c->stream = (hipStream_t)s;  // NULL is the legacy default stream (what torch uses by default)
+  return NLK_OK;
+}
+
+int nlk_ctx_use_own_stream(nlk_ctx* c) {
+  if (!c) return NLK_EINVAL;
+  c->stream = c->own_stream;
   return NLK_OK;
 }
 
@@ -432,10 +439,12 @@ int nlk_dev_warp_bicubic(nlk_ctx* c, float* imw, const float* im, const float* o
   return NLK_OK;
 }
 
-int nlk_dev_frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const float* prev,
-                             const float* basic, int w, int h, int ch, float sigma,
-                             const struct nlkalman_params* P, int oy, int ngy, int smoother) {
-  int rc = check_images(c, acc, cur, w, h, ch);
+// phase 1: layout + block matching; leaves topk / gcoords / tinfo / marks of the strip in the
+// context (c->last = its geometry)
+static int run_match(nlk_ctx* c, const float* cur, const float* prev, const float* basic, int w,
+                     int h, int ch, float sigma, const struct nlkalman_params* P, int oy, int ngy,
+                     int smoother) {
+  int rc = check_images(c, cur, cur, w, h, ch);
   if (rc) return rc;
   if (!P) return fail(c, NLK_EINVAL, "null parameters");
   HIPCHK(c, hipSetDevice(c->device));
@@ -529,37 +538,83 @@ int nlk_dev_frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const flo
   if (rc) return rc;
   mark(c, 2);
 
-  // ---- processed-mask replay
-  if (g.R == 0) {
-    // a group cannot reach another grid target: nothing is ever skipped
-    HIPCHK(c, hipMemsetAsync(c->active.p, 1, (size_t)ngrid, c->stream));
-  } else if (g.ngy <= 1024 && !getenv("NLK_COMMIT_LDS")) {
-    const int threads = ((g.ngy + 63) / 64) * 64;
-    auto kern = g.R == 1 ? k_mask_commit_wave<1> : (g.R == 2 ? k_mask_commit_wave<2> : k_mask_commit_wave<3>);
-    hipLaunchKernelGGL(kern, dim3(1), dim3(threads), 0, c->stream, (const uint64_t*)c->marks.p,
-                       (uint8_t*)c->active.p, g.ngx, g.ngy);
-    HIPCHK(c, hipGetLastError());
-  } else {
-    const int rpt = (g.ngy + 1023) / 1024;
-    const int threads = min(1024, ((g.ngy + 63) / 64) * 64);
-    const size_t bits = sizeof(uint32_t) * ((size_t)(ngrid + (g.R + 1) * g.ngx + 63) / 32 + 1);
-    if (bits > 160 * 1024 || rpt > 4)
-      return fail(c, NLK_EUNSUP, "patch grid %dx%d too large for the mask replay", g.ngx, g.ngy);
-    auto kern = rpt == 1 ? k_mask_commit<1> : (rpt == 2 ? k_mask_commit<2> : k_mask_commit<4>);
-    HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)bits));
-    hipLaunchKernelGGL(kern, dim3(1), dim3(threads), bits, c->stream,
-                       (const uint64_t*)c->marks.p, (uint8_t*)c->active.p, g.ngx, g.ngy, g.R);
-    HIPCHK(c, hipGetLastError());
-  }
-  mark(c, 3);
-
-  // ---- group processing + aggregation
-  if ((rc = launch_group(c, g, img_match, img_cur, img_prev, acc))) return rc;
-  mark(c, 4);
+  c->p_match = img_match; c->p_cur = img_cur; c->p_prev = img_prev;
   c->last = g;
   c->have_last = true;
   return NLK_OK;
+}
+
+// phase 2: replay of the raster-order processed mask over the mark words of a whole patch grid
+static int run_commit(nlk_ctx* c, const uint64_t* marks, uint8_t* active, int ngx, int ngy, int R) {
+  const int ngrid = ngx * ngy;
+  if (R == 0) {
+    // a group cannot reach another grid target: nothing is ever skipped
+    HIPCHK(c, hipMemsetAsync(active, 1, (size_t)ngrid, c->stream));
+  } else if (ngy <= 1024 && R <= 3 && !getenv("NLK_COMMIT_LDS")) {
+    const int threads = ((ngy + 63) / 64) * 64;
+    auto kern = R == 1 ? k_mask_commit_wave<1> : (R == 2 ? k_mask_commit_wave<2> : k_mask_commit_wave<3>);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(threads), 0, c->stream, marks, active, ngx, ngy);
+    HIPCHK(c, hipGetLastError());
+  } else {
+    const int rpt = (ngy + 1023) / 1024;
+    const int threads = min(1024, ((ngy + 63) / 64) * 64);
+    const size_t bits = sizeof(uint32_t) * ((size_t)(ngrid + (R + 1) * ngx + 63) / 32 + 1);
+    if (bits > 160 * 1024 || rpt > 4)
+      return fail(c, NLK_EUNSUP, "patch grid %dx%d too large for the mask replay", ngx, ngy);
+    auto kern = rpt == 1 ? k_mask_commit<1> : (rpt == 2 ? k_mask_commit<2> : k_mask_commit<4>);
+    HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)bits));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(threads), bits, c->stream, marks, active, ngx, ngy, R);
+    HIPCHK(c, hipGetLastError());
+  }
+  return NLK_OK;
+}
+
+int nlk_dev_frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const float* prev,
+                             const float* basic, int w, int h, int ch, float sigma,
+                             const struct nlkalman_params* P, int oy, int ngy, int smoother) {
+  if (!acc) return fail(c, NLK_EINVAL, "null accumulator");
+  int rc = run_match(c, cur, prev, basic, w, h, ch, sigma, P, oy, ngy, smoother);
+  if (rc) return rc;
+  const NlkGeom& g = c->last;
+  if ((rc = run_commit(c, (const uint64_t*)c->marks.p, (uint8_t*)c->active.p, g.ngx, g.ngy, g.R)))
+    return rc;
+  mark(c, 3);
+  if ((rc = launch_group(c, g, c->p_match, c->p_cur, c->p_prev, acc, (const uint8_t*)c->active.p)))
+    return rc;
+  mark(c, 4);
+  return NLK_OK;
+}
+
+// ---- the same three phases as separate entry points (exact masks across GPUs)
+int nlk_dev_strip_match(nlk_ctx* c, const float* cur, const float* prev, const float* basic, int w,
+                        int h, int ch, float sigma, const struct nlkalman_params* P, int oy,
+                        int ngy, int smoother, void* marks_out, int* reach) {
+  int rc = run_match(c, cur, prev, basic, w, h, ch, sigma, P, oy, ngy, smoother);
+  if (rc) return rc;
+  if (reach) *reach = c->last.R;
+  if (marks_out)
+    HIPCHK(c, hipMemcpyAsync(marks_out, c->marks.p, sizeof(uint64_t) * (size_t)c->last.ngx * c->last.ngy,
+                             hipMemcpyDeviceToDevice, c->stream));
+  return NLK_OK;
+}
+
+int nlk_dev_mask_commit(nlk_ctx* c, const void* marks, int ngx, int ngy, int reach,
+                        unsigned char* active) {
+  if (!c || !marks || !active || ngx < 1 || ngy < 1 || reach < 0)
+    return fail(c, NLK_EINVAL, "bad mask-commit arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = run_commit(c, (const uint64_t*)marks, active, ngx, ngy, reach);
+  mark(c, 3);
+  return rc;
+}
+
+int nlk_dev_strip_group(nlk_ctx* c, float* acc, const unsigned char* active) {
+  if (!c || !c->have_last) return fail(c, NLK_EINVAL, "nlk_dev_strip_match has not run");
+  if (!acc || !active) return fail(c, NLK_EINVAL, "null accumulator / active flags");
+  int rc = launch_group(c, c->last, c->p_match, c->p_cur, c->p_prev, acc, active);
+  mark(c, 4);
+  return rc;
 }
 
 int nlk_dev_frame_normalize(nlk_ctx* c, float* out, const float* acc, const float* cur, int w,

@@ -20,6 +20,13 @@ processed-mask is replayed per strip, exactly like the reference's static
 OpenMP split of the grid rows (reference: src/nlkalman.c:586): targets near a
 seam may be skipped differently than in the serial order (measured ~0.001 dB).
 
+EXACT mode (`phases=` given): step 2 is split in three. Every rank matches its
+strip and produces one 64-bit mark word per target; the mark words of all
+strips are all-gathered (the one real collective of the path, ~1 MB at 1080p);
+every rank replays the raster-order mask over the WHOLE patch grid (integer
+work, 0.2 ms) and processes its strip with its slice of the result. The output
+then equals the single-GPU / serial order exactly, for any number of ranks.
+
 The compute callbacks are injected so that this module never imports a
 backend: bench.py passes the HIP C-ABI, the CPU tests pass the oracle.
 """
@@ -52,7 +59,12 @@ class StripFrame:
     adds the strip's weighted patches into the planar accumulator tensor
     acc[(ch+1), hl, w]; `normalize(out, acc, cur, y0, y1)` writes rows [y0, y1)."""
 
-    def __init__(self, rank, world, w, h, ch, psz, halo, device, accumulate, normalize):
+    def __init__(self, rank, world, w, h, ch, psz, halo, device, accumulate, normalize,
+                 phases=None, stage_host=False):
+        """phases = (match, commit, group) callbacks selects the exact mode:
+        match(marks[int64, ngy_l*ngx], cur, prev, oy, ngy_l) -> reach R;
+        commit(marks_full[int64], ngx, ngy, R, active_full[uint8]);
+        group(acc, active_slice[uint8], ...) (state of the last match)."""
         self.rank, self.world, self.w, self.h, self.ch = rank, world, w, h, ch
         self.step_px = psz // 2
         self.plan = strip_plan(h, psz, halo, world)
@@ -65,6 +77,19 @@ class StripFrame:
         self.out = torch.zeros((self.hl, w, ch), **f32)
         self.acc = torch.zeros((ch + 1, self.hl, w), **f32)
         self.accumulate, self.normalize = accumulate, normalize
+        self.phases = phases
+        # stage_host: move exchanged tensors through host memory (lets the "gloo" backend
+        # drive GPU-resident strips in tests; RCCL exchanges device memory directly)
+        self.stage_host = stage_host
+        self.ngx = (w - psz) // self.step_px + 1
+        self.ngy = (h - psz) // self.step_px + 1
+        self.rows = [q["gy1"] - q["gy0"] for q in self.plan]
+        if phases is not None:
+            mx = max(self.rows) * self.ngx
+            self.marks_pad = torch.zeros(mx, dtype=torch.int64, device=device)
+            self.marks_all = [torch.zeros(mx, dtype=torch.int64, device=device) for _ in range(world)]
+            self.marks_full = torch.zeros(self.ngy * self.ngx, dtype=torch.int64, device=device)
+            self.active_full = torch.zeros(self.ngy * self.ngx, dtype=torch.uint8, device=device)
         self.up = rank - 1 if rank > 0 else None
         self.dn = rank + 1 if rank < world - 1 else None
 
@@ -81,11 +106,26 @@ class StripFrame:
         self.prev[self._l(p["own0"]):self._l(p["own1"])] = prev_own_full[p["own0"]:p["own1"]]
 
     def _exchange(self, sends, recvs):
+        if self.stage_host:
+            sends = [(t.cpu(), peer) for t, peer in sends]
+            dev_recvs, recvs = recvs, [(torch.empty(t.shape, dtype=t.dtype), peer) for t, peer in recvs]
         ops = [dist.P2POp(dist.isend, t, peer) for t, peer in sends]
         ops += [dist.P2POp(dist.irecv, t, peer) for t, peer in recvs]
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+        if self.stage_host:
+            for (d, _), (hbuf, _) in zip(dev_recvs, recvs):
+                d.copy_(hbuf)
+
+    def _all_gather(self, outs, t):
+        if not self.stage_host:
+            dist.all_gather(outs, t)
+            return
+        houts = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        dist.all_gather(houts, t.cpu())
+        for o, hbuf in zip(outs, houts):
+            o.copy_(hbuf)
 
     def step(self):
         p, plan, w, ch = self.p, self.plan, self.w, self.ch
@@ -109,8 +149,23 @@ class StripFrame:
             self.prev[l(p["own1"]):] = rb
         # (2) kernels on the strip
         self.acc.zero_()
-        self.accumulate(self.acc, self.cur, self.prev, p["gy0"] * self.step_px - p["Y0"],
-                        p["gy1"] - p["gy0"])
+        oy, ngy_l = p["gy0"] * self.step_px - p["Y0"], p["gy1"] - p["gy0"]
+        if self.phases is None:
+            self.accumulate(self.acc, self.cur, self.prev, oy, ngy_l)
+        else:
+            match, commit, group = self.phases
+            n_l = ngy_l * self.ngx
+            reach = match(self.marks_pad[:n_l], self.cur, self.prev, oy, ngy_l)
+            if self.world > 1:
+                self._all_gather(self.marks_all, self.marks_pad)
+                off = 0
+                for r, nr in enumerate(self.rows):
+                    self.marks_full[off:off + nr * self.ngx] = self.marks_all[r][:nr * self.ngx]
+                    off += nr * self.ngx
+            else:
+                self.marks_full.copy_(self.marks_pad[:n_l])
+            commit(self.marks_full, self.ngx, self.ngy, reach, self.active_full)
+            group(self.acc, self.active_full[p["gy0"] * self.ngx:p["gy1"] * self.ngx])
         # (3) accumulator rows written outside the own rows go to their owner
         sends, recvs, at, ab = [], [], None, None
         if self.up is not None:

@@ -13,6 +13,10 @@
  *   nlk_dev_warp_bicubic                src/nlkalman.c:29-88
  *   nlk_dev_filter_frame                src/nlkalman.c:518-951  (nlkalman_filter_frame)
  *   nlk_dev_smooth_frame                src/nlkalman.c:1409-1865 (nlkalman_smooth_frame)
+ *   nlk_dev_strip_match / nlk_dev_mask_commit / nlk_dev_strip_group
+ *                                       the three phases of the frame functions:
+ *                                       :605-857 (search, selection, groups), :597-600 +
+ *                                       :930-931 (processed mask), :713-932 (filtering)
  *   nlk_dev_frame_accumulate/_normalize the same two functions split at
  *                                       src/nlkalman.c:939 / :1853 so that row
  *                                       strips can exchange accumulator halos
@@ -56,8 +60,12 @@ const char *nlk_last_error(const nlk_ctx *ctx); /* ctx may be NULL: last global 
 int nlk_ctx_set_profiling(nlk_ctx *ctx, int on);
 /* mean over the frame calls made since nlk_ctx_set_profiling(ctx, 1); synchronises */
 int nlk_ctx_get_timings(nlk_ctx *ctx, struct nlk_timings *t);
-/* run the context's work on an externally owned hipStream_t (NULL = own stream) */
+/* run the context's work on an externally owned hipStream_t; NULL is the legacy
+ * default stream itself (what torch.cuda.current_stream() is unless changed), so
+ * that the kernels order with the caller's own work on that stream.
+ * nlk_ctx_use_own_stream switches back to the context's private stream. */
 int nlk_ctx_set_stream(nlk_ctx *ctx, void *hip_stream);
+int nlk_ctx_use_own_stream(nlk_ctx *ctx);
 void *nlk_ctx_get_stream(nlk_ctx *ctx);
 
 /* device memory + transfers (so that C callers need no HIP headers) */
@@ -97,6 +105,23 @@ int nlk_dev_frame_accumulate(nlk_ctx *ctx, float *acc, const float *cur,
 /* out[y][x][c] = acc_c / acc_w where acc_w > 1e-6, else cur (rows [y0, y1)) */
 int nlk_dev_frame_normalize(nlk_ctx *ctx, float *out, const float *acc,
                             const float *cur, int w, int h, int ch, int y0, int y1);
+
+/* The three phases of nlk_dev_frame_accumulate as separate calls, for an EXACT
+ * processed-mask across row strips: every rank runs `strip_match` on its strip
+ * and gets one 64-bit mark word per target (grid-relative, so strips can simply
+ * be concatenated in grid-row order: an all-gather), `mask_commit` replays the
+ * raster order (reference: src/nlkalman.c:597-600, 930-931) over the mark words
+ * of the WHOLE patch grid, and `strip_group` processes the strip's targets with
+ * its slice of the resulting active flags. `marks_out` / `active` are device
+ * buffers of ngx*ngy uint64 / bytes; `reach` receives the R to hand to
+ * mask_commit. strip_group uses the state strip_match left in the context. */
+int nlk_dev_strip_match(nlk_ctx *ctx, const float *cur, const float *prev,
+                        const float *basic, int w, int h, int ch, float sigma,
+                        const struct nlkalman_params *prms, int oy, int ngy,
+                        int smoother, void *marks_out, int *reach);
+int nlk_dev_mask_commit(nlk_ctx *ctx, const void *marks, int ngx, int ngy, int reach,
+                        unsigned char *active);
+int nlk_dev_strip_group(nlk_ctx *ctx, float *acc, const unsigned char *active);
 
 /* per-target records of the last frame call, copied to host (tests only):
  * active[ngrid] (1 = processed), nsel/np0/nagg[ngrid], topk[ngrid*kmax] and

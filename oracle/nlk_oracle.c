@@ -597,6 +597,11 @@ static void smooth_target(const frame_ctx *f, scratch_t *s, int px, int py, int 
   aggregate(f, s, nagg, vp, np0 ? 1 : 0); /* reference: :1844 */
 }
 
+/* When non-NULL, the processed-mask test is replaced by these externally decided
+ * flags (one per strip target, 1 = process): the "group" phase of the three-phase
+ * strip form below. */
+static const unsigned char *g_active_in = NULL;
+
 /* oy/ngy: first image row and number of patch-grid rows to process (a whole
  * frame is oy = 0, ngy = (h - psz)/step + 1). acc != NULL selects the row-strip
  * form: nothing is normalised, the weighted sums and weights are ADDED to the
@@ -650,6 +655,7 @@ static void run_frame(float *out, const float *cur, const float *prev,
         int m;
 #pragma omp atomic read
         m = f.mask[px + (long)py * w];
+        if (g_active_in) m = !g_active_in[gx + gy * f.ngx];
         if (m) {
           if (tr && tr->active) tr->active[gx + gy * f.ngx] = 0;
           continue;
@@ -709,6 +715,92 @@ void nlko_frame_normalize(float *out, const float *acc, const float *cur, int w,
     for (int c = 0; c < ch; ++c)
       out[i * ch + c] = acc[ch * npix + i] > 1e-6 ? acc[c * npix + i] / acc[ch * npix + i]
                                                   : cur[i * ch + c];
+}
+
+/* ---- three-phase strip form (mirror of nlk_dev_strip_match / nlk_dev_mask_commit /
+ * nlk_dev_strip_group in include/nlk_hip.h) */
+
+/* Phase 1: for EVERY target of the strip, the group it would aggregate
+ * (reference: src/nlkalman.c:605-609, 630-707, 725-732, 779-793, 857) encoded as a
+ * mark word: bit (dj+R)*(2R+1) + (di+R) is set when the group holds the grid target
+ * (di, dj) away and the group marks the processed-mask (reference: :931, :1844). */
+void nlko_strip_match(uint64_t *marks, const float *cur, const float *prev,
+                      const float *basic, int w, int h, int ch, float sigma,
+                      const nlko_params *P, int oy, int ngy, int smoother, int *reach) {
+  frame_ctx f;
+  memset(&f, 0, sizeof f);
+  (void)sigma;
+  f.w = w; f.h = h; f.ch = ch;
+  f.psz = P->patch_sz; f.step = f.psz / 2; f.P2 = f.psz * f.psz; f.E = f.P2 * ch;
+  f.P = *P;
+  f.cur = cur; f.prev = prev; f.match = basic ? basic : cur; f.have_basic = basic != NULL;
+  f.ngx = (w - f.psz) / f.step + 1;
+  f.ngy = ngy;
+  const int wmark = (smoother || prev) ? P->search_sz_t : P->search_sz_x;
+  const int R = wmark / f.step, side = 2 * R + 1;
+  if (reach) *reach = R;
+  scratch_t s = scratch_new(&f);
+  const int ntagg = P->npatches_tagg;
+  for (int gy = 0; gy < ngy; ++gy)
+    for (int gx = 0; gx < f.ngx; ++gx) {
+      const int px = gx * f.step, py = oy + gy * f.step;
+      uint64_t m = 0;
+      const int prev_p = patch_valid(&f, prev, px, py);
+      int k = prev_p ? P->npatches_t : P->npatches_x;
+      if (k > 1) {
+        const int wsz = (smoother || prev_p) ? P->search_sz_t : P->search_sz_x;
+        k = block_match(&f, &s, px, py, wsz, k);
+        int np0 = 0, np1 = 0;
+        for (int i = 0; i < k; ++i) {
+          const int pv = prev_p && patch_valid(&f, prev, s.cand[i].x, s.cand[i].y);
+          np1++;
+          np0 += pv;
+          const int slot = pv ? (np0 <= ntagg ? np0 - 1 : -1)
+                              : ((!smoother && np1 <= ntagg) ? np1 - 1 : -1);
+          if (slot >= 0) { s.gx[slot] = s.cand[i].x; s.gy[slot] = s.cand[i].y; }
+        }
+        const int nagg = smoother ? imin(np0, ntagg) : imin(np0 ? np0 : np1, ntagg);
+        const int mark = smoother ? (np0 > 0) : !(prev && np0 == 0);
+        for (int n = 0; mark && n < nagg; ++n) {
+          const int dx = s.gx[n] - px, dy = s.gy[n] - py;
+          if (dx % f.step == 0 && dy % f.step == 0)
+            m |= 1ull << ((dy / f.step + R) * side + dx / f.step + R);
+        }
+      }
+      marks[gx + (long)gy * f.ngx] = m;
+    }
+  scratch_free(&s);
+}
+
+/* Phase 2: the raster-order replay itself (reference: src/nlkalman.c:597-600 skip,
+ * :930-931 mark) on mark words: a target is processed iff no earlier processed
+ * target's group contained it. */
+void nlko_mask_commit(const uint64_t *marks, int ngx, int ngy, int R, unsigned char *active) {
+  const int side = 2 * R + 1;
+  unsigned char *hit = calloc((size_t)ngx * ngy, 1);
+  for (int j = 0; j < ngy; ++j)
+    for (int i = 0; i < ngx; ++i) {
+      const long t = i + (long)j * ngx;
+      active[t] = !hit[t];
+      if (hit[t]) continue;
+      for (int b = 0; b < side * side; ++b)
+        if ((marks[t] >> b) & 1) {
+          const int jj = j + b / side - R, ii = i + b % side - R;
+          if (jj >= 0 && jj < ngy && ii >= 0 && ii < ngx) hit[ii + (long)jj * ngx] = 1;
+        }
+    }
+  free(hit);
+}
+
+/* Phase 3: filter + aggregate the strip's targets flagged in `active` */
+void nlko_strip_group(float *acc, const unsigned char *active, const float *cur,
+                      const float *prev, const float *basic, int w, int h, int ch,
+                      float sigma, const nlko_params *P, int oy, int ngy, int smoother) {
+  float *tmp = malloc(sizeof(float) * (size_t)w * h * ch);
+  g_active_in = active;
+  run_frame(tmp, cur, prev, basic, w, h, ch, sigma, P, 1, NULL, smoother, oy, ngy, acc);
+  g_active_in = NULL;
+  free(tmp);
 }
 
 int nlko_max_threads(void) {

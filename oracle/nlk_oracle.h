@@ -44,5 +44,12 @@ void nlko_frame_accumulate(float *acc, const float *cur, const float *prev,
                            const nlko_params *P, int oy, int ngy, int smoother);
 void nlko_frame_normalize(float *out, const float *acc, const float *cur, int w, int h,
                           int ch, int y0, int y1);
+void nlko_strip_match(uint64_t *marks, const float *cur, const float *prev,
+                      const float *basic, int w, int h, int ch, float sigma,
+                      const nlko_params *P, int oy, int ngy, int smoother, int *reach);
+void nlko_mask_commit(const uint64_t *marks, int ngx, int ngy, int R, unsigned char *active);
+void nlko_strip_group(float *acc, const unsigned char *active, const float *cur,
+                      const float *prev, const float *basic, int w, int h, int ch,
+                      float sigma, const nlko_params *P, int oy, int ngy, int smoother);
 int nlko_max_threads(void);
 #endif

@@ -66,6 +66,12 @@ def lib():
         L.nlko_frame_accumulate.argtypes = [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float,
                                             C.POINTER(Params), C.c_int, C.c_int, C.c_int]
         L.nlko_frame_normalize.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        u64p, u8p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)
+        L.nlko_strip_match.argtypes = [u64p, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float,
+                                       C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.nlko_mask_commit.argtypes = [u64p, C.c_int, C.c_int, C.c_int, u8p]
+        L.nlko_strip_group.argtypes = [fp, u8p, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float,
+                                       C.POINTER(Params), C.c_int, C.c_int, C.c_int]
         L.nlko_max_threads.restype = C.c_int
         _LIB = L
     return _LIB
@@ -202,6 +208,33 @@ def frame_normalize(acc, cur, y0, y1):
     out = np.zeros_like(cur)
     lib().nlko_frame_normalize(_fp(out), _fp(acc), _fp(cur), w, h, ch, int(y0), int(y1))
     return out
+
+
+def strip_match(marks, cur, prev, basic, sigma, params, oy, ngy, smoother=False):
+    """Three-phase strip form, phase 1: fills marks[ngy*ngx] (uint64), returns the reach R."""
+    cur, prev, basic = _img(cur), _img(prev), _img(basic)
+    h, w, ch = cur.shape
+    r = C.c_int()
+    lib().nlko_strip_match(marks.ctypes.data_as(C.POINTER(C.c_uint64)), _fp(cur), _fp(prev), _fp(basic),
+                           w, h, ch, float(sigma), C.byref(params), int(oy), int(ngy), int(smoother),
+                           C.byref(r))
+    return r.value
+
+
+def mask_commit(marks, ngx, ngy, reach):
+    active = np.zeros(ngx * ngy, np.uint8)
+    lib().nlko_mask_commit(marks.ctypes.data_as(C.POINTER(C.c_uint64)), ngx, ngy, reach,
+                           active.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return active
+
+
+def strip_group(acc, active, cur, prev, basic, sigma, params, oy, ngy, smoother=False):
+    cur, prev, basic = _img(cur), _img(prev), _img(basic)
+    h, w, ch = cur.shape
+    active = np.ascontiguousarray(active, np.uint8)
+    lib().nlko_strip_group(_fp(acc), active.ctypes.data_as(C.POINTER(C.c_uint8)), _fp(cur), _fp(prev),
+                           _fp(basic), w, h, ch, float(sigma), C.byref(params), int(oy), int(ngy),
+                           int(smoother))
 
 
 def max_threads():

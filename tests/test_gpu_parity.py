@@ -211,6 +211,134 @@ def test_gpu_strips_match_oracle_strips(ctx, built, O, synth, world):
     cases.assert_close(got, want, f"{world} strips on the GPU vs on the oracle")
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_gpu_exact_strips_equal_whole_frame(ctx, built, O, synth, world):
+    """The three-phase strip form (match per strip -> concatenated mark words ->
+    whole-grid mask replay -> group per strip), i.e. what N ranks do in exact
+    mode, run sequentially on one GPU: must equal the whole-frame call."""
+    import importlib
+    strips = importlib.import_module("bwd-nlkalman_amd.strips")
+    w, h, ch, sigma = 96, 128, 3, 20.0
+    n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, 33)
+    o0, o1 = O.rgb2opp(n0), O.rgb2opp(n1)
+    p = built.default_params(sigma, built.FLT1)
+    prev = O.filter_frame(o0, None, None, sigma, _to_o(O, p))
+    whole, rec = _dev_frame(ctx, False, o1, prev, None, sigma, p)
+    plan = strips.strip_plan(h, p.patch_sz, max(p.search_sz_x, p.search_sz_t), world)
+    step = p.patch_sz // 2
+    ngx, ngy = (w - p.patch_sz) // step + 1, (h - p.patch_sz) // step + 1
+    d_marks = ctx.upload(np.zeros(ngx * ngy, np.uint64))
+    d_active = ctx.upload(np.zeros(ngx * ngy, np.uint8))
+    bufs = []
+    for s in plan:  # phase 1 on every strip
+        cur_s = np.ascontiguousarray(o1[s["Y0"]:s["Y1"]])
+        prev_s = np.ascontiguousarray(prev[s["Y0"]:s["Y1"]])
+        d_cur, d_prev = ctx.upload(cur_s), ctx.upload(prev_s)
+        oy, ngy_l = s["gy0"] * step - s["Y0"], s["gy1"] - s["gy0"]
+        reach = ctx.strip_match(d_marks + 8 * s["gy0"] * ngx, d_cur, d_prev, None, w, cur_s.shape[0], ch,
+                                sigma, p, oy, ngy_l)
+        bufs.append((d_cur, d_prev, cur_s.shape[0], oy, ngy_l))
+    ctx.mask_commit(d_marks, ngx, ngy, reach, d_active)  # phase 2 on the whole grid
+    assert np.array_equal(ctx.download(d_active, (ngx * ngy,), np.uint8), rec["active"])
+    acc = np.zeros((ch + 1, h, w), np.float32)
+    for s, (d_cur, d_prev, hl, oy, ngy_l) in zip(plan, bufs):  # phase 3 per strip
+        ctx.strip_match(None, d_cur, d_prev, None, w, hl, ch, sigma, p, oy, ngy_l)  # restore the strip state
+        d_acc = ctx.upload(np.zeros((ch + 1, hl, w), np.float32))
+        ctx.strip_group(d_acc, d_active + s["gy0"] * ngx)
+        acc[:, s["Y0"]:s["Y1"]] += ctx.download(d_acc, (ch + 1, hl, w))
+        for x in (d_cur, d_prev, d_acc):
+            ctx.free(x)
+    d_acc, d_cur, d_out = ctx.upload(acc), ctx.upload(o1), ctx.alloc(o1.nbytes)
+    ctx.frame_normalize(d_out, d_acc, d_cur, w, h, ch, 0, h)
+    got = ctx.download(d_out, o1.shape)
+    for x in (d_acc, d_cur, d_out, d_marks, d_active):
+        ctx.free(x)
+    cases.assert_close(got, whole, f"exact strips x{world} vs whole frame", maxabs=5e-4, rmse=5e-5)
+
+
+def _two_rank_worker(rank, world, port, q):
+    import importlib
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p_ in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    pkg = importlib.import_module("bwd-nlkalman_amd")
+    synth = importlib.import_module("bwd-nlkalman_amd.synth")
+    strips = importlib.import_module("bwd-nlkalman_amd.strips")
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    w, h, ch, sigma = 320, 256, 3, 20.0
+    dev = torch.device("cuda", 0)
+    ctx = pkg.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, 5)
+    t_n0, t_n1 = torch.from_numpy(n0).to(dev), torch.from_numpy(n1).to(dev)
+    ctx.rgb2opp(t_n0.data_ptr(), w, h, ch)
+    ctx.rgb2opp(t_n1.data_ptr(), w, h, ch)
+    p = pkg.default_params(sigma, pkg.FLT1)
+    t_prev, t_whole = torch.empty_like(t_n0), torch.empty_like(t_n0)
+    ctx.filter_frame(t_prev.data_ptr(), t_n0.data_ptr(), None, None, w, h, ch, sigma, p)
+    ctx.filter_frame(t_whole.data_ptr(), t_n1.data_ptr(), t_prev.data_ptr(), None, w, h, ch, sigma, p)
+
+    def accumulate(acc, cur, prev, oy, ngy):
+        ctx.frame_accumulate(acc.data_ptr(), cur.data_ptr(), prev.data_ptr(), None, w, cur.shape[0], ch,
+                             sigma, p, oy, ngy)
+
+    def normalize(out, acc, cur, y0, y1):
+        ctx.frame_normalize(out.data_ptr(), acc.data_ptr(), cur.data_ptr(), w, cur.shape[0], ch, y0, y1)
+
+    def match(marks, cur, prev, oy, ngy):
+        return ctx.strip_match(marks.data_ptr(), cur.data_ptr(), prev.data_ptr(), None, w, cur.shape[0],
+                               ch, sigma, p, oy, ngy)
+
+    def commit(marks_full, ngx, ngy, reach, active_full):
+        ctx.mask_commit(marks_full.data_ptr(), ngx, ngy, reach, active_full.data_ptr())
+
+    def group(acc, active):
+        ctx.strip_group(acc.data_ptr(), active.data_ptr())
+    res = {}
+    for mode, phases in (("exact", (match, commit, group)), ("per-strip", None)):
+        sf = strips.StripFrame(rank, world, w, h, ch, p.patch_sz, max(p.search_sz_x, p.search_sz_t), dev,
+                               accumulate, normalize, phases=phases, stage_host=True)
+        sf.load(t_n1, t_prev)
+        sf.step()
+        sf.step()
+        y0, y1, rows = sf.own_rows()
+        full = torch.zeros((h, w, ch))
+        full[y0:y1] = rows.cpu()
+        dist.all_reduce(full)
+        res[mode] = full.numpy()
+    if rank == 0:
+        q.put((res, t_whole.cpu().numpy()))
+    dist.destroy_process_group()
+
+
+def test_two_processes_drive_gpu_strips(built):
+    """bench.py's N > 1 code path end to end on the one GPU of the test box: two
+    processes (gloo, exchanged tensors staged through the host) run the HIP
+    kernels on their strips; exact mode must equal the whole-frame call."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res, whole = q.get(timeout=600)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    cases.assert_close(res["exact"], whole, "2 processes, exact mode, vs whole frame", maxabs=5e-4, rmse=5e-5)
+    d = np.abs(res["per-strip"] - whole)
+    assert np.isfinite(res["per-strip"]).all() and (d > 1e-2).mean() < 0.2  # seam-order differences only
+
+
 def test_full_size_1080p_against_oracle(ctx, built, O, synth):
     """BASELINE.json configs[1] at full size: 1920x1080 RGB sigma=20 FLT1
     temporal. The serial oracle needs ~25 s; mask decisions must be identical,

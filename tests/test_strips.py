@@ -48,7 +48,26 @@ def _callbacks(O, p):
     return accumulate, normalize
 
 
-def _worker(rank, world, port, q):
+def _phases(O, p, state):
+    """Oracle-backed (match, commit, group) callbacks of the exact mode."""
+    def match(marks, cur, prev, oy, ngy):
+        m = np.zeros(marks.numel(), np.uint64)
+        state.update(cur=cur.numpy(), prev=prev.numpy(), oy=oy, ngy=ngy)
+        r = O.strip_match(m, state["cur"], state["prev"], None, SIGMA, p, oy, ngy)
+        marks.copy_(torch.from_numpy(m.view(np.int64)))
+        return r
+
+    def commit(marks_full, ngx, ngy, reach, active_full):
+        act = O.mask_commit(marks_full.numpy().view(np.uint64), ngx, ngy, reach)
+        active_full.copy_(torch.from_numpy(act))
+
+    def group(acc, active):
+        O.strip_group(acc.numpy(), active.numpy(), state["cur"], state["prev"], None, SIGMA, p,
+                      state["oy"], state["ngy"])
+    return match, commit, group
+
+
+def _worker(rank, world, port, q, exact=False):
     _setup_paths()
     import oracle as O
     strips = importlib.import_module("bwd-nlkalman_amd.strips")
@@ -57,7 +76,8 @@ def _worker(rank, world, port, q):
     o1, prev, p = _frames(O, synth)
     acc_fn, norm_fn = _callbacks(O, p)
     sf = strips.StripFrame(rank, world, W, H, CH, p.patch_sz, max(p.search_sz_x, p.search_sz_t),
-                           torch.device("cpu"), acc_fn, norm_fn)
+                           torch.device("cpu"), acc_fn, norm_fn,
+                           phases=_phases(O, p, {}) if exact else None)
     sf.load(torch.from_numpy(o1), torch.from_numpy(prev))
     sf.step()
     sf.step()  # a second step must give the same result (buffers fully re-initialised)
@@ -107,6 +127,26 @@ def test_strips_over_gloo(world, O, synth):
     clean = O.rgb2opp(synth.clean_frame(W, H, CH, 1))
     assert abs(synth.psnr(got, clean) - synth.psnr(whole, clean)) < 0.05
     assert np.isfinite(got).all()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exact_strips_over_gloo_equal_serial_order(world, O, synth):
+    """Exact mode: all-gather of the mark words + whole-grid mask replay on every
+    rank. The result must equal the serial whole-frame order (not just PSNR-wise)."""
+    import cases
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, True)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = q.get(timeout=240)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    o1, prev, p = _frames(O, synth)
+    whole = O.filter_frame(o1, prev, None, SIGMA, p)
+    cases.assert_close(got, whole, f"exact mode, {world} ranks, vs serial whole frame", maxabs=5e-4, rmse=5e-5)
 
 
 def test_strip_plan_properties():
