@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--force-strips", action="store_true",
+                    help="run the N > 1 strip machinery even at N = 1 (measures its fixed overhead)")
     args = ap.parse_args()
 
     import torch
@@ -111,7 +113,7 @@ def main():
             ctx.filter_frame(t_f2.data_ptr(), t_n1.data_ptr(), t_prev.data_ptr(), t_f1.data_ptr(),
                              w, h, ch, sigma, p2)
             ctx.smooth_frame(t_out.data_ptr(), t_prev.data_ptr(), t_f2.data_ptr(), None, w, h, ch, sigma, ps)
-    elif world == 1:
+    elif world == 1 and not args.force_strips:
         def one_step():
             ctx.filter_frame(t_out.data_ptr(), t_n1.data_ptr(), t_prev.data_ptr(), None,
                              w, h, ch, sigma, p)
