@@ -400,3 +400,55 @@ def test_smoother_full_size_1080p(ctx, built, O, synth):
     r, tr = O.smooth_frame(f0, f1, None, sigma, _to_o(O, ps), trace=True)
     _check_records(rec, tr, "smo 1080p")
     cases.assert_close(g, r, "smo 1080p", flips=40)
+
+
+def test_randomised_parameters_and_shapes(ctx, built, O):
+    """40 seeded random configurations: odd image sizes, every supported patch
+    size, clipped windows, k larger than the window, group sizes above k, NaN
+    holes, second-iteration and smoother calls. Integer records exact, pixels
+    within tolerance, for each of them."""
+    rng = np.random.default_rng(2024)
+    done = 0
+    for it in range(200):
+        if done == 40:
+            break
+        psz = int(rng.choice([4, 6, 8, 8, 8, 10, 12, 12, 16]))
+        step = psz // 2
+        ch = int(rng.choice([1, 3]))
+        w = int(rng.integers(psz, 90))
+        h = int(rng.integers(psz, 70))
+        smoother = rng.random() < 0.25
+        wsz_t = int(rng.integers(1, min(15, 3 * step + step - 1) + 1))
+        wsz_x = int(rng.integers(1, min(15, 3 * step + step - 1) + 1))
+        npx, npt = int(rng.integers(2, 70)), int(rng.integers(2, 70))
+        ntagg = int(rng.integers(1, 45))
+        over = dict(patch_sz=psz, search_sz_x=wsz_x, search_sz_t=wsz_t, npatches_x=npx, npatches_t=npt,
+                    npatches_tagg=ntagg)
+        mode = built.SMO1 if smoother else int(rng.choice([built.FLT1, built.FLT2]))
+        sigma = float(rng.choice([10.0, 20.0, 40.0]))
+        p = built.default_params(sigma, mode, **over)
+        cur = rng.uniform(0, 255, (h, w, ch)).astype(np.float32)
+        kind = rng.integers(0, 3) if not smoother else rng.integers(1, 3)
+        prev = None
+        if kind >= 1:
+            prev = (cur + rng.normal(0, 8, cur.shape)).astype(np.float32)
+        if kind == 2:
+            y0, x0 = int(rng.integers(0, h)), int(rng.integers(0, w))
+            prev[y0:y0 + int(rng.integers(1, 9)), x0:x0 + int(rng.integers(1, 9)), :] = np.nan
+            prev[:, :1, :] = np.nan
+        basic = None
+        if not smoother and mode == built.FLT2:
+            basic = (cur + rng.normal(0, 3, cur.shape)).astype(np.float32)
+        fn = O.smooth_frame if smoother else O.filter_frame
+        r, tr = fn(cur, prev, basic, sigma, _to_o(O, p), trace=True)
+        try:
+            g, rec = _dev_frame(ctx, smoother, cur, prev, basic, sigma, p)
+        except built.NlkError as e:  # combinations the kernels reject loudly (reach > 3)
+            assert "reach" in str(e) or "LDS" in str(e), str(e)
+            continue
+        what = f"random #{it}: {w}x{h}x{ch} psz{psz} sx{wsz_x} st{wsz_t} nx{npx} nt{npt} na{ntagg} " \
+               f"mode{mode} prev{kind} sigma{sigma}"
+        _check_records(rec, tr, what)
+        cases.assert_close(g, r, what, maxabs=5e-3, rmse=5e-4)
+        done += 1
+    assert done == 40
