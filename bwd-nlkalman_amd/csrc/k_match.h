@@ -164,11 +164,80 @@ __device__ inline void nlk_match_target(const float* __restrict__ tile, int plan
   nlk_wave_lds_fence();
 }
 
+// Group membership, records and mark word of one target whose sorted k-NN list is in sel[0..k)
+// (reference: src/nlkalman.c:725-732, 779-793, 857, 931; smoother :1669-1676, :1844).
+template <int PSZ>
+__device__ inline void nlk_match_epilogue(const NlkGeom& g, size_t t, int px, int py, int prev_p,
+                                          int k, const uint32_t* __restrict__ sel,
+                                          uint32_t* __restrict__ grp,
+                                          const uint8_t* __restrict__ vmap,
+                                          uint32_t* __restrict__ topk, NlkTarget* __restrict__ tinfo,
+                                          uint32_t* __restrict__ gcoords,
+                                          uint64_t* __restrict__ marks, int lane) {
+  constexpr int step = PSZ / 2;
+  NlkTarget info = {0, 0, 0, prev_p};
+  // --- group membership: the first ntagg kept candidates that have a valid
+  // previous patch, or (none valid) the first ntagg kept candidates
+  int np0 = 0;
+  for (int base = 0; base < k; base += 64) {
+    const int i = base + lane;
+    uint32_t q = 0;
+    int v = 0;
+    if (i < k) {
+      q = sel[i];
+      topk[t * g.kmax + i] = q;
+      v = prev_p ? vmap[(size_t)nlk_y(q) * g.w + nlk_x(q)] : 0;
+    }
+    const uint64_t b = __ballot(v);
+    const int slot = np0 + __popcll(b & ((1ull << lane) - 1ull));
+    if (v && slot < g.ntagg) grp[slot] = q;
+    np0 += __popcll(b);
+  }
+  nlk_wave_lds_fence();
+
+  int nagg, mark;
+  if (g.smoother) {
+    nagg = min(np0, g.ntagg);
+    mark = np0 > 0;  // reference: :1844
+  } else {
+    nagg = min(np0 ? np0 : k, g.ntagg);
+    mark = !(g.have_prev && np0 == 0);  // reference: :931
+  }
+  uint64_t mbits = 0;
+  const int side = 2 * g.R + 1;
+  for (int base = 0; base < nagg; base += 64) {
+    const int i = base + lane;
+    if (i < nagg) {
+      const uint32_t q = np0 ? grp[i] : sel[i];
+      gcoords[t * g.gstride + i] = q;
+      const int dx = nlk_x(q) - px, dy = nlk_y(q) - py;
+      if (mark && dx % step == 0 && dy % step == 0) {
+        const int di = dx / step, dj = dy / step;
+        mbits |= 1ull << ((dj + g.R) * side + di + g.R);
+      }
+    }
+  }
+  if (g.smoother && np0 == 0) {  // pass-through of the target patch
+    nagg = 1;
+    if (lane == 0) gcoords[t * g.gstride] = nlk_pack_xy(px, py);
+  }
+  mbits = nlk_wave_or(mbits);
+  if (lane == 0) {
+    info.nsel = k;
+    info.np0 = np0;
+    info.nagg = nagg;
+    info.flags = prev_p | (mark << 1);
+    tinfo[t] = info;
+    marks[t] = mbits;
+  }
+}
+
 template <int PSZ, int CH, int MAXM>
 __global__ void __launch_bounds__(NLK_BM_THREADS)
 k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGeom g,
           NlkTile tl, uint32_t* __restrict__ topk, NlkTarget* __restrict__ tinfo,
-          uint32_t* __restrict__ gcoords, uint64_t* __restrict__ marks) {
+          uint32_t* __restrict__ gcoords, uint64_t* __restrict__ marks,
+          uint32_t* __restrict__ wide_list, uint32_t* __restrict__ wide_count) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: makes per-target addresses uniform
@@ -182,8 +251,8 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
 
   // image region staged in LDS: the tile's patches + the halo of the dominant
   // window. (In a temporal frame the few targets without a valid previous patch
-  // search a wider window, reference: src/nlkalman.c:637; they read the image
-  // through L2 instead.)
+  // search a wider window, reference: src/nlkalman.c:637; they are queued
+  // for k_bm_wide.)
   const int rx0 = max(gx0 * step - wmax, 0);
   const int rx1 = min((gx0 + cx - 1) * step + wmax + PSZ, g.w);
   const int ry0 = max(g.oy + gy0 * step - wmax, 0);
@@ -260,8 +329,10 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
     const int y0 = max(py - wsz, 0), y1 = min(py + wsz, g.h - PSZ) + 1;
     const int nwx = x1 - x0, n = nwx * (y1 - y0);
     k = min(k, n);
-    const float* tgt = img + (size_t)py * g.w + px;  // wave-uniform address
-    const bool in_lds = x0 >= rx0 && x1 - 1 + PSZ <= rx1 && y0 >= ry0 && y1 - 1 + PSZ <= ry1;
+    // (MAXM of this kernel is sized for the dominant window: a clipped wide window near the
+    // image border can lie inside the region and still have too many candidates)
+    const bool in_lds = x0 >= rx0 && x1 - 1 + PSZ <= rx1 && y0 >= ry0 && y1 - 1 + PSZ <= ry1 &&
+                        n <= 64 * MAXM;
     if (in_lds) {
       const int cbase = (y0 - ry0) * rwp + (x0 - rx0);
       // target patch from the LDS tile too (scalar loads from the image measured 6 % slower)
@@ -276,74 +347,80 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
       else
         nlk_match_target<PSZ, CH, MAXM>(tile, plane, rwp, tl_tgt, plane, rwp, cbase, nwx, n, k,
                                         x0, y0, surv, sel, lane);
-    } else {  // window leaves the LDS region: same arithmetic on the image itself
-      const int cbase = y0 * g.w + x0;
-      if (n <= 128)
-        nlk_match_target<PSZ, CH, 2>(img, (int)npix, g.w, tgt, (int)npix, g.w, cbase, nwx, n, k,
-                                     x0, y0, surv, sel, lane);
-      else if (MAXM <= 7 || n <= 448)
-        nlk_match_target<PSZ, CH, (MAXM < 7 ? MAXM : 7)>(img, (int)npix, g.w, tgt, (int)npix, g.w,
-                                                         cbase, nwx, n, k, x0, y0, surv,
-                                                         sel, lane);
-      else
-        nlk_match_target<PSZ, CH, MAXM>(img, (int)npix, g.w, tgt, (int)npix, g.w, cbase, nwx, n,
-                                        k, x0, y0, surv, sel, lane);
-    }
-
-    // --- group membership: the first ntagg kept candidates that have a valid
-    // previous patch, or (none valid) the first ntagg kept candidates
-    int np0 = 0;
-    for (int base = 0; base < k; base += 64) {
-      const int i = base + lane;
-      uint32_t q = 0;
-      int v = 0;
-      if (i < k) {
-        q = sel[i];
-        topk[t * g.kmax + i] = q;
-        v = prev_p ? vmap[(size_t)nlk_y(q) * g.w + nlk_x(q)] : 0;
-      }
-      const uint64_t b = __ballot(v);
-      const int slot = np0 + __popcll(b & ((1ull << lane) - 1ull));
-      if (v && slot < g.ntagg) grp[slot] = q;
-      np0 += __popcll(b);
-    }
-    nlk_wave_lds_fence();
-
-    int nagg, mark;
-    if (g.smoother) {
-      nagg = min(np0, g.ntagg);
-      mark = np0 > 0;  // reference: :1844
     } else {
-      nagg = min(np0 ? np0 : k, g.ntagg);
-      mark = !(g.have_prev && np0 == 0);  // reference: :931
+      // window leaves the LDS region (a target without a valid previous patch in a
+      // temporal frame): queued for k_bm_wide, which stages a window of its own
+      if (lane == 0) wide_list[atomicAdd(wide_count, 1u)] = (uint32_t)t;
+      continue;
     }
-    uint64_t mbits = 0;
-    const int side = 2 * g.R + 1;
-    for (int base = 0; base < nagg; base += 64) {
-      const int i = base + lane;
-      if (i < nagg) {
-        const uint32_t q = np0 ? grp[i] : sel[i];
-        gcoords[t * g.gstride + i] = q;
-        const int dx = nlk_x(q) - px, dy = nlk_y(q) - py;
-        if (mark && dx % step == 0 && dy % step == 0) {
-          const int di = dx / step, dj = dy / step;
-          mbits |= 1ull << ((dj + g.R) * side + di + g.R);
+    nlk_match_epilogue<PSZ>(g, t, px, py, prev_p, k, sel, grp, vmap, topk, tinfo, gcoords, marks, lane);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Targets whose window does not fit the tile of k_bm_topk (queued there): one
+// wavefront per target stages the target's own window (patch + 2*wsz) in a
+// private LDS region and runs the same distance / selection / epilogue code.
+template <int PSZ, int CH, int MAXM>
+__global__ void __launch_bounds__(NLK_BM_THREADS)
+k_bm_wide(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGeom g, NlkTile tl,
+          uint32_t* __restrict__ topk, NlkTarget* __restrict__ tinfo,
+          uint32_t* __restrict__ gcoords, uint64_t* __restrict__ marks,
+          uint32_t* __restrict__ wide_list, uint32_t* __restrict__ wide_count) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int step = PSZ / 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rwp = tl.rwp, plane = rwp * tl.rh_max;  // per-wavefront region [CH][rh_max][rwp]
+  const int per_wave = ((CH * plane + 1) & ~1) + ((3 * tl.ksel_max + g.gstride + 1) & ~1);
+  float* tile = smem + (size_t)wave * per_wave;
+  uint64_t* surv = (uint64_t*)(tile + ((CH * plane + 1) & ~1));
+  uint32_t* sel = (uint32_t*)(surv + tl.ksel_max);
+  uint32_t* grp = sel + tl.ksel_max;
+  const size_t npix = (size_t)g.w * g.h;
+  const int count = (int)*wide_count;
+  for (int e = blockIdx.x * NLK_BM_WAVES + wave; e < count; e += gridDim.x * NLK_BM_WAVES) {
+    const size_t t = wide_list[e];
+    const int gy = (int)(t / g.ngx), gx = (int)(t - (size_t)gy * g.ngx);
+    const int px = gx * step, py = g.oy + gy * step;
+    const int prev_p = g.have_prev ? vmap[(size_t)py * g.w + px] : 0;
+    int k = prev_p ? g.npt : g.npx;
+    const int wsz = (g.smoother || prev_p) ? g.wsz_t : g.wsz_x;
+    const int x0 = max(px - wsz, 0), x1 = min(px + wsz, g.w - PSZ) + 1;
+    const int y0 = max(py - wsz, 0), y1 = min(py + wsz, g.h - PSZ) + 1;
+    const int nwx = x1 - x0, n = nwx * (y1 - y0);
+    k = min(k, n);
+    // stage rows [y0, y1 + PSZ - 1) x [x0, x1 + PSZ - 1) of every channel
+    const int rw = x1 - 1 + PSZ - x0, rh = y1 - 1 + PSZ - y0;
+    for (int r0 = 0; r0 < CH * rh; r0 += 8) {  // 8 rows in flight, like k_bm_topk
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = min(r0 + j, CH * rh - 1);
+        const int c = r / rh, y = r - c * rh;
+        v[j] = lane < rw ? img[c * npix + (size_t)(y0 + y) * g.w + x0 + lane] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = r0 + j;
+        if (r < CH * rh && lane < rw) {
+          const int c = r / rh, y = r - c * rh;
+          tile[c * plane + y * rwp + lane] = v[j];
         }
       }
     }
-    if (g.smoother && np0 == 0) {  // pass-through of the target patch
-      nagg = 1;
-      if (lane == 0) gcoords[t * g.gstride] = nlk_pack_xy(px, py);
-    }
-    mbits = nlk_wave_or(mbits);
-    if (lane == 0) {
-      info.nsel = k;
-      info.np0 = np0;
-      info.nagg = nagg;
-      info.flags = prev_p | (mark << 1);
-      tinfo[t] = info;
-      marks[t] = mbits;
-    }
+    nlk_wave_lds_fence();
+    const float* tl_tgt = tile + (py - y0) * rwp + (px - x0);
+    if (n <= 128)
+      nlk_match_target<PSZ, CH, 2>(tile, plane, rwp, tl_tgt, plane, rwp, 0, nwx, n, k, x0, y0, surv,
+                                   sel, lane);
+    else if (MAXM <= 7 || n <= 448)
+      nlk_match_target<PSZ, CH, (MAXM < 7 ? MAXM : 7)>(tile, plane, rwp, tl_tgt, plane, rwp, 0, nwx,
+                                                       n, k, x0, y0, surv, sel, lane);
+    else
+      nlk_match_target<PSZ, CH, MAXM>(tile, plane, rwp, tl_tgt, plane, rwp, 0, nwx, n, k, x0, y0,
+                                      surv, sel, lane);
+    nlk_match_epilogue<PSZ>(g, t, px, py, prev_p, k, sel, grp, vmap, topk, tinfo, gcoords, marks, lane);
     __builtin_amdgcn_wave_barrier();
   }
 }

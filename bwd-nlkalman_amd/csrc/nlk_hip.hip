@@ -36,7 +36,7 @@ struct nlk_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   char err[512] = "";
-  Buf pl_cur, pl_prev, pl_basic, rowok, vmap, topk, tinfo, gcoords, marks, active, acc, tabs;
+  Buf pl_cur, pl_prev, pl_basic, rowok, vmap, topk, tinfo, gcoords, marks, active, acc, tabs, wide;
   int tabs_psz = 0;
   NlkGeom last{};
   bool have_last = false;
@@ -205,43 +205,46 @@ int launch_group(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cu
 
 template <int PSZ, int CH, int MAXM>
 int launch_match_t(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds,
-                   const float* img) {
-  auto kern = k_bm_topk<PSZ, CH, MAXM>;
+                   const float* img, bool wide) {
+  auto kern = wide ? k_bm_wide<PSZ, CH, MAXM> : k_bm_topk<PSZ, CH, MAXM>;
   HIPCHK(c, hipFuncSetAttribute((const void*)kern,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(nlk_xcd_grid(tl.ntx * tl.nty)), dim3(NLK_BM_THREADS), lds, c->stream, img,
+  // k_bm_wide: the queue length is only known on the device, so a fixed grid strides over it
+  const int grid = wide ? 512 : nlk_xcd_grid(tl.ntx * tl.nty);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NLK_BM_THREADS), lds, c->stream, img,
                      (const uint8_t*)c->vmap.p, g, tl, (uint32_t*)c->topk.p,
-                     (NlkTarget*)c->tinfo.p, (uint32_t*)c->gcoords.p, (uint64_t*)c->marks.p);
+                     (NlkTarget*)c->tinfo.p, (uint32_t*)c->gcoords.p, (uint64_t*)c->marks.p,
+                     (uint32_t*)c->wide.p + 1, (uint32_t*)c->wide.p);
   HIPCHK(c, hipGetLastError());
   return NLK_OK;
 }
 
 template <int PSZ, int CH>
 int launch_match_m(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds,
-                   const float* img, int maxm) {
-  if (maxm <= 2) return launch_match_t<PSZ, CH, 2>(c, g, tl, lds, img);
-  if (maxm <= 7) return launch_match_t<PSZ, CH, 7>(c, g, tl, lds, img);
-  return launch_match_t<PSZ, CH, 16>(c, g, tl, lds, img);
+                   const float* img, int maxm, bool wide) {
+  if (maxm <= 2) return launch_match_t<PSZ, CH, 2>(c, g, tl, lds, img, wide);
+  if (maxm <= 7) return launch_match_t<PSZ, CH, 7>(c, g, tl, lds, img, wide);
+  return launch_match_t<PSZ, CH, 16>(c, g, tl, lds, img, wide);
 }
 
 template <int CH>
 int launch_match_ch(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds,
-                    const float* img, int maxm) {
+                    const float* img, int maxm, bool wide) {
   switch (g.psz) {
-    case 4: return launch_match_m<4, CH>(c, g, tl, lds, img, maxm);
-    case 6: return launch_match_m<6, CH>(c, g, tl, lds, img, maxm);
-    case 8: return launch_match_m<8, CH>(c, g, tl, lds, img, maxm);
-    case 10: return launch_match_m<10, CH>(c, g, tl, lds, img, maxm);
-    case 12: return launch_match_m<12, CH>(c, g, tl, lds, img, maxm);
-    case 16: return launch_match_m<16, CH>(c, g, tl, lds, img, maxm);
+    case 4: return launch_match_m<4, CH>(c, g, tl, lds, img, maxm, wide);
+    case 6: return launch_match_m<6, CH>(c, g, tl, lds, img, maxm, wide);
+    case 8: return launch_match_m<8, CH>(c, g, tl, lds, img, maxm, wide);
+    case 10: return launch_match_m<10, CH>(c, g, tl, lds, img, maxm, wide);
+    case 12: return launch_match_m<12, CH>(c, g, tl, lds, img, maxm, wide);
+    case 16: return launch_match_m<16, CH>(c, g, tl, lds, img, maxm, wide);
   }
   return fail(c, NLK_EUNSUP, "patch size %d not supported (4, 6, 8, 10, 12, 16)", g.psz);
 }
 
 int launch_match(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds, const float* img,
-                 int maxm) {
-  if (g.ch == 1) return launch_match_ch<1>(c, g, tl, lds, img, maxm);
-  if (g.ch == 3) return launch_match_ch<3>(c, g, tl, lds, img, maxm);
+                 int maxm, bool wide) {
+  if (g.ch == 1) return launch_match_ch<1>(c, g, tl, lds, img, maxm, wide);
+  if (g.ch == 3) return launch_match_ch<3>(c, g, tl, lds, img, maxm, wide);
   return fail(c, NLK_EUNSUP, "%d channels not supported (1 or 3)", g.ch);
 }
 
@@ -508,7 +511,8 @@ static int run_match(nlk_ctx* c, const float* cur, const float* prev, const floa
       (rc = reserve(c, c->tinfo, sizeof(NlkTarget) * (size_t)ngrid)) ||
       (rc = reserve(c, c->gcoords, sizeof(uint32_t) * (size_t)ngrid * ntagg_alloc)) ||
       (rc = reserve(c, c->marks, sizeof(uint64_t) * (size_t)ngrid)) ||
-      (rc = reserve(c, c->active, (size_t)ngrid)))
+      (rc = reserve(c, c->active, (size_t)ngrid)) ||
+      (rc = reserve(c, c->wide, sizeof(uint32_t) * ((size_t)ngrid + 1))))  // [0] = queue length
     return rc;
   mark(c, 1);
 
@@ -534,8 +538,27 @@ static int run_match(nlk_ctx* c, const float* cur, const float* prev, const floa
                                       (size_t)NLK_BM_WAVES * (3 * tl.ksel_max + ntagg_alloc));
   if (lds > 160 * 1024)
     return fail(c, NLK_EUNSUP, "matching tile needs %zu bytes of LDS (> 160 KiB)", lds);
-  rc = launch_match(c, g, tl, lds, img_match, (ncand + 63) / 64);
+  // targets of a temporal frame without a valid previous patch search the spatial window
+  // (reference: :637); when that one is the wider, they are queued for a second launch
+  const bool wide = g.have_prev && !g.smoother && g.wsz_x > g.wsz_t;
+  if (wide) HIPCHK(c, hipMemsetAsync(c->wide.p, 0, sizeof(uint32_t), c->stream));
+  const int wdom = 2 * tl.halo + 1;
+  rc = launch_match(c, g, tl, lds, img_match, (wdom * wdom + 63) / 64, false);
   if (rc) return rc;
+  if (wide) {
+    NlkTile tw = tl;
+    const int need = 2 * g.wsz_x + g.psz, ww = 2 * g.wsz_x + 1;
+    tw.halo = g.wsz_x;
+    tw.rwp = need + ((ww - need) % 32 + 32) % 32;
+    tw.rh_max = need;
+    const size_t per_wave = (((size_t)ch * tw.rwp * tw.rh_max + 1) & ~(size_t)1) +
+                            ((3 * (size_t)tw.ksel_max + ntagg_alloc + 1) & ~(size_t)1);
+    const size_t lds_w = sizeof(float) * NLK_BM_WAVES * per_wave;
+    if (lds_w > 160 * 1024)
+      return fail(c, NLK_EUNSUP, "spatial window of a temporal frame needs %zu bytes of LDS (> 160 KiB)", lds_w);
+    rc = launch_match(c, g, tw, lds_w, img_match, (ncand + 63) / 64, true);
+    if (rc) return rc;
+  }
   mark(c, 2);
 
   c->p_match = img_match; c->p_cur = img_cur; c->p_prev = img_prev;
