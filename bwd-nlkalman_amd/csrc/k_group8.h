@@ -44,6 +44,7 @@ struct NlkGTile {
   int tgx, tgy, ntx, nty;
   int rwp, rh_max;  // LDS accumulator region: row stride / rows
   int wmax;         // halo of the LDS tile around its targets (groups reaching further spill to HBM atomics)
+  int plane;        // k_group8m: floats per accumulator plane (padded, see there)
 };
 
 typedef float nlk_f4u __attribute__((ext_vector_type(4), aligned(4)));

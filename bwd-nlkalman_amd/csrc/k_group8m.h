@@ -1,0 +1,399 @@
+// k_group8m.h — group processing for 8x8 patches on the matrix cores
+// (reference: src/nlkalman.c:713-932 filter, :1603-1845 smoother).
+//
+// The 2-D DCT of an 8x8 patch is folded by the even/odd symmetry of the DCT-II
+// basis in both directions: with F_q[i][j] = X[i][j] +- X[i][7-j] +- X[7-i][j]
+// +- X[7-i][7-j] (q = parity of the vertical / horizontal frequency, i, j < 4)
+//   Y[2a+qr][2b+qc] = sum_{i,j} C[2a+qr][i] C[2b+qc][j] F_q[i][j]
+// i.e. four 16x16 matrices D_q applied to four 16-vectors: 1024 MACs per patch,
+// all of them useful, as v_mfma_f32_16x16x4_f32 products over 16 patches at a
+// time (exact f32: the f32 MFMA is an fmaf chain). The inverse uses the same
+// matrices and unfolds with the same butterflies.
+//
+// Lane roles (lo = lane & 15, g4 = lane >> 4):
+//   loads    lane = patch slot lo, rows g4 and 7-g4 of that patch (2 x 8 floats);
+//            its folded values F_q[g4][s] are the MFMA operand of k-step s.
+//   pass A   C = X^T D_q^T: register j of quadrant q = coefficient lo of
+//            candidate 4*g4+j. Statistics over the candidates are therefore
+//            register sums plus one reduction over the four lane groups; the
+//            gains come out per coefficient along the lanes.
+//   pass B   slot = 4*channel + member. C' = D_q X (operands swapped) leaves
+//            coefficient 4*g4+j of slot lo in register j, which is exactly the
+//            operand layout of the inverse product X^T = Y^T D_q; its result has
+//            the folded pixel lo of slot 4*g4+j in register j: lane group =
+//            channel plane, register = member.
+// Aggregation: after unfolding, lane (pixel lo, plane g4) holds 4 pixels of each
+// of the 4 members of a step; one LDS read-modify-write per (member, pixel)
+// touches 16 distinct pixels in (CH + 1) distinct planes (the weight plane is
+// produced by the same path: gain 0 and the DCT of a constant-1 patch as mean),
+// so the private accumulator tile needs no atomics (k_group8.h explains the
+// tile and its flush).
+#pragma once
+#include "nlk_common.h"
+#include "k_group8.h"
+
+typedef float nlk_f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float nlk_bperm(float v, int src_lane) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+__device__ __forceinline__ uint32_t nlk_bperm_u(uint32_t v, int src_lane) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
+}
+
+// rows g4 and 7-g4 of the 8x8 patch at p (row stride w) -> folded values F[q][s]
+__device__ __forceinline__ void nlk_fold_load(const float* __restrict__ p, int w, int g4, bool on,
+                                              float (&F)[4][4]) {
+  float a[8], b[8];
+  if (on) {
+    nlk_load_row8(p + g4 * w, a);
+    nlk_load_row8(p + (7 - g4) * w, b);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) a[c] = b[c] = 0.f;
+  }
+  float P[8], M[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { P[c] = a[c] + b[c]; M[c] = a[c] - b[c]; }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    F[0][s] = P[s] + P[7 - s];
+    F[1][s] = P[s] - P[7 - s];
+    F[2][s] = M[s] + M[7 - s];
+    F[3][s] = M[s] - M[7 - s];
+  }
+}
+
+// C_q += X^T D_q^T (patches along the rows) or D_q X (swapped: coefficients along the rows)
+template <bool SWAP>
+__device__ __forceinline__ void nlk_mfma_fwd(const float (&F)[4][4], const float (&dA)[4][4],
+                                             nlk_f4 (&C)[4]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      C[q] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x4f32(dA[q][s], F[q][s], C[q], 0, 0, 0)
+                  : __builtin_amdgcn_mfma_f32_16x16x4f32(F[q][s], dA[q][s], C[q], 0, 0, 0);
+}
+
+template <int CH, bool SMO>
+__global__ void __launch_bounds__(64, 2)
+k_group8m(const float* __restrict__ img,   // matching / statistics image (planar)
+          const float* __restrict__ cur,   // image whose patches are filtered
+          const float* __restrict__ prev,  // previous output or nullptr
+          const uint8_t* __restrict__ vmap, NlkGeom g, NlkGTile tl,
+          const uint32_t* __restrict__ topk, const NlkTarget* __restrict__ tinfo,
+          const uint32_t* __restrict__ gcoords, const uint8_t* __restrict__ active,
+          const float* __restrict__ basis,   // [8][8] orthonormal DCT-II
+          const float* __restrict__ window,  // [8][8] aggregation window
+          float* __restrict__ acc) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [(CH+1)][plane]
+  constexpr int PSZ = 8, step = 4;
+  const int lane = threadIdx.x;
+  const int tile_id = nlk_xcd_tile(blockIdx.x, tl.ntx * tl.nty);
+  if (tile_id >= tl.ntx * tl.nty) return;
+  const int tile_x = tile_id % tl.ntx, tile_y = tile_id / tl.ntx;
+  const int gx0 = tile_x * tl.tgx, gy0 = tile_y * tl.tgy;
+  const int cx = min(tl.tgx, g.ngx - gx0), cy = min(tl.tgy, g.ngy - gy0);
+  const int rx0 = max(gx0 * step - tl.wmax, 0);
+  const int rx1 = min((gx0 + cx - 1) * step + tl.wmax + PSZ, g.w);
+  const int ry0 = max(g.oy + gy0 * step - tl.wmax, 0);
+  const int ry1 = min(g.oy + (gy0 + cy - 1) * step + tl.wmax + PSZ, g.h);
+  const int rw = rx1 - rx0, rh = ry1 - ry0;
+  const int rwp = tl.rwp, plane = tl.plane;
+  for (int i = lane; i < (CH + 1) * plane; i += 64) smem[i] = 0.f;
+  __syncthreads();
+
+  const int lo = lane & 15, g4 = lane >> 4;
+  // D_q as the forward operand (dA: D_q[coef lo][pixel 4*g4+s]) and as the inverse
+  // operand (dI: D_q[coef 4*g4+s][pixel lo]); q = 2*qr + qc
+  float dA[4][4], dI[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int qr = q >> 1, qc = q & 1;
+      dA[q][s] = basis[(2 * (lo >> 2) + qr) * 8 + g4] * basis[(2 * (lo & 3) + qc) * 8 + s];
+      dI[q][s] = basis[(2 * g4 + qr) * 8 + (lo >> 2)] * basis[(2 * s + qc) * 8 + (lo & 3)];
+    }
+  // aggregation role: folded pixel lo = (pi, pj) of plane g4 -> 4 pixels of the patch
+  const int pi = lo >> 2, pj = lo & 3;
+  const bool agg_on = g4 <= CH;
+  int poff[4], goff[4];
+  float win[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int r = (kk & 2) ? 7 - pi : pi, c = (kk & 1) ? 7 - pj : pj;
+    poff[kk] = (agg_on ? g4 : 0) * plane + r * rwp + c;
+    goff[kk] = r * g.w + c;
+    win[kk] = window[r * 8 + c];
+  }
+  const size_t npix = (size_t)g.w * g.h;
+  float* acc_p = acc + (size_t)(agg_on ? g4 : 0) * npix;
+  const float* src = g.have_basic ? cur : img;  // patches that get filtered
+  const float s2 = g.sigma2;
+  // pass-B role of the lane as a load slot: channel / member of slot lo
+  const int bch = lo >> 2, bm = lo & 3;
+
+  int rec_act = 0, rec_nsel = 0, rec_nagg = 0, rec_flags = 0;
+  if (lane < cx * cy) {
+    const int ty = lane / cx, tx = lane - ty * cx;
+    const size_t t = (size_t)(gy0 + ty) * g.ngx + gx0 + tx;
+    rec_act = active[t];
+    const NlkTarget info = tinfo[t];
+    rec_nsel = info.nsel; rec_nagg = info.nagg; rec_flags = info.flags;
+  }
+
+  for (int tt = 0; tt < cx * cy; ++tt) {
+    if (!__builtin_amdgcn_readlane(rec_act, tt)) continue;
+    const int nagg = __builtin_amdgcn_readlane(rec_nagg, tt);
+    if (nagg == 0) continue;
+    const int ty = tt / cx, tx = tt - ty * cx;
+    const size_t t = (size_t)(gy0 + ty) * g.ngx + gx0 + tx;
+    const bool prev_p = __builtin_amdgcn_readlane(rec_flags, tt) & 1;
+    const int k = __builtin_amdgcn_readlane(rec_nsel, tt);
+
+    // candidate / member lists: one entry per lane (two rounds); validity and
+    // group-membership bits of the candidates as wave-uniform masks
+    uint32_t qreg[2], greg[2];
+    uint64_t vbits[2], gbits[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int i = lane + 64 * m;
+      qreg[m] = i < k ? topk[t * g.kmax + i] : 0u;
+      greg[m] = i < nagg ? gcoords[t * g.gstride + i] : 0u;
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int i = lane + 64 * m;
+      const int org = nlk_y(qreg[m]) * g.w + nlk_x(qreg[m]);
+      vbits[m] = __ballot(prev_p && i < k && vmap[org]);
+    }
+    const int np0a = __popcll(vbits[0]);
+    const int np0 = np0a + __popcll(vbits[1]);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int rank = (m ? np0a : 0) + __popcll(vbits[m] & ((1ull << lane) - 1ull));
+      gbits[m] = __ballot(((vbits[m] >> lane) & 1ull) && rank < g.ntagg);
+    }
+    const int np1 = k;
+    const int ngrp = min(np0, g.ntagg);
+    const float in1 = np1 ? 1.f / (float)np1 : 0.f;
+    const float in0 = np0 ? 1.f / (float)np0 : 0.f;
+    const float ing = ngrp ? 1.f / (float)ngrp : 0.f;
+    const bool passthrough = SMO && np0 == 0;  // reference: :1795-1804
+
+    // ---------------- pass A: statistics over the k kept candidates, one channel at a time
+    float G[4][4], MU[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        G[q][j] = 0.f;
+        // weight plane: gain 0, mean = DCT of the constant-1 patch (8 at frequency (0,0))
+        MU[q][j] = (!SMO && bch == CH && q == 0 && g4 == 0 && j == 0) ? 8.f : 0.f;
+      }
+    float part_sum = 0.f;
+    const int nb = (k + 15) >> 4;
+    for (int ch = 0; ch < CH; ++ch) {
+      const float* img_c = img + ch * npix;
+      const float* prev_c = prev ? prev + ch * npix : nullptr;
+      // sums of d = coefficient - x0 (x0 = coefficient of the first candidate):
+      // S0/S1 image (all candidates), S2/S3 previous frame (valid ones), S4 squared
+      // image-previous difference, S5 previous frame over the group members
+      float S[6][4], x0[4];
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[a][q] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x0[q] = 0.f;
+      for (int b = 0; b < nb; ++b) {
+        const int ci = 16 * b + lo;
+        const uint32_t qc = nlk_bperm_u(b < 4 ? qreg[0] : qreg[1], ci & 63);
+        const int org = nlk_y(qc) * g.w + nlk_x(qc);
+        const uint64_t vw = b < 4 ? vbits[0] : vbits[1];
+        const uint64_t gw = b < 4 ? gbits[0] : gbits[1];
+        const int sh = 16 * (b & 3) + 4 * g4;
+        const uint32_t vnib = (uint32_t)(vw >> sh) & 0xFu, gnib = (uint32_t)(gw >> sh) & 0xFu;
+        float F[4][4];
+        nlk_f4 C[4];
+        nlk_fold_load(img_c + org, g.w, g4, ci < k, F);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) C[q] = nlk_f4{-x0[q], -x0[q], -x0[q], -x0[q]};
+        nlk_mfma_fwd<false>(F, dA, C);
+        if (b == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            x0[q] = nlk_bperm(C[q][0], lo);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) C[q][j] -= x0[q];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float km = (16 * b + 4 * g4 + j) < k ? 1.f : 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float md = km * C[q][j];
+            S[0][q] += md;
+            S[1][q] = fmaf(md, C[q][j], S[1][q]);
+          }
+        }
+        if (np0 > 0) {
+          nlk_f4 Cp[4];
+          const bool von = ci < k && ((vw >> (ci & 63)) & 1ull);
+          nlk_fold_load(prev_c + org, g.w, g4, von, F);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Cp[q] = nlk_f4{-x0[q], -x0[q], -x0[q], -x0[q]};
+          nlk_mfma_fwd<false>(F, dA, Cp);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float vm = (vnib >> j) & 1u ? 1.f : 0.f;
+            const float gm = (gnib >> j) & 1u ? 1.f : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float d = Cp[q][j], md = vm * d;
+              S[2][q] += md;
+              S[3][q] = fmaf(md, d, S[3][q]);
+              const float df = C[q][j] - d;  // reference: :769-783, smoother :1659-1667
+              S[4][q] = fmaf(vm * df, df, S[4][q]);
+              if (!SMO) S[5][q] = fmaf(gm, d, S[5][q]);
+            }
+          }
+        }
+      }
+      // candidates are spread over the four lane groups
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = S[a][q];
+          v += nlk_bperm(v, lane ^ 16);
+          v += nlk_bperm(v, lane ^ 32);
+          S[a][q] = v;
+        }
+      // ---- gains of coefficient lo of each quadrant (reference: :799-811, :859-904; smoother :1683-1776)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float mean1 = x0[q] + S[0][q] * in1;
+        const float v1 = (S[1][q] - S[0][q] * S[0][q] * in1) * in1;       // image variance
+        const float v0 = (S[3][q] - S[2][q] * S[2][q] * in0) * in0;       // previous-frame variance
+        const float v01n = S[4][q] * in0;
+        float a, term, m;
+        if (SMO) {
+          a = v1 / (v1 + g.beta_t * v01n);
+          const float pv = v0 - g.beta_t * v01n;
+          term = (1 - a * a) * v1 + a * a * (pv > 0.f ? pv : 0.f);
+          m = 0.f;
+        } else if (np0 > 0) {
+          const float d = v01n - (g.have_basic ? 0.f : s2);
+          const float v = v0 + (0.f > d ? 0.f : d);
+          a = v / (v + g.beta_t * s2);
+          term = (1 - a * a) * v + a * a * s2;
+          m = x0[q] + S[5][q] * ing;
+        } else {
+          const float d = v1 - (g.have_basic ? 0.f : s2);
+          const float v = 0.f > d ? 0.f : d;
+          a = v / (v + g.beta_x * s2);
+          term = a * v;
+          m = mean1;
+        }
+        if (g4 == 0) part_sum += term;
+        const float mu = (1 - a) * m;  // filter: a*PG + (1-a)*M (reference: :879, :902)
+        // to the pass-B layout: coefficient 4*g4+j of the slots of this channel
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float ta = nlk_bperm(a, 4 * g4 + j), tm = nlk_bperm(mu, 4 * g4 + j);
+          if (bch == ch) { G[q][j] = passthrough ? 0.f : ta; MU[q][j] = tm; }
+        }
+      }
+    }
+    // the reference adds the same per-coefficient terms once per group member
+    float vp = nlk_wave_sum8(part_sum) * (float)nagg;
+    if (passthrough) vp = 0.f;
+    const float wgt = 1.f / (vp > 1e-6f ? vp : 1e-6f);
+    float ww[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) ww[kk] = wgt * win[kk];
+
+    // ---------------- pass B: shrink, invert and aggregate the group members, 4 per step
+    for (int n0 = 0; n0 < nagg; n0 += 4) {
+      const int n = n0 + bm;
+      const uint32_t qm = nlk_bperm_u(n < 64 ? greg[0] : greg[1], n & 63);
+      const int org = nlk_y(qm) * g.w + nlk_x(qm);
+      const bool on = bch < CH && n < nagg;
+      float F[4][4];
+      nlk_f4 Y[4], Z[4];
+      nlk_fold_load(src + bch * npix + org, g.w, g4, on, F);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Y[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
+      nlk_mfma_fwd<true>(F, dA, Y);
+      if (SMO) {
+        nlk_f4 Yp[4];
+        nlk_fold_load(prev + bch * npix + org, g.w, g4, on && !passthrough, F);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Yp[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
+        nlk_mfma_fwd<true>(F, dA, Yp);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            Y[q][j] = (1 - G[q][j]) * Y[q][j] + G[q][j] * Yp[q][j];  // reference: :1775
+        if (bch == CH) {  // weight plane
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Y[q][j] = (q == 0 && g4 == 0 && j == 0) ? 8.f : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Y[q][j] = fmaf(G[q][j], Y[q][j], MU[q][j]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Z[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          Z[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(Y[q][s], dI[q][s], Z[q], 0, 0, 0);
+      // register m of Z = member n0+m, plane g4, folded pixel lo
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if (n0 + m >= nagg) break;
+        const uint32_t q = (n0 + m) < 64 ? __builtin_amdgcn_readlane(greg[0], n0 + m)
+                                         : __builtin_amdgcn_readlane(greg[1], n0 + m - 64);
+        const int qx = nlk_x(q), qy = nlk_y(q);
+        const float e0 = Z[0][m] + Z[1][m], e1 = Z[0][m] - Z[1][m];
+        const float o0 = Z[2][m] + Z[3][m], o1 = Z[2][m] - Z[3][m];
+        float px[4] = {e0 + o0, e1 + o1, e0 - o0, e1 - o1};
+        const int lx = qx - rx0, ly = qy - ry0;
+        if (lx >= 0 && ly >= 0 && lx + PSZ <= rw && ly + PSZ <= rh) {
+          if (agg_on) {
+            float* dst = smem + ly * rwp + lx;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) dst[poff[kk]] = fmaf(ww[kk], px[kk], dst[poff[kk]]);
+          }
+        } else if (agg_on) {
+          float* dst = acc_p + (size_t)qy * g.w + qx;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) unsafeAtomicAdd(dst + goff[kk], ww[kk] * px[kk]);
+        }
+      }
+    }
+  }
+
+  // ---------------- flush the tile accumulator (coalesced rows, skip untouched)
+  __syncthreads();
+  for (int p = 0; p <= CH; ++p)
+    for (int y = 0; y < rh; ++y) {
+      const float* srow = smem + p * plane + y * rwp;
+      float* drow = acc + (size_t)p * npix + (size_t)(ry0 + y) * g.w + rx0;
+      for (int xx = lane; xx < rw; xx += 64) {
+        const float v = srow[xx];
+        if (v != 0.f) unsafeAtomicAdd(drow + xx, v);
+      }
+    }
+}

@@ -16,6 +16,7 @@
 #include "k_frame.h"
 #include "k_group.h"
 #include "k_group8.h"
+#include "k_group8m.h"
 #include "k_group12.h"
 #include "k_match.h"
 #include "nlk_common.h"
@@ -166,14 +167,27 @@ int launch_group_fast_t(nlk_ctx* c, const NlkGeom& g, const float* img, const fl
   // LDS tile halo = reach of the dominant kind of group; the rare spatial-branch
   // groups of a temporal frame that reach further fall back to HBM atomics
   tl.wmax = (g.smoother || g.have_prev) ? g.wsz_t : g.wsz_x;
-  tl.rwp = ((tl.tgx - 1) * g.step + 2 * tl.wmax + g.psz) | 1;
+  // psz 8 runs its DCTs on the matrix cores (k_group8m.h); NLK_GROUP_DPP selects the
+  // register/DPP kernel (k_group8.h) for comparison
+  const bool mfma = PSZ == 8 && !getenv("NLK_GROUP_DPP");
+  const int rw_max = (tl.tgx - 1) * g.step + 2 * tl.wmax + g.psz;
   tl.rh_max = (tl.tgy - 1) * g.step + 2 * tl.wmax + g.psz;
-  const size_t lds = sizeof(float) * (size_t)(CH + 1) * tl.rwp * tl.rh_max;
+  if (mfma) {
+    // one aggregation access = 4x4 pixels of each plane: row stride = 4 and plane
+    // stride = 16 (mod 32 banks) make the 64 lanes hit every bank twice
+    tl.rwp = rw_max + ((4 - rw_max) % 32 + 32) % 32;
+    tl.plane = tl.rwp * tl.rh_max;
+    tl.plane += ((16 - tl.plane) % 32 + 32) % 32;
+  } else {
+    tl.rwp = rw_max | 1;
+    tl.plane = tl.rwp * tl.rh_max;
+  }
+  const size_t lds = sizeof(float) * (size_t)(CH + 1) * tl.plane;
   if (lds > 160 * 1024) return fail(c, NLK_EUNSUP, "aggregation tile needs %zu bytes of LDS", lds);
   void (*kern)(const float*, const float*, const float*, const uint8_t*, NlkGeom, NlkGTile,
                const uint32_t*, const NlkTarget*, const uint32_t*, const uint8_t*, const float*,
                const float*, float*);
-  if (PSZ == 8) kern = k_group8<CH, SMO>;
+  if (PSZ == 8) kern = mfma ? k_group8m<CH, SMO> : k_group8<CH, SMO>;
   else kern = k_group12<CH, SMO>;
   HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
