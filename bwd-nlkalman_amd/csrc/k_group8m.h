@@ -31,6 +31,16 @@
 #pragma once
 #include "nlk_common.h"
 #include "k_group8.h"
+#include <type_traits>
+#ifndef NLK_EXP
+#define NLK_EXP 0
+#endif
+#if NLK_EXP == 4
+__device__ unsigned long long nlk_dbg[8];
+#define NLK_T(i) { const unsigned long long _t = clock64(); dbg[i] += _t - tlast; tlast = _t; }
+#else
+#define NLK_T(i)
+#endif
 
 typedef float nlk_f4 __attribute__((ext_vector_type(4)));
 
@@ -41,20 +51,24 @@ __device__ __forceinline__ uint32_t nlk_bperm_u(uint32_t v, int src_lane) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
 }
 
-// rows g4 and 7-g4 of the 8x8 patch at p (row stride w) -> folded values F[q][s]
-__device__ __forceinline__ void nlk_fold_load(const float* __restrict__ p, int w, int g4, bool on,
-                                              float (&F)[4][4]) {
-  float a[8], b[8];
-  if (on) {
-    nlk_load_row8(p + g4 * w, a);
-    nlk_load_row8(p + (7 - g4) * w, b);
-  } else {
+// rows g4 and 7-g4 of the 8x8 patch at p (row stride w). Always executed: slots without
+// a patch are pointed at some valid patch by the caller and masked out later (loads under
+// divergent control flow would make the compiler wait for every load in flight).
+__device__ __forceinline__ void nlk_rows_load(const float* __restrict__ p, int w, int g4,
+                                              float (&R)[16]) {
+  const nlk_f4u a0 = *reinterpret_cast<const nlk_f4u*>(p + g4 * w);
+  const nlk_f4u a1 = *reinterpret_cast<const nlk_f4u*>(p + g4 * w + 4);
+  const nlk_f4u b0 = *reinterpret_cast<const nlk_f4u*>(p + (7 - g4) * w);
+  const nlk_f4u b1 = *reinterpret_cast<const nlk_f4u*>(p + (7 - g4) * w + 4);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) a[c] = b[c] = 0.f;
-  }
+  for (int c = 0; c < 4; ++c) { R[c] = a0[c]; R[4 + c] = a1[c]; R[8 + c] = b0[c]; R[12 + c] = b1[c]; }
+}
+
+// the two rows -> folded values F[q][s] (q = 2*qr + qc, see the header)
+__device__ __forceinline__ void nlk_fold(const float (&R)[16], float (&F)[4][4]) {
   float P[8], M[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) { P[c] = a[c] + b[c]; M[c] = a[c] - b[c]; }
+  for (int c = 0; c < 8; ++c) { P[c] = R[c] + R[8 + c]; M[c] = R[c] - R[8 + c]; }
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     F[0][s] = P[s] + P[7 - s];
@@ -77,7 +91,7 @@ __device__ __forceinline__ void nlk_mfma_fwd(const float (&F)[4][4], const float
 }
 
 template <int CH, bool SMO>
-__global__ void __launch_bounds__(64, 2)
+__global__ void __launch_bounds__(64, 3)
 k_group8m(const float* __restrict__ img,   // matching / statistics image (planar)
           const float* __restrict__ cur,   // image whose patches are filtered
           const float* __restrict__ prev,  // previous output or nullptr
@@ -101,7 +115,9 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   const int ry1 = min(g.oy + (gy0 + cy - 1) * step + tl.wmax + PSZ, g.h);
   const int rw = rx1 - rx0, rh = ry1 - ry0;
   const int rwp = tl.rwp, plane = tl.plane;
-  for (int i = lane; i < (CH + 1) * plane; i += 64) smem[i] = 0.f;
+  for (int i = lane; i < (CH + 1) * plane / 4; i += 64)  // (plane is a multiple of 16)
+    reinterpret_cast<nlk_f4*>(smem)[i] = nlk_f4{0.f, 0.f, 0.f, 0.f};
+  float* stash = smem + (CH + 1) * plane;  // [CH][2][4][16]: gains / means between the passes
   __syncthreads();
 
   const int lo = lane & 15, g4 = lane >> 4;
@@ -135,22 +151,32 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   // pass-B role of the lane as a load slot: channel / member of slot lo
   const int bch = lo >> 2, bm = lo & 3;
 
-  int rec_act = 0, rec_nsel = 0, rec_nagg = 0, rec_flags = 0;
+  int rec_act = 0, rec_nsel = 0, rec_nagg = 0;
+  uint32_t rec_vb[4] = {0u, 0u, 0u, 0u};
   if (lane < cx * cy) {
     const int ty = lane / cx, tx = lane - ty * cx;
     const size_t t = (size_t)(gy0 + ty) * g.ngx + gx0 + tx;
     rec_act = active[t];
     const NlkTarget info = tinfo[t];
-    rec_nsel = info.nsel; rec_nagg = info.nagg; rec_flags = info.flags;
+    rec_nsel = info.nsel; rec_nagg = info.nagg;
+    rec_vb[0] = (uint32_t)info.vbits[0]; rec_vb[1] = (uint32_t)(info.vbits[0] >> 32);
+    rec_vb[2] = (uint32_t)info.vbits[1]; rec_vb[3] = (uint32_t)(info.vbits[1] >> 32);
   }
 
+#if NLK_EXP == 4
+  unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+  const unsigned long long tstart = tlast;
+#endif
+  NLK_T(5)
   for (int tt = 0; tt < cx * cy; ++tt) {
     if (!__builtin_amdgcn_readlane(rec_act, tt)) continue;
     const int nagg = __builtin_amdgcn_readlane(rec_nagg, tt);
     if (nagg == 0) continue;
+#if NLK_EXP == 4
+    dbg[6] += 1;
+#endif
     const int ty = tt / cx, tx = tt - ty * cx;
     const size_t t = (size_t)(gy0 + ty) * g.ngx + gx0 + tx;
-    const bool prev_p = __builtin_amdgcn_readlane(rec_flags, tt) & 1;
     const int k = __builtin_amdgcn_readlane(rec_nsel, tt);
 
     // candidate / member lists: one entry per lane (two rounds); validity and
@@ -163,12 +189,11 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       qreg[m] = i < k ? topk[t * g.kmax + i] : 0u;
       greg[m] = i < nagg ? gcoords[t * g.gstride + i] : 0u;
     }
+    // (validity bits of the kept candidates come with the records of the match kernel)
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int i = lane + 64 * m;
-      const int org = nlk_y(qreg[m]) * g.w + nlk_x(qreg[m]);
-      vbits[m] = __ballot(prev_p && i < k && vmap[org]);
-    }
+    for (int m = 0; m < 2; ++m)
+      vbits[m] = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rec_vb[2 * m], tt) |
+                 ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rec_vb[2 * m + 1], tt) << 32);
     const int np0a = __popcll(vbits[0]);
     const int np0 = np0a + __popcll(vbits[1]);
 #pragma unroll
@@ -183,42 +208,64 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     const float ing = ngrp ? 1.f / (float)ngrp : 0.f;
     const bool passthrough = SMO && np0 == 0;  // reference: :1795-1804
 
-    // ---------------- pass A: statistics over the k kept candidates, one channel at a time
-    float G[4][4], MU[4][4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        G[q][j] = 0.f;
-        // weight plane: gain 0, mean = DCT of the constant-1 patch (8 at frequency (0,0))
-        MU[q][j] = (!SMO && bch == CH && q == 0 && g4 == 0 && j == 0) ? 8.f : 0.f;
-      }
+    // ---------------- pass A: statistics over the k kept candidates, one channel at a
+    // time. A step transforms 16 patches: 16 candidates of the image, or - when the
+    // target has previous-frame patches - 8 candidates of the image AND their 8
+    // previous-frame patches (slot lo = 4*(c>>1) + 2*isprev + (c&1), so that both
+    // coefficients of a candidate end up in the same lane: registers j and j+2).
     float part_sum = 0.f;
-    const int nb = (k + 15) >> 4;
-    for (int ch = 0; ch < CH; ++ch) {
-      const float* img_c = img + ch * npix;
-      const float* prev_c = prev ? prev + ch * npix : nullptr;
-      // sums of d = coefficient - x0 (x0 = coefficient of the first candidate):
-      // S0/S1 image (all candidates), S2/S3 previous frame (valid ones), S4 squared
-      // image-previous difference, S5 previous frame over the group members
-      float S[6][4], x0[4];
+    // sums of d = coefficient - x0 (x0 = coefficient of the first candidate):
+    // S0/S1 image (all candidates), S2/S3 previous frame (valid ones), S4 squared
+    // image-previous difference, S5 previous frame over the group members
+    float S[6][4], x0[4];
 #pragma unroll
-      for (int a = 0; a < 6; ++a)
+    for (int a = 0; a < 6; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) S[a][q] = 0.f;
+      for (int q = 0; q < 4; ++q) S[a][q] = 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) x0[q] = 0.f;
-      for (int b = 0; b < nb; ++b) {
-        const int ci = 16 * b + lo;
-        const uint32_t qc = nlk_bperm_u(b < 4 ? qreg[0] : qreg[1], ci & 63);
-        const int org = nlk_y(qc) * g.w + nlk_x(qc);
-        const uint64_t vw = b < 4 ? vbits[0] : vbits[1];
-        const uint64_t gw = b < 4 ? gbits[0] : gbits[1];
-        const int sh = 16 * (b & 3) + 4 * g4;
-        const uint32_t vnib = (uint32_t)(vw >> sh) & 0xFu, gnib = (uint32_t)(gw >> sh) & 0xFu;
-        float F[4][4];
+    for (int q = 0; q < 4; ++q) x0[q] = 0.f;
+    NLK_T(0)
+    // two copies of the loop (with / without previous-frame patches).
+    // Load schedule: the rows of step it+1 are requested right after those of step it
+    // were folded and the address of step it+2 is prepared, so every request has a
+    // whole step to land. All loads are unconditional (a slot without a patch reads a
+    // valid one and is masked out): a load under a run-time branch would turn every
+    // wait into a wait for all loads in flight.
+    auto pass_a = [&](auto has_prev) {
+      constexpr bool HP = decltype(has_prev)::value;
+      constexpr int CB = HP ? 8 : 16;  // candidates per step
+      const int nb = (k + CB - 1) / CB;
+      const int njobs = CH * nb;
+      if (njobs == 0) return;
+      const int slot_c = HP ? 2 * (lo >> 2) + (lo & 1) : lo;
+      const bool slot_prev = HP && ((lo >> 1) & 1);
+      // rows of slot lo of step bb of channel cc; a candidate without a valid previous
+      // patch (NaNs) reads the image instead: finite, and masked out of the sums
+      auto slot_ptr = [&](int bb, int cc) -> const float* {
+        const int ci = CB * bb + slot_c, cl = min(ci, k - 1);
+        const uint32_t qc = nlk_bperm_u(cl < 64 ? qreg[0] : qreg[1], cl & 63);
+        const int o = nlk_y(qc) * g.w + nlk_x(qc);
+        const bool usep = slot_prev && ci < k && (((ci < 64 ? vbits[0] : vbits[1]) >> (ci & 63)) & 1ull);
+        return (usep ? prev : img) + cc * npix + o;
+      };
+      auto next_job = [&](int bb, int cc, int& ob, int& oc) {
+        ob = bb + 1; oc = cc;
+        if (ob == nb) { ob = 0; oc = cc + 1; }
+        if (oc == CH) { ob = bb; oc = cc; }  // (past the end: a harmless reload)
+      };
+      float R[16], F[4][4];
+      int b = 0, ch = 0, b1, ch1;
+      nlk_rows_load(slot_ptr(0, 0), g.w, g4, R);
+      next_job(b, ch, b1, ch1);
+      const float* pnext = slot_ptr(b1, ch1);
+      for (int it = 0; it < njobs; ++it) {
+        int b2, ch2;
+        next_job(b1, ch1, b2, ch2);
+        nlk_fold(R, F);
+        nlk_rows_load(pnext, g.w, g4, R);
+        pnext = slot_ptr(b2, ch2);
+        __builtin_amdgcn_sched_barrier(0);
         nlk_f4 C[4];
-        nlk_fold_load(img_c + org, g.w, g4, ci < k, F);
 #pragma unroll
         for (int q = 0; q < 4; ++q) C[q] = nlk_f4{-x0[q], -x0[q], -x0[q], -x0[q]};
         nlk_mfma_fwd<false>(F, dA, C);
@@ -230,85 +277,118 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
             for (int j = 0; j < 4; ++j) C[q][j] -= x0[q];
           }
         }
+        if (HP) {
+          const uint64_t vw = b < 8 ? vbits[0] : vbits[1];
+          const uint64_t gw = b < 8 ? gbits[0] : gbits[1];
+          const int sh = 8 * (b & 7) + 2 * g4;
+          const uint32_t vnib = (uint32_t)(vw >> sh) & 3u, gnib = (uint32_t)(gw >> sh) & 3u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float km = (16 * b + 4 * g4 + j) < k ? 1.f : 0.f;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float md = km * C[q][j];
-            S[0][q] += md;
-            S[1][q] = fmaf(md, C[q][j], S[1][q]);
-          }
-        }
-        if (np0 > 0) {
-          nlk_f4 Cp[4];
-          const bool von = ci < k && ((vw >> (ci & 63)) & 1ull);
-          nlk_fold_load(prev_c + org, g.w, g4, von, F);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) Cp[q] = nlk_f4{-x0[q], -x0[q], -x0[q], -x0[q]};
-          nlk_mfma_fwd<false>(F, dA, Cp);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < 2; ++j) {
+            const float km = (8 * b + 2 * g4 + j) < k ? 1.f : 0.f;
             const float vm = (vnib >> j) & 1u ? 1.f : 0.f;
             const float gm = (gnib >> j) & 1u ? 1.f : 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const float d = Cp[q][j], md = vm * d;
+              const float di = C[q][j], mdi = km * di;
+              S[0][q] += mdi;
+              S[1][q] = fmaf(mdi, di, S[1][q]);
+              const float d = C[q][j + 2], md = vm * d;
               S[2][q] += md;
               S[3][q] = fmaf(md, d, S[3][q]);
-              const float df = C[q][j] - d;  // reference: :769-783, smoother :1659-1667
+              const float df = di - d;  // reference: :769-783, smoother :1659-1667
               S[4][q] = fmaf(vm * df, df, S[4][q]);
               if (!SMO) S[5][q] = fmaf(gm, d, S[5][q]);
             }
           }
-        }
-      }
-      // candidates are spread over the four lane groups
-#pragma unroll
-      for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v = S[a][q];
-          v += nlk_bperm(v, lane ^ 16);
-          v += nlk_bperm(v, lane ^ 32);
-          S[a][q] = v;
-        }
-      // ---- gains of coefficient lo of each quadrant (reference: :799-811, :859-904; smoother :1683-1776)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float mean1 = x0[q] + S[0][q] * in1;
-        const float v1 = (S[1][q] - S[0][q] * S[0][q] * in1) * in1;       // image variance
-        const float v0 = (S[3][q] - S[2][q] * S[2][q] * in0) * in0;       // previous-frame variance
-        const float v01n = S[4][q] * in0;
-        float a, term, m;
-        if (SMO) {
-          a = v1 / (v1 + g.beta_t * v01n);
-          const float pv = v0 - g.beta_t * v01n;
-          term = (1 - a * a) * v1 + a * a * (pv > 0.f ? pv : 0.f);
-          m = 0.f;
-        } else if (np0 > 0) {
-          const float d = v01n - (g.have_basic ? 0.f : s2);
-          const float v = v0 + (0.f > d ? 0.f : d);
-          a = v / (v + g.beta_t * s2);
-          term = (1 - a * a) * v + a * a * s2;
-          m = x0[q] + S[5][q] * ing;
         } else {
-          const float d = v1 - (g.have_basic ? 0.f : s2);
-          const float v = 0.f > d ? 0.f : d;
-          a = v / (v + g.beta_x * s2);
-          term = a * v;
-          m = mean1;
-        }
-        if (g4 == 0) part_sum += term;
-        const float mu = (1 - a) * m;  // filter: a*PG + (1-a)*M (reference: :879, :902)
-        // to the pass-B layout: coefficient 4*g4+j of the slots of this channel
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float ta = nlk_bperm(a, 4 * g4 + j), tm = nlk_bperm(mu, 4 * g4 + j);
-          if (bch == ch) { G[q][j] = passthrough ? 0.f : ta; MU[q][j] = tm; }
+          for (int j = 0; j < 4; ++j) {
+            const float km = (16 * b + 4 * g4 + j) < k ? 1.f : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float md = km * C[q][j];
+              S[0][q] += md;
+              S[1][q] = fmaf(md, C[q][j], S[1][q]);
+            }
+          }
         }
+        if (b == nb - 1) {
+          NLK_T(1)
+          // the channel is complete: candidates are spread over the four lane groups
+#pragma unroll
+          for (int a = 0; a < (HP ? 6 : 2); ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float v = S[a][q];
+              v += nlk_bperm(v, lane ^ 16);
+              v += nlk_bperm(v, lane ^ 32);
+              S[a][q] = v;
+            }
+          // ---- gains of coefficient lo of each quadrant (reference: :799-811, :859-904; smoother :1683-1776)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float mean1 = x0[q] + S[0][q] * in1;
+            const float v1 = (S[1][q] - S[0][q] * S[0][q] * in1) * in1;  // image variance
+            const float v0 = (S[3][q] - S[2][q] * S[2][q] * in0) * in0;  // previous-frame variance
+            const float v01n = S[4][q] * in0;
+            float a, term, m;
+            if (SMO) {
+              a = v1 / (v1 + g.beta_t * v01n);
+              const float pv = v0 - g.beta_t * v01n;
+              term = (1 - a * a) * v1 + a * a * (pv > 0.f ? pv : 0.f);
+              m = 0.f;
+            } else if (HP) {
+              const float d = v01n - (g.have_basic ? 0.f : s2);
+              const float v = v0 + (0.f > d ? 0.f : d);
+              a = v / (v + g.beta_t * s2);
+              term = (1 - a * a) * v + a * a * s2;
+              m = x0[q] + S[5][q] * ing;
+            } else {
+              const float d = v1 - (g.have_basic ? 0.f : s2);
+              const float v = 0.f > d ? 0.f : d;
+              a = v / (v + g.beta_x * s2);
+              term = a * v;
+              m = mean1;
+            }
+            if (g4 == 0) {
+              part_sum += term;
+              // parked in LDS for pass B: [channel][gain | (1-a)*mean][quadrant][coefficient]
+              // (filter: a*PG + (1-a)*M, reference: :879, :902)
+              stash[((ch * 2 + 0) * 4 + q) * 16 + lo] = a;
+              stash[((ch * 2 + 1) * 4 + q) * 16 + lo] = (1 - a) * m;
+            }
+          }
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) S[a][q] = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) x0[q] = 0.f;
+          NLK_T(2)
+        }
+        b = b1; ch = ch1; b1 = b2; ch1 = ch2;
       }
+    };
+    if (np0 > 0) pass_a(std::true_type{});
+    else pass_a(std::false_type{});
+
+    // ---------------- pass B: shrink, invert and aggregate the group members, 4 per step
+    // (slot lo = 4*channel + member; slots without a member / channel read a valid patch
+    // and their results are not used)
+    const int bchc = min(bch, CH - 1);
+    auto member_off = [&](int n0) -> int {
+      const int n = min(n0 + bm, nagg - 1);
+      const uint32_t qm = nlk_bperm_u(n < 64 ? greg[0] : greg[1], n & 63);
+      return bchc * (int)npix + nlk_y(qm) * g.w + nlk_x(qm);
+    };
+    const float* psrc = passthrough ? src : prev;  // (smoother) previous-frame patches
+    float R[16], Rp[16], F[4][4];
+    {
+      const int off = member_off(0);
+      nlk_rows_load(src + off, g.w, g4, R);
+      if (SMO) nlk_rows_load(psrc + off, g.w, g4, Rp);
     }
+    int offn = member_off(4);
     // the reference adds the same per-coefficient terms once per group member
     float vp = nlk_wave_sum8(part_sum) * (float)nagg;
     if (passthrough) vp = 0.f;
@@ -316,41 +396,51 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     float ww[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) ww[kk] = wgt * win[kk];
-
-    // ---------------- pass B: shrink, invert and aggregate the group members, 4 per step
+    const float* st_g = stash + (bchc * 2 + 0) * 64 + 4 * g4;  // + 16*q: gains of coefficients 4*g4 .. 4*g4+3
+    const float* st_m = stash + (bchc * 2 + 1) * 64 + 4 * g4;
+    NLK_T(3)
     for (int n0 = 0; n0 < nagg; n0 += 4) {
-      const int n = n0 + bm;
-      const uint32_t qm = nlk_bperm_u(n < 64 ? greg[0] : greg[1], n & 63);
-      const int org = nlk_y(qm) * g.w + nlk_x(qm);
-      const bool on = bch < CH && n < nagg;
-      float F[4][4];
       nlk_f4 Y[4], Z[4];
-      nlk_fold_load(src + bch * npix + org, g.w, g4, on, F);
+      nlk_fold(R, F);
+      nlk_rows_load(src + offn, g.w, g4, R);
 #pragma unroll
       for (int q = 0; q < 4; ++q) Y[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
-      nlk_mfma_fwd<true>(F, dA, Y);
       if (SMO) {
+        float Fp[4][4];
         nlk_f4 Yp[4];
-        nlk_fold_load(prev + bch * npix + org, g.w, g4, on && !passthrough, F);
+        nlk_fold(Rp, Fp);
+        nlk_rows_load(psrc + offn, g.w, g4, Rp);
+        offn = member_off(n0 + 8);
+        __builtin_amdgcn_sched_barrier(0);
+        nlk_mfma_fwd<true>(F, dA, Y);
 #pragma unroll
         for (int q = 0; q < 4; ++q) Yp[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
-        nlk_mfma_fwd<true>(F, dA, Yp);
+        nlk_mfma_fwd<true>(Fp, dA, Yp);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q) {
+          const nlk_f4 gq = *reinterpret_cast<const nlk_f4*>(st_g + 16 * q);
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            Y[q][j] = (1 - G[q][j]) * Y[q][j] + G[q][j] * Yp[q][j];  // reference: :1775
-        if (bch == CH) {  // weight plane
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Y[q][j] = (q == 0 && g4 == 0 && j == 0) ? 8.f : 0.f;
+          for (int j = 0; j < 4; ++j) {
+            const float a = passthrough ? 0.f : gq[j];
+            const float wv = (q == 0 && g4 == 0 && j == 0) ? 8.f : 0.f;  // weight plane: DCT of a constant-1 patch
+            Y[q][j] = bch < CH ? (1 - a) * Y[q][j] + a * Yp[q][j]  // reference: :1775
+                               : (bch == CH ? wv : 0.f);
+          }
         }
       } else {
+        offn = member_off(n0 + 8);
+        __builtin_amdgcn_sched_barrier(0);
+        nlk_mfma_fwd<true>(F, dA, Y);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q) {
+          const nlk_f4 gq = *reinterpret_cast<const nlk_f4*>(st_g + 16 * q);
+          const nlk_f4 mq = *reinterpret_cast<const nlk_f4*>(st_m + 16 * q);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) Y[q][j] = fmaf(G[q][j], Y[q][j], MU[q][j]);
+          for (int j = 0; j < 4; ++j) {
+            const float wv = (q == 0 && g4 == 0 && j == 0) ? 8.f : 0.f;  // weight plane: gain 0, DCT of a constant-1 patch
+            Y[q][j] = bch < CH ? fmaf(gq[j], Y[q][j], mq[j]) : (bch == CH ? wv : 0.f);
+          }
+        }
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) Z[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
@@ -373,8 +463,11 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         if (lx >= 0 && ly >= 0 && lx + PSZ <= rw && ly + PSZ <= rh) {
           if (agg_on) {
             float* dst = smem + ly * rwp + lx;
+            float old[4];  // the four pixels are distinct: read them together
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) dst[poff[kk]] = fmaf(ww[kk], px[kk], dst[poff[kk]]);
+            for (int kk = 0; kk < 4; ++kk) old[kk] = dst[poff[kk]];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) dst[poff[kk]] = fmaf(ww[kk], px[kk], old[kk]);
           }
         } else if (agg_on) {
           float* dst = acc_p + (size_t)qy * g.w + qx;
@@ -383,17 +476,31 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         }
       }
     }
+    NLK_T(4)
   }
 
   // ---------------- flush the tile accumulator (coalesced rows, skip untouched)
   __syncthreads();
-  for (int p = 0; p <= CH; ++p)
-    for (int y = 0; y < rh; ++y) {
-      const float* srow = smem + p * plane + y * rwp;
-      float* drow = acc + (size_t)p * npix + (size_t)(ry0 + y) * g.w + rx0;
-      for (int xx = lane; xx < rw; xx += 64) {
-        const float v = srow[xx];
-        if (v != 0.f) unsafeAtomicAdd(drow + xx, v);
-      }
+  {
+    // a narrow tile (<= 32 columns) puts two rows on the 64 lanes
+    const bool two = rw <= 32;
+    const int fx = two ? (lane & 31) : lane, fy = two ? (lane >> 5) : 0;
+    const int sx = two ? 32 : 64, sy = two ? 2 : 1;
+    for (int p = 0; p <= CH; ++p) {
+      const float* sp = smem + p * plane;
+      float* dp = acc + (size_t)p * npix + (size_t)ry0 * g.w + rx0;
+#pragma unroll 4
+      for (int y = fy; y < rh; y += sy)
+        for (int xx = fx; xx < rw; xx += sx) {
+          const float v = sp[y * rwp + xx];
+          if (v != 0.f) unsafeAtomicAdd(dp + (size_t)y * g.w + xx, v);
+        }
     }
+  }
+#if NLK_EXP == 4
+  NLK_T(5)
+  dbg[7] = tlast - tstart;
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&nlk_dbg[i], dbg[i]);
+#endif
 }

@@ -175,10 +175,11 @@ __device__ inline void nlk_match_epilogue(const NlkGeom& g, size_t t, int px, in
                                           uint32_t* __restrict__ gcoords,
                                           uint64_t* __restrict__ marks, int lane) {
   constexpr int step = PSZ / 2;
-  NlkTarget info = {0, 0, 0, prev_p};
+  NlkTarget info = {0, 0, 0, prev_p, {0ull, 0ull}};
   // --- group membership: the first ntagg kept candidates that have a valid
   // previous patch, or (none valid) the first ntagg kept candidates
   int np0 = 0;
+  uint64_t vb[2] = {0ull, 0ull};
   for (int base = 0; base < k; base += 64) {
     const int i = base + lane;
     uint32_t q = 0;
@@ -189,6 +190,7 @@ __device__ inline void nlk_match_epilogue(const NlkGeom& g, size_t t, int px, in
       v = prev_p ? vmap[(size_t)nlk_y(q) * g.w + nlk_x(q)] : 0;
     }
     const uint64_t b = __ballot(v);
+    if (base < 128) vb[base >> 6] = b;
     const int slot = np0 + __popcll(b & ((1ull << lane) - 1ull));
     if (v && slot < g.ntagg) grp[slot] = q;
     np0 += __popcll(b);
@@ -227,6 +229,7 @@ __device__ inline void nlk_match_epilogue(const NlkGeom& g, size_t t, int px, in
     info.np0 = np0;
     info.nagg = nagg;
     info.flags = prev_p | (mark << 1);
+    info.vbits[0] = vb[0]; info.vbits[1] = vb[1];
     tinfo[t] = info;
     marks[t] = mbits;
   }
@@ -313,7 +316,7 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
     const size_t t = (size_t)gy * g.ngx + gx;
     const int prev_p = __builtin_amdgcn_readlane(rec_prev, tt);
     int k = prev_p ? g.npt : g.npx;
-    NlkTarget info = {0, 0, 0, prev_p};
+    NlkTarget info = {0, 0, 0, prev_p, {0ull, 0ull}};
     if (k <= 1) {
       // single-patch mode aggregates nothing in the filter (reference: :815-857);
       // the smoother passes the target patch through (reference: :1795-1804)

@@ -24,6 +24,7 @@ struct NlkTarget {
   int np0;    // kept candidates with a valid previous patch
   int nagg;   // group members that are filtered and aggregated
   int flags;  // bit0: prev_p, bit1: group marks the processed-mask
+  uint64_t vbits[2];  // bit i: kept candidate i (< 128) has a valid previous patch
 };
 
 static __host__ __device__ inline uint32_t nlk_pack_xy(int x, int y) {

@@ -182,7 +182,7 @@ int launch_group_fast_t(nlk_ctx* c, const NlkGeom& g, const float* img, const fl
     tl.rwp = rw_max | 1;
     tl.plane = tl.rwp * tl.rh_max;
   }
-  const size_t lds = sizeof(float) * (size_t)(CH + 1) * tl.plane;
+  const size_t lds = sizeof(float) * ((size_t)(CH + 1) * tl.plane + (mfma ? CH * 128 : 0));
   if (lds > 160 * 1024) return fail(c, NLK_EUNSUP, "aggregation tile needs %zu bytes of LDS", lds);
   void (*kern)(const float*, const float*, const float*, const uint8_t*, NlkGeom, NlkGTile,
                const uint32_t*, const NlkTarget*, const uint32_t*, const uint8_t*, const float*,
@@ -733,3 +733,12 @@ int nlk_ctx_read_records(nlk_ctx* c, int* ngrid, int* kmax, int* gmax, unsigned 
 }
 
 }  // extern "C"
+
+#if NLK_EXP == 4
+extern "C" int nlk_debug_read(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(nlk_dbg), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(nlk_dbg), z, sizeof z); }
+  return 0;
+}
+#endif
