@@ -32,15 +32,6 @@
 #include "nlk_common.h"
 #include "k_group8.h"
 #include <type_traits>
-#ifndef NLK_EXP
-#define NLK_EXP 0
-#endif
-#if NLK_EXP == 4
-__device__ unsigned long long nlk_dbg[8];
-#define NLK_T(i) { const unsigned long long _t = clock64(); dbg[i] += _t - tlast; tlast = _t; }
-#else
-#define NLK_T(i)
-#endif
 
 typedef float nlk_f4 __attribute__((ext_vector_type(4)));
 
@@ -56,10 +47,12 @@ __device__ __forceinline__ uint32_t nlk_bperm_u(uint32_t v, int src_lane) {
 // divergent control flow would make the compiler wait for every load in flight).
 __device__ __forceinline__ void nlk_rows_load(const float* __restrict__ p, int w, int g4,
                                               float (&R)[16]) {
-  const nlk_f4u a0 = *reinterpret_cast<const nlk_f4u*>(p + g4 * w);
-  const nlk_f4u a1 = *reinterpret_cast<const nlk_f4u*>(p + g4 * w + 4);
-  const nlk_f4u b0 = *reinterpret_cast<const nlk_f4u*>(p + (7 - g4) * w);
-  const nlk_f4u b1 = *reinterpret_cast<const nlk_f4u*>(p + (7 - g4) * w + 4);
+  // (explicit global address space: a pointer selected at run time would otherwise be
+  // loaded with flat instructions, which also count on the LDS counter)
+  typedef const __attribute__((address_space(1))) nlk_f4u* gp4;
+  const float* ra = p + g4 * w;
+  const float* rb = p + (7 - g4) * w;
+  const nlk_f4u a0 = *(gp4)(ra), a1 = *(gp4)(ra + 4), b0 = *(gp4)(rb), b1 = *(gp4)(rb + 4);
 #pragma unroll
   for (int c = 0; c < 4; ++c) { R[c] = a0[c]; R[4 + c] = a1[c]; R[8 + c] = b0[c]; R[12 + c] = b1[c]; }
 }
@@ -147,6 +140,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   const size_t npix = (size_t)g.w * g.h;
   float* acc_p = acc + (size_t)(agg_on ? g4 : 0) * npix;
   const float* src = g.have_basic ? cur : img;  // patches that get filtered
+  const ptrdiff_t prev_off = prev ? prev - img : 0;  // (an offset, not a second base pointer, keeps the loads global)
   const float s2 = g.sigma2;
   // pass-B role of the lane as a load slot: channel / member of slot lo
   const int bch = lo >> 2, bm = lo & 3;
@@ -162,19 +156,10 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     rec_vb[0] = (uint32_t)info.vbits[0]; rec_vb[1] = (uint32_t)(info.vbits[0] >> 32);
     rec_vb[2] = (uint32_t)info.vbits[1]; rec_vb[3] = (uint32_t)(info.vbits[1] >> 32);
   }
-
-#if NLK_EXP == 4
-  unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
-  const unsigned long long tstart = tlast;
-#endif
-  NLK_T(5)
   for (int tt = 0; tt < cx * cy; ++tt) {
     if (!__builtin_amdgcn_readlane(rec_act, tt)) continue;
     const int nagg = __builtin_amdgcn_readlane(rec_nagg, tt);
     if (nagg == 0) continue;
-#if NLK_EXP == 4
-    dbg[6] += 1;
-#endif
     const int ty = tt / cx, tx = tt - ty * cx;
     const size_t t = (size_t)(gy0 + ty) * g.ngx + gx0 + tx;
     const int k = __builtin_amdgcn_readlane(rec_nsel, tt);
@@ -224,7 +209,6 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       for (int q = 0; q < 4; ++q) S[a][q] = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) x0[q] = 0.f;
-    NLK_T(0)
     // two copies of the loop (with / without previous-frame patches).
     // Load schedule: the rows of step it+1 are requested right after those of step it
     // were folded and the address of step it+2 is prepared, so every request has a
@@ -246,7 +230,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         const uint32_t qc = nlk_bperm_u(cl < 64 ? qreg[0] : qreg[1], cl & 63);
         const int o = nlk_y(qc) * g.w + nlk_x(qc);
         const bool usep = slot_prev && ci < k && (((ci < 64 ? vbits[0] : vbits[1]) >> (ci & 63)) & 1ull);
-        return (usep ? prev : img) + cc * npix + o;
+        return img + (usep ? prev_off : (ptrdiff_t)0) + cc * npix + o;
       };
       auto next_job = [&](int bb, int cc, int& ob, int& oc) {
         ob = bb + 1; oc = cc;
@@ -313,7 +297,6 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
           }
         }
         if (b == nb - 1) {
-          NLK_T(1)
           // the channel is complete: candidates are spread over the four lane groups
 #pragma unroll
           for (int a = 0; a < (HP ? 6 : 2); ++a)
@@ -333,20 +316,20 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
             const float v01n = S[4][q] * in0;
             float a, term, m;
             if (SMO) {
-              a = v1 / (v1 + g.beta_t * v01n);
+              a = v1 * __builtin_amdgcn_rcpf(v1 + g.beta_t * v01n);
               const float pv = v0 - g.beta_t * v01n;
               term = (1 - a * a) * v1 + a * a * (pv > 0.f ? pv : 0.f);
               m = 0.f;
             } else if (HP) {
               const float d = v01n - (g.have_basic ? 0.f : s2);
               const float v = v0 + (0.f > d ? 0.f : d);
-              a = v / (v + g.beta_t * s2);
+              a = v * __builtin_amdgcn_rcpf(v + g.beta_t * s2);
               term = (1 - a * a) * v + a * a * s2;
               m = x0[q] + S[5][q] * ing;
             } else {
               const float d = v1 - (g.have_basic ? 0.f : s2);
               const float v = 0.f > d ? 0.f : d;
-              a = v / (v + g.beta_x * s2);
+              a = v * __builtin_amdgcn_rcpf(v + g.beta_x * s2);
               term = a * v;
               m = mean1;
             }
@@ -364,7 +347,6 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
             for (int q = 0; q < 4; ++q) S[a][q] = 0.f;
 #pragma unroll
           for (int q = 0; q < 4; ++q) x0[q] = 0.f;
-          NLK_T(2)
         }
         b = b1; ch = ch1; b1 = b2; ch1 = ch2;
       }
@@ -398,7 +380,6 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     for (int kk = 0; kk < 4; ++kk) ww[kk] = wgt * win[kk];
     const float* st_g = stash + (bchc * 2 + 0) * 64 + 4 * g4;  // + 16*q: gains of coefficients 4*g4 .. 4*g4+3
     const float* st_m = stash + (bchc * 2 + 1) * 64 + 4 * g4;
-    NLK_T(3)
     for (int n0 = 0; n0 < nagg; n0 += 4) {
       nlk_f4 Y[4], Z[4];
       nlk_fold(R, F);
@@ -476,7 +457,6 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         }
       }
     }
-    NLK_T(4)
   }
 
   // ---------------- flush the tile accumulator (coalesced rows, skip untouched)
@@ -497,10 +477,4 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         }
     }
   }
-#if NLK_EXP == 4
-  NLK_T(5)
-  dbg[7] = tlast - tstart;
-  if (lane == 0)
-    for (int i = 0; i < 8; ++i) atomicAdd(&nlk_dbg[i], dbg[i]);
-#endif
 }

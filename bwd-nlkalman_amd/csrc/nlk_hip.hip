@@ -734,11 +734,3 @@ int nlk_ctx_read_records(nlk_ctx* c, int* ngrid, int* kmax, int* gmax, unsigned 
 
 }  // extern "C"
 
-#if NLK_EXP == 4
-extern "C" int nlk_debug_read(unsigned long long* out, int reset) {
-  hipDeviceSynchronize();
-  hipMemcpyFromSymbol(out, HIP_SYMBOL(nlk_dbg), sizeof(unsigned long long) * 8);
-  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(nlk_dbg), z, sizeof z); }
-  return 0;
-}
-#endif
