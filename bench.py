@@ -34,7 +34,7 @@ WORKLOADS = {
     "C5": (1920, 1080, 3, 20.0, 8, 1),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
-VALU_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: peak FP32 vector
+MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense f32 MFMA peak (= the f32 vector peak)
 
 
 def cpu_baseline(O, o1, prev, sigma, p):
@@ -170,31 +170,47 @@ def main():
         ms = dt / args.steps * 1e3
         value = w * h / (dt / args.steps) / 1e6
         out = t_out.cpu().numpy()
-        # dominant kernel and its roofline; algorithmic bytes and flops: DESIGN.md §5
+        # dominant kernel and its roofline; algorithmic bytes and flops: DESIGN.md §5.
+        # The group kernel runs its DCTs on the f32 matrix cores and everything else on the
+        # f32 vector ALU, which share one FP32 datapath on gfx950 (tools/ubench/mfma_valu.hip):
+        # it is priced against the dense f32 MFMA peak. Algorithmic flops per launch =
+        # 2 * 8^3 MACs per 8x8 patch transform (row-column matrix form) x the transforms the
+        # path needs: per processed target (nsel image + nsel previous-frame patches when it
+        # has any + 2 * nagg for the members' forward and inverse) x channels; the counts are
+        # read from the last launch's records (single GPU; strips: the 70 % of the C2 frame).
         k, ngrid = p.npatches_t, ngx * ngy
         alg_bytes = {"match": w * h * ch * 4 + ngrid * k * 4,
                      "group": 2 * w * h * ch * 4 + (ch + 1) * w * h * 4 + ngrid * k * 4}
-        alg_flops = {"match": ngrid * (121 * 192 * 3), "group": ngrid * 0.70 * 0.60e6}
+        if world == 1:
+            rec = ctx.read_records()
+            act = rec["active"].astype(bool) & (rec["nagg"] > 0)
+            ntr = (rec["nsel"] * (1 + (rec["np0"] > 0)) + 2 * rec["nagg"])[act].sum()
+            group_flops = float(ntr) * ch * 2 * 2 * 8 ** 3
+        else:
+            group_flops = ngrid * 0.70 * 0.60e6
+        alg_flops = {"match": ngrid * (121 * 192 * 3), "group": group_flops}
         dom = "group" if tm["group_ms"] >= tm["match_ms"] else "match"
         dur = tm[dom + "_ms"] * 1e-3
         gbs = alg_bytes[dom] / world / dur / 1e9 if dur > 0 else 0.0
         tfl = alg_flops[dom] / world / dur / 1e12 if dur > 0 else 0.0
-        kname = "k_group8" if dom == "group" else "k_bm_topk"
+        kname = "k_group8m" if dom == "group" else "k_bm_topk"
         # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE in separate runs, tools/pmc_run.sh); valid for the single-GPU C2 launch only
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if world == 1 and args.workload == "C2" and os.path.exists(tpath):
             traffic = json.load(open(tpath))["kernels"].get(kname, {}).get("traffic_bytes")
-        roof = {"kernel": kname, "bound": "hbm",
-                "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
+        roof = {"kernel": kname, "bound": "mfma",
+                "achieved": round(tfl, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                 "launch_ms": round(tm[dom + "_ms"], 4),
+                "algorithmic_flops_per_launch": int(alg_flops[dom] / world),
                 "algorithmic_bytes_per_launch": alg_bytes[dom] // world,
-                "valu": {"achieved": round(tfl, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tfl / VALU_PEAK_TFLOPS, 4)},
-                "note": "the path does ~1e3 flop per algorithmic byte: it is bound by f32 VALU "
-                        "issue + LDS, not by HBM (DESIGN.md §5); traffic: see profiles/"}
+                "hbm": {"achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 6)},
+                "note": "~550 flop per algorithmic byte: compute bound. f32 MFMA and f32 VALU share "
+                        "the FP32 datapath on gfx950 (no co-issue gain measured), so the bound is "
+                        "32 cycles per MFMA + 4 per VALU instruction: see DESIGN.md §5"}
         res = {"metric": "Mpix/s per frame (nlkalman-flt, 1080p sigma=20)"
                if args.workload == "C2" else f"Mpix/s per frame (nlkalman-flt, {args.workload})",
                "value": round(value, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,

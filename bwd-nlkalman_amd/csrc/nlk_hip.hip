@@ -159,14 +159,16 @@ template <int PSZ, int CH, bool SMO>
 int launch_group_fast_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
                         const float* prev, float* acc, const uint8_t* active) {
   NlkGTile tl{};
-  // 4 x 1 targets per wavefront measured best (profiles/README.md); NLK_GTX/NLK_GTY override for experiments
-  tl.tgx = getenv("NLK_GTX") ? atoi(getenv("NLK_GTX")) : 4;
-  tl.tgy = getenv("NLK_GTY") ? atoi(getenv("NLK_GTY")) : 1;
-  tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
-  tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
   // LDS tile halo = reach of the dominant kind of group; the rare spatial-branch
   // groups of a temporal frame that reach further fall back to HBM atomics
   tl.wmax = (g.smoother || g.have_prev) ? g.wsz_t : g.wsz_x;
+  // 4 x 1 targets per wavefront measured best for the temporal radius (profiles/README.md);
+  // with a wide halo the tile would leave LDS room for ~1 wavefront per SIMD: 2 x 1 then.
+  // NLK_GTX/NLK_GTY override for experiments
+  tl.tgx = getenv("NLK_GTX") ? atoi(getenv("NLK_GTX")) : (PSZ == 8 && tl.wmax > 6 ? 2 : 4);
+  tl.tgy = getenv("NLK_GTY") ? atoi(getenv("NLK_GTY")) : 1;
+  tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
+  tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
   // psz 8 runs its DCTs on the matrix cores (k_group8m.h); NLK_GROUP_DPP selects the
   // register/DPP kernel (k_group8.h) for comparison
   const bool mfma = PSZ == 8 && !getenv("NLK_GROUP_DPP");

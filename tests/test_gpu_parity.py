@@ -369,6 +369,34 @@ def test_full_size_1080p_against_oracle(ctx, built, O, synth):
     assert np.quantile(np.abs(g2[..., 1:] - g[..., 1:]), 0.9999) < 2e-2
 
 
+def test_group_kernels_agree_matrix_vs_dpp(ctx, built, synth, monkeypatch):
+    """The 8x8 group kernel has two implementations: k_group8m (DCTs on the f32
+    matrix cores, the default) and k_group8 (registers + DPP, NLK_GROUP_DPP=1).
+    Same records, same formulas, different summation orders: all four frame calls
+    must agree to FP noise (and neither is a fallback of the other: both run HIP)."""
+    w, h, ch, sigma = 320, 200, 3, 20.0
+    n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, 5)
+    o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+    p1, p2, p3 = (built.default_params(sigma, m) for m in (built.FLT1, built.FLT2, built.SMO1))
+
+    def chain():
+        f0, _ = _dev_frame(ctx, False, o0, None, None, sigma, p1)
+        hole = f0.copy()
+        hole[40:70, 100:160] = np.nan                      # spatial-fallback targets
+        f1, _ = _dev_frame(ctx, False, o1, hole, None, sigma, p1)
+        f2, _ = _dev_frame(ctx, False, o1, hole, f1, sigma, p2)
+        s0, _ = _dev_frame(ctx, True, f0, f2, None, sigma, p3)
+        return f0, f1, f2, s0
+
+    monkeypatch.delenv("NLK_GROUP_DPP", raising=False)
+    a = chain()
+    monkeypatch.setenv("NLK_GROUP_DPP", "1")
+    b = chain()
+    for name, x, y in zip(("flt1 spatial", "flt1 temporal", "flt2", "smo1"), a, b):
+        assert np.isfinite(x).all() and np.isfinite(y).all()
+        cases.assert_close(x, y, f"matrix vs DPP group kernel, {name}")
+
+
 def test_4k_patch12_against_parallel_oracle(ctx, built, O, synth):
     """BASELINE.json configs[2] geometry (3840x2160 RGB, sigma 40, 12x12 patches),
     temporal FLT1. With step 6 > temporal radius 5 a group never reaches another
