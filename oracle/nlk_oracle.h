@@ -52,4 +52,22 @@ void nlko_strip_group(float *acc, const unsigned char *active, const float *cur,
                       const float *prev, const float *basic, int w, int h, int ch,
                       float sigma, const nlko_params *P, int oy, int ngy, int smoother);
 int nlko_max_threads(void);
+
+/* ---- dual TV-L1 optical flow + occlusion mask (tvl1_oracle.c; reference: lib/tvl1flow/) */
+float tvl1o_bicubic_at(const float *im, float uu, float vv, int nx, int ny, int border_out);
+void tvl1o_forward_gradient(const float *f, float *fx, float *fy, int nx, int ny);
+void tvl1o_centered_gradient(const float *f, float *dx, float *dy, int nx, int ny);
+void tvl1o_divergence(const float *v1, const float *v2, float *div, int nx, int ny);
+void tvl1o_gaussian(float *im, int nx, int ny, double sigma);
+void tvl1o_zoom_size(int nx, int ny, int *nxx, int *nyy, float factor);
+void tvl1o_zoom_out(const float *im, float *out, int nx, int ny, float factor);
+void tvl1o_zoom_in(const float *im, float *out, int nx, int ny, int nxx, int nyy);
+int tvl1o_flow_scale(const float *I0, const float *I1, float *u1, float *u2, int nx, int ny,
+                     float tau, float lambda, float theta, int warps, float epsilon, int *iters_out);
+void tvl1o_normalize(const float *I0, const float *I1, float *o0, float *o1, int n);
+int tvl1o_auto_scales(int nx, int ny, int nscales, float zfactor);
+void tvl1o_flow(const float *I0, const float *I1, float *u1, float *u2, int nx, int ny, float tau,
+                float lambda, float theta, int nscales, int fscale, float zfactor, int warps,
+                float epsilon);
+void tvl1o_occlusion_mask(const float *flow, float *mask, int nx, int ny, float th);
 #endif

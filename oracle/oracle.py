@@ -39,7 +39,7 @@ class Trace(C.Structure):
 def build():
     """Compile oracle/libnlk_oracle.so if missing or stale."""
     so = os.path.join(_HERE, "libnlk_oracle.so")
-    src = [os.path.join(_HERE, f) for f in ("nlk_oracle.c", "nlk_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("nlk_oracle.c", "tvl1_oracle.c", "nlk_oracle.h")]
     if (not os.path.exists(so)
             or os.path.getmtime(so) < max(os.path.getmtime(s) for s in src)):
         subprocess.check_call(["make", "-C", _HERE, "libnlk_oracle.so"],
@@ -73,6 +73,23 @@ def lib():
         L.nlko_strip_group.argtypes = [fp, u8p, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float,
                                        C.POINTER(Params), C.c_int, C.c_int, C.c_int]
         L.nlko_max_threads.restype = C.c_int
+        i, f = C.c_int, C.c_float
+        L.tvl1o_bicubic_at.argtypes = [fp, f, f, i, i, i]
+        L.tvl1o_bicubic_at.restype = f
+        L.tvl1o_forward_gradient.argtypes = [fp, fp, fp, i, i]
+        L.tvl1o_centered_gradient.argtypes = [fp, fp, fp, i, i]
+        L.tvl1o_divergence.argtypes = [fp, fp, fp, i, i]
+        L.tvl1o_gaussian.argtypes = [fp, i, i, C.c_double]
+        L.tvl1o_zoom_size.argtypes = [i, i, C.POINTER(i), C.POINTER(i), f]
+        L.tvl1o_zoom_out.argtypes = [fp, fp, i, i, f]
+        L.tvl1o_zoom_in.argtypes = [fp, fp, i, i, i, i]
+        L.tvl1o_flow_scale.argtypes = [fp, fp, fp, fp, i, i, f, f, f, i, f, C.POINTER(i)]
+        L.tvl1o_flow_scale.restype = i
+        L.tvl1o_normalize.argtypes = [fp, fp, fp, fp, i]
+        L.tvl1o_auto_scales.argtypes = [i, i, i, f]
+        L.tvl1o_auto_scales.restype = i
+        L.tvl1o_flow.argtypes = [fp, fp, fp, fp, i, i, f, f, f, i, i, f, i, f]
+        L.tvl1o_occlusion_mask.argtypes = [fp, fp, i, i, f]
         _LIB = L
     return _LIB
 
@@ -239,3 +256,36 @@ def strip_group(acc, active, cur, prev, basic, sigma, params, oy, ngy, smoother=
 
 def max_threads():
     return lib().nlko_max_threads()
+
+
+# ---- dual TV-L1 optical flow (tvl1_oracle.c; reference: lib/tvl1flow/)
+TVL1_DEFAULTS = dict(tau=0.25, lam=0.15, theta=0.3, nscales=100, fscale=0, zfactor=0.5,
+                     nwarps=5, epsilon=0.01)  # reference: lib/tvl1flow/main.c:26-35
+
+
+def tvl1_auto_scales(w, h, nscales=100, zfactor=0.5):
+    return lib().tvl1o_auto_scales(w, h, nscales, zfactor)
+
+
+def tvl1_flow(i0, i1, **kw):
+    """Flow from gray image i0 to i1 (h, w float32) -> (u, v), parameters as the
+    reference's command line (the number of scales is capped by the image size)."""
+    p = dict(TVL1_DEFAULTS, **kw)
+    i0 = np.ascontiguousarray(i0, np.float32)
+    i1 = np.ascontiguousarray(i1, np.float32)
+    h, w = i0.shape
+    ns = tvl1_auto_scales(w, h, p["nscales"], p["zfactor"])
+    fs = min(p["fscale"], ns)
+    u, v = np.zeros((h, w), np.float32), np.zeros((h, w), np.float32)
+    lib().tvl1o_flow(_fp(i0), _fp(i1), _fp(u), _fp(v), w, h, p["tau"], p["lam"], p["theta"], ns, fs,
+                     p["zfactor"], p["nwarps"], p["epsilon"])
+    return u, v
+
+
+def tvl1_occlusion_mask(flow, th):
+    """flow (h, w, 2) -> mask (h, w) of 0 / 255 (|divergence| > th)."""
+    flow = np.ascontiguousarray(flow, np.float32)
+    h, w, _ = flow.shape
+    m = np.zeros((h, w), np.float32)
+    lib().tvl1o_occlusion_mask(_fp(flow), _fp(m), w, h, th)
+    return m
