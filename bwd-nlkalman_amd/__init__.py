@@ -28,11 +28,20 @@ HIP_SYMBOLS = [
     "nlk_dev_warp_bicubic", "nlk_dev_filter_frame", "nlk_dev_smooth_frame",
     "nlk_dev_frame_accumulate", "nlk_dev_frame_normalize", "nlk_ctx_read_records",
     "nlk_dev_strip_match", "nlk_dev_mask_commit", "nlk_dev_strip_group",
+    "nlk_tvl1_default_params", "nlk_tvl1_scales", "nlk_dev_tvl1_flow", "nlk_dev_gray",
+    "nlk_dev_occlusion_mask",
 ]
 API_SYMBOLS = [
     "rgb2opp", "opp2rgb", "warp_bicubic", "nlkalman_default_params",
     "nlkalman_filter_frame", "nlkalman_smooth_frame",
 ]
+
+
+class Tvl1Params(C.Structure):
+    """struct nlk_tvl1_params (include/nlk_hip.h; reference: lib/tvl1flow/main.c:26-35)."""
+    _fields_ = [("tau", C.c_float), ("lam", C.c_float), ("theta", C.c_float),
+                ("nscales", C.c_int), ("fscale", C.c_int), ("zfactor", C.c_float),
+                ("nwarps", C.c_int), ("epsilon", C.c_float)]
 
 
 class Params(C.Structure):
@@ -110,6 +119,12 @@ def hip():
         L.nlk_dev_strip_group.argtypes = [vp, fp, vp]
         L.nlk_ctx_read_records.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i),
                                            vp, vp, vp, vp, vp, vp]
+        L.nlk_tvl1_default_params.argtypes = [C.POINTER(Tvl1Params)]
+        L.nlk_tvl1_default_params.restype = None
+        L.nlk_tvl1_scales.argtypes = [i, i, i, f]
+        L.nlk_dev_tvl1_flow.argtypes = [vp, fp, fp, fp, i, i, C.POINTER(Tvl1Params), C.POINTER(i)]
+        L.nlk_dev_gray.argtypes = [vp, fp, fp, i, i, i]
+        L.nlk_dev_occlusion_mask.argtypes = [vp, fp, fp, i, i, f]
         _hip = L
     return _hip
 
@@ -151,6 +166,18 @@ def _img(a):
 
 
 # ---------------------------------------------------------------- drop-in API
+
+def tvl1_params(w, h, **over):
+    """nlk_tvl1_default_params + the scale count the reference's command line would use
+    for a w x h image (fields may be overridden, e.g. lam=0.4, fscale=1)."""
+    p = Tvl1Params()
+    hip().nlk_tvl1_default_params(C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    p.nscales = hip().nlk_tvl1_scales(w, h, p.nscales, p.zfactor)
+    p.fscale = min(p.fscale, p.nscales)
+    return p
+
 
 def default_params(sigma, mode, **over):
     """nlkalman_default_params (reference: src/nlkalman.c:426-487); host-only."""
@@ -278,6 +305,19 @@ class Context:
     def smooth_frame(self, d_out, d_filt, d_prev, d_basic, w, h, ch, sigma, params):
         self._chk(self.L.nlk_dev_smooth_frame(self.h, d_out, d_filt, d_prev, d_basic, w, h,
                                               ch, float(sigma), C.byref(params)))
+
+    def tvl1_flow(self, d_flow, d_i0, d_i1, w, h, params):
+        """Flow I0 -> I1 into d_flow (w*h interleaved pairs); returns the iteration count."""
+        it = C.c_int()
+        self._chk(self.L.nlk_dev_tvl1_flow(self.h, d_flow, d_i0, d_i1, w, h, C.byref(params),
+                                           C.byref(it)))
+        return it.value
+
+    def gray(self, d_gray, d_im, w, h, ch):
+        self._chk(self.L.nlk_dev_gray(self.h, d_gray, d_im, w, h, ch))
+
+    def occlusion_mask(self, d_mask, d_flow, w, h, th):
+        self._chk(self.L.nlk_dev_occlusion_mask(self.h, d_mask, d_flow, w, h, float(th)))
 
     def frame_accumulate(self, d_acc, d_cur, d_prev, d_basic, w, h, ch, sigma, params, oy,
                          ngy, smoother=False):

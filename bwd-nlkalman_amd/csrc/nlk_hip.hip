@@ -19,6 +19,7 @@
 #include "k_group8m.h"
 #include "k_group12.h"
 #include "k_match.h"
+#include "k_tvl1.h"
 #include "nlk_common.h"
 
 namespace {
@@ -38,6 +39,8 @@ struct nlk_ctx {
   hipStream_t stream = nullptr;
   char err[512] = "";
   Buf pl_cur, pl_prev, pl_basic, rowok, vmap, topk, tinfo, gcoords, marks, active, acc, tabs, wide;
+  Buf tv;                         // TV-L1 pyramids and work images
+  NlkTvState* tv_host = nullptr;  // pinned: the solver state read back between iteration batches
   int tabs_psz = 0;
   NlkGeom last{};
   bool have_last = false;
@@ -334,9 +337,10 @@ void nlk_ctx_destroy(nlk_ctx* c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   Buf* bufs[] = {&c->pl_cur, &c->pl_prev, &c->pl_basic, &c->rowok, &c->vmap, &c->topk,
-                 &c->tinfo, &c->gcoords, &c->marks, &c->active, &c->acc, &c->tabs};
+                 &c->tinfo, &c->gcoords, &c->marks, &c->active, &c->acc, &c->tabs, &c->wide, &c->tv};
   for (Buf* b : bufs)
     if (b->p) hipFree(b->p);
+  if (c->tv_host) (void)hipHostFree(c->tv_host);
   if (c->ev) {
     for (int i = 0; i < nlk_ctx::MAXSETS * nlk_ctx::NEV; ++i) (void)hipEventDestroy(c->ev[i]);
     free(c->ev);
@@ -736,3 +740,4 @@ int nlk_ctx_read_records(nlk_ctx* c, int* ngrid, int* kmax, int* gmax, unsigned 
 
 }  // extern "C"
 
+#include "tvl1_host.h"

@@ -1,0 +1,194 @@
+// tvl1_host.h — host side of the TV-L1 optical flow entry points of include/nlk_hip.h
+// (included by nlk_hip.hip; kernels: k_tvl1.h). Reference: lib/tvl1flow/tvl1flow_lib.c:345-474
+// (multiscale driver), :93-275 (one scale), main.c:26-35, 152-157 (defaults, scale count).
+#pragma once
+
+namespace {
+
+// normalised half kernel, exactly as the reference computes it (mask.c:229-256)
+int tv_gauss_kernel(nlk_ctx* c, double sigma, int nx, int ny, NlkTvGauss* g) {
+  const int rad = (int)(5 * sigma) + 1;
+  if (rad > 32) return fail(c, NLK_EUNSUP, "TV-L1: Gaussian sigma %.3f too large (radius %d > 32)", sigma, rad);
+  if (rad > nx || rad > ny)
+    return fail(c, NLK_EUNSUP, "TV-L1: a %dx%d pyramid level is smaller than the Gaussian radius %d", nx, ny, rad);
+  const double den = 2 * sigma * sigma;
+  for (int i = 0; i < rad; ++i) g->b[i] = 1 / (sigma * sqrt(2.0 * 3.1415926)) * exp(-i * i / den);
+  double norm = 0;
+  for (int i = 0; i < rad; ++i) norm += g->b[i];
+  norm *= 2;
+  norm -= g->b[0];
+  for (int i = 0; i < rad; ++i) g->b[i] /= norm;
+  g->rad = rad;
+  return NLK_OK;
+}
+
+inline dim3 tv_grid(int nx, int ny) { return dim3((nx + 31) / 32, (ny + 7) / 8); }
+const dim3 tv_block(32, 8);
+
+// in -> out (may alias), tmp = scratch of the same size
+int tv_gaussian(nlk_ctx* c, const float* in, float* out, float* tmp, int nx, int ny, double sigma) {
+  NlkTvGauss g;
+  int rc = tv_gauss_kernel(c, sigma, nx, ny, &g);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_tv_gauss, tv_grid(nx, ny), tv_block, 0, c->stream, in, tmp, nx, ny, g, 0);
+  hipLaunchKernelGGL(k_tv_gauss, tv_grid(nx, ny), tv_block, 0, c->stream, (const float*)tmp, out, nx,
+                     ny, g, 1);
+  HIPCHK(c, hipGetLastError());
+  return NLK_OK;
+}
+
+// one scale (reference: tvl1flow_lib.c:93-275)
+int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2, int nx, int ny,
+             const nlk_tvl1_params& P, float* work, float* part, NlkTvState* st, NlkTvState* host_st,
+             int* iters_total) {
+  const size_t n = (size_t)nx * ny;
+  float *I1x = work, *I1y = I1x + n, *I1wx = I1y + n, *I1wy = I1wx + n, *grad = I1wy + n;
+  float *rho_c = grad + n, *p11 = rho_c + n, *p12 = p11 + n, *p21 = p12 + n, *p22 = p21 + n;
+  const dim3 grid = tv_grid(nx, ny);
+  const int nparts = grid.x * grid.y;
+  const float l_t = P.lambda * P.theta, taut = P.tau / P.theta, eps2 = P.epsilon * P.epsilon;
+  hipLaunchKernelGGL(k_tv_centered_grad, grid, tv_block, 0, c->stream, I1, I1x, I1y, nx, ny);
+  HIPCHK(c, hipMemsetAsync(p11, 0, sizeof(float) * n * 4, c->stream));
+  for (int wi = 0; wi < P.nwarps; ++wi) {
+    hipLaunchKernelGGL(k_tv_warp, grid, tv_block, 0, c->stream, I0, I1, (const float*)I1x,
+                       (const float*)I1y, (const float*)u1, (const float*)u2, I1wx, I1wy, grad, rho_c, nx,
+                       ny);
+    hipLaunchKernelGGL(k_tv_reset, dim3(1), dim3(1), 0, c->stream, st);
+    // the loop's exit test lives on the device (k_tv_dual); the host launches iterations in
+    // batches and looks at the state between them, so no launch waits for a read-back
+    int launched = 0;
+    const int batch = getenv("NLK_TV_BATCH") ? atoi(getenv("NLK_TV_BATCH")) : 12;
+    while (launched < NLK_TV_MAXIT) {
+      const int upto = launched + batch < NLK_TV_MAXIT ? launched + batch : NLK_TV_MAXIT;
+      for (int it = launched + 1; it <= upto; ++it) {
+        hipLaunchKernelGGL(k_tv_primal, grid, dim3(256), 0, c->stream, (const float*)rho_c,
+                           (const float*)I1wx, (const float*)I1wy, (const float*)grad, u1, u2,
+                           (const float*)p11, (const float*)p12, (const float*)p21, (const float*)p22, part,
+                           (const NlkTvState*)st, it, nx, ny, l_t, P.theta);
+        hipLaunchKernelGGL(k_tv_dual, grid, dim3(256), 0, c->stream, (const float*)u1, (const float*)u2,
+                           p11, p12, p21, p22, (const float*)part, nparts, st, it, nx, ny, taut, eps2);
+      }
+      launched = upto;
+      HIPCHK(c, hipMemcpyAsync(host_st, st, sizeof(NlkTvState), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (host_st->stop_iter < NLK_TV_MAXIT || host_st->iters >= NLK_TV_MAXIT) break;
+    }
+    if (iters_total) *iters_total += host_st->iters;
+  }
+  HIPCHK(c, hipGetLastError());
+  return NLK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void nlk_tvl1_default_params(struct nlk_tvl1_params* p) {  // reference: lib/tvl1flow/main.c:26-35
+  p->tau = 0.25f; p->lambda = 0.15f; p->theta = 0.3f;
+  p->nscales = 100; p->fscale = 0; p->zfactor = 0.5f;
+  p->nwarps = 5; p->epsilon = 0.01f;
+}
+
+int nlk_tvl1_scales(int w, int h, int nscales, float zfactor) {  // reference: main.c:152-157
+  const float N = 1 + log(hypot(w, h) / 16.0) / log(1 / zfactor);
+  return N < nscales ? (int)N : nscales;
+}
+
+int nlk_dev_gray(nlk_ctx* c, float* gray, const float* im, int w, int h, int ch) {
+  if (!c || !gray || !im || w <= 0 || h <= 0 || ch <= 0) return fail(c, NLK_EINVAL, "nlk_dev_gray: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int n = w * h;
+  hipLaunchKernelGGL(k_tv_gray, dim3((n + 255) / 256), dim3(256), 0, c->stream, im, gray, n, ch);
+  HIPCHK(c, hipGetLastError());
+  return NLK_OK;
+}
+
+int nlk_dev_occlusion_mask(nlk_ctx* c, float* mask, const float* flow, int w, int h, float th) {
+  if (!c || !mask || !flow || w <= 0 || h <= 0) return fail(c, NLK_EINVAL, "nlk_dev_occlusion_mask: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_tv_occlusion, tv_grid(w, h), tv_block, 0, c->stream, flow, mask, w, h, th);
+  HIPCHK(c, hipGetLastError());
+  return NLK_OK;
+}
+
+int nlk_dev_tvl1_flow(nlk_ctx* c, float* flow, const float* I0, const float* I1, int w, int h,
+                      const struct nlk_tvl1_params* P, int* iterations) {
+  if (!c || !flow || !I0 || !I1 || !P) return fail(c, NLK_EINVAL, "nlk_dev_tvl1_flow: null argument");
+  if (w < 2 || h < 2) return fail(c, NLK_EINVAL, "nlk_dev_tvl1_flow: %dx%d image", w, h);
+  if (!(P->tau > 0) || !(P->lambda > 0) || !(P->theta > 0) || !(P->zfactor > 0 && P->zfactor < 1) ||
+      P->nscales < 1 || P->nscales > 64 || P->fscale < 0 || P->nwarps < 1 || !(P->epsilon > 0))
+    return fail(c, NLK_EINVAL, "nlk_dev_tvl1_flow: parameter out of range");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int ns = P->nscales;
+  int W[64], H[64];
+  W[0] = w; H[0] = h;
+  size_t pyr = (size_t)w * h;
+  for (int s = 1; s < ns; ++s) {  // reference: zoom.c:23-35
+    W[s] = (int)((float)W[s - 1] * P->zfactor + 0.5);
+    H[s] = (int)((float)H[s - 1] * P->zfactor + 0.5);
+    if (W[s] < 2 || H[s] < 2) return fail(c, NLK_EINVAL, "nlk_dev_tvl1_flow: %d scales leave a %dx%d level", ns, W[s], H[s]);
+    pyr += (size_t)W[s] * H[s];
+  }
+  const size_t n0 = (size_t)w * h;
+  const dim3 g0 = tv_grid(w, h);
+  // scratch: 4 pyramids (I0, I1, u1, u2) + 10 work images + 2 temporaries at full size + partial sums
+  const size_t floats = 4 * pyr + 12 * n0 + (size_t)g0.x * g0.y + 64;
+  int rc = reserve(c, c->tv, sizeof(float) * floats);
+  if (rc) return rc;
+  if (!c->tv_host) HIPCHK(c, hipHostMalloc((void**)&c->tv_host, sizeof(NlkTvState)));
+  float* base = (float*)c->tv.p;
+  float *I0s[64], *I1s[64], *U1[64], *U2[64];
+  float* q = base;
+  for (int s = 0; s < ns; ++s) {
+    const size_t n = (size_t)W[s] * H[s];
+    I0s[s] = q; q += n; I1s[s] = q; q += n; U1[s] = q; q += n; U2[s] = q; q += n;
+  }
+  float* work = q; q += 10 * n0;
+  float* tmp = q; q += n0;
+  float* tmp2 = q; q += n0;
+  float* part = q; q += (size_t)g0.x * g0.y;
+  NlkTvState* st = (NlkTvState*)q;  // 64 floats reserved
+  int* mm = (int*)(q + 8);
+
+  // normalise both images to 0..255 with one common range, pre-smooth (reference: :376-381)
+  hipLaunchKernelGGL(k_tv_init_minmax, dim3(1), dim3(1), 0, c->stream, mm);
+  hipLaunchKernelGGL(k_tv_minmax, dim3(1024), dim3(256), 0, c->stream, I0, I1, (int)n0, mm);
+  hipLaunchKernelGGL(k_tv_normalize, dim3((n0 + 255) / 256), dim3(256), 0, c->stream, I0, I1, I0s[0],
+                     I1s[0], (int)n0, (const int*)mm);
+  if ((rc = tv_gaussian(c, I0s[0], I0s[0], tmp, w, h, 0.8))) return rc;
+  if ((rc = tv_gaussian(c, I1s[0], I1s[0], tmp, w, h, 0.8))) return rc;
+  // pyramid (reference: :384-398, zoom.c:44-79)
+  const float zsigma = 0.6 * sqrt(1.0 / (P->zfactor * P->zfactor) - 1.0);
+  for (int s = 1; s < ns; ++s)
+    for (int k = 0; k < 2; ++k) {
+      const float* src = k ? I1s[s - 1] : I0s[s - 1];
+      float* dst = k ? I1s[s] : I0s[s];
+      if ((rc = tv_gaussian(c, src, tmp2, tmp, W[s - 1], H[s - 1], zsigma))) return rc;
+      hipLaunchKernelGGL(k_tv_zoom, tv_grid(W[s], H[s]), tv_block, 0, c->stream, (const float*)tmp2, dst,
+                         W[s - 1], H[s - 1], W[s], H[s], P->zfactor, P->zfactor, 1.f, 0);
+    }
+  const size_t nc = (size_t)W[ns - 1] * H[ns - 1];
+  HIPCHK(c, hipMemsetAsync(U1[ns - 1], 0, sizeof(float) * nc, c->stream));
+  HIPCHK(c, hipMemsetAsync(U2[ns - 1], 0, sizeof(float) * nc, c->stream));
+  // coarse to fine; scales finer than fscale only receive the upsampled flow (reference: :404-461)
+  int iters = 0;
+  const float inv = (float)1.0 / P->zfactor;
+  for (int s = ns - 1; s >= 0; --s) {
+    if (s >= P->fscale)
+      if ((rc = tv_scale(c, I0s[s], I1s[s], U1[s], U2[s], W[s], H[s], *P, work, part, st, c->tv_host, &iters)))
+        return rc;
+    if (s == 0) break;
+    const float fx = (float)W[s - 1] / W[s], fy = (float)H[s - 1] / H[s];  // zoom.c:94-95
+    for (int k = 0; k < 2; ++k)
+      hipLaunchKernelGGL(k_tv_zoom, tv_grid(W[s - 1], H[s - 1]), tv_block, 0, c->stream,
+                         (const float*)(k ? U2[s] : U1[s]), k ? U2[s - 1] : U1[s - 1], W[s], H[s], W[s - 1],
+                         H[s - 1], fx, fy, inv, 1);
+  }
+  hipLaunchKernelGGL(k_tv_interleave, dim3((n0 + 255) / 256), dim3(256), 0, c->stream, (const float*)U1[0],
+                     (const float*)U2[0], flow, (int)n0);
+  HIPCHK(c, hipGetLastError());
+  if (iterations) *iterations = iters;
+  return NLK_OK;
+}
+
+}  // extern "C"

@@ -20,6 +20,12 @@
  *   nlk_dev_frame_accumulate/_normalize the same two functions split at
  *                                       src/nlkalman.c:939 / :1853 so that row
  *                                       strips can exchange accumulator halos
+ *   nlk_dev_tvl1_flow                   lib/tvl1flow/tvl1flow_lib.c:345-474
+ *                                       (Dual_TVL1_optic_flow_multiscale)
+ *   nlk_tvl1_default_params / _scales   lib/tvl1flow/main.c:26-35, 152-157
+ *   nlk_dev_gray                        lib/iio/iio.c:1048-1056 (what the flow tool's
+ *                                       reader does to a colour image)
+ *   nlk_dev_occlusion_mask              scripts/nlkalman-seq.sh:70-73 (plambda)
  */
 #ifndef NLK_HIP_H
 #define NLK_HIP_H
@@ -89,6 +95,31 @@ int nlk_dev_filter_frame(nlk_ctx *ctx, float *deno1, const float *nisy1,
 int nlk_dev_smooth_frame(nlk_ctx *ctx, float *smoo1, const float *filt1,
                          const float *smoo0, const float *bsic1, int w, int h,
                          int ch, float sigma, const struct nlkalman_params *prms);
+
+/* ---- optical flow between two frames: the dual TV-L1 method the
+ * pipelines run before every filter call (scripts/nlkalman-seq.sh:57-66). Images are
+ * single-channel float (w*h); `flow` receives w*h interleaved (u, v) pairs, the layout
+ * nlk_dev_warp_bicubic and the .flo files use. I1(x + flow(x)) ~ I0(x). */
+struct nlk_tvl1_params {
+  float tau;      /* time step (0.25) */
+  float lambda;   /* data attachment weight (0.15) */
+  float theta;    /* tightness (0.3) */
+  int nscales;    /* pyramid levels actually used: cap it with nlk_tvl1_scales() */
+  int fscale;     /* finest level that is solved; finer ones get the upsampled flow */
+  float zfactor;  /* pyramid factor (0.5) */
+  int nwarps;     /* warps per level (5) */
+  float epsilon;  /* stop when the mean squared update <= epsilon^2 (0.01) */
+};
+void nlk_tvl1_default_params(struct nlk_tvl1_params *p);
+/* number of levels the reference's command line derives from the image size */
+int nlk_tvl1_scales(int w, int h, int nscales, float zfactor);
+/* `iterations` (may be NULL) receives the total number of fixed-point iterations */
+int nlk_dev_tvl1_flow(nlk_ctx *ctx, float *flow, const float *I0, const float *I1, int w, int h,
+                      const struct nlk_tvl1_params *prms, int *iterations);
+/* luminance .299 R + .587 G + .114 B of an interleaved image (ch >= 3), copy of channel 0 otherwise */
+int nlk_dev_gray(nlk_ctx *ctx, float *gray, const float *im, int w, int h, int ch);
+/* 255 where |backward-difference divergence of the flow| > th, else 0 */
+int nlk_dev_occlusion_mask(nlk_ctx *ctx, float *mask, const float *flow, int w, int h, float th);
 
 /* Row-strip form used by the multi-GPU driver. The images are a strip of the
  * frame (h rows) that already contains the search halo; targets are the patch
