@@ -35,6 +35,7 @@ API_SYMBOLS = [
     "rgb2opp", "opp2rgb", "warp_bicubic", "nlkalman_default_params",
     "nlkalman_filter_frame", "nlkalman_smooth_frame",
 ]
+TVL1_SYMBOLS = ["Dual_TVL1_optic_flow_multiscale"]  # include/tvl1flow.h, exported by libnlkalman.so
 
 
 class Tvl1Params(C.Structure):

@@ -17,6 +17,7 @@
 
 #include "nlk_hip.h"
 #include "nlkalman.h"
+#include "tvl1flow.h"
 
 static nlk_ctx *g_ctx = NULL;
 
@@ -153,4 +154,31 @@ void nlkalman_smooth_frame(float *smoo1, float *filt1, float *smoo0, float *bsic
                            int ch, float sigma, const struct nlkalman_params prms, int frame) {
   (void)frame;
   frame_call(1, smoo1, filt1, smoo0, bsic1, w, h, ch, sigma, &prms);
+}
+
+/* reference: lib/tvl1flow/tvl1flow_lib.c:345-474 — host pointers in, planar u1 / u2 out */
+void Dual_TVL1_optic_flow_multiscale(float *I0, float *I1, float *u1, float *u2, const int nxx,
+                                     const int nyy, const float tau, const float lambda,
+                                     const float theta, const int nscales, const int fscale,
+                                     const float zfactor, const int warps, const float epsilon,
+                                     const bool verbose) {
+  (void)verbose;
+  nlk_ctx *c = ctx();
+  const size_t n = (size_t)nxx * nyy;
+  struct nlk_tvl1_params P = {tau, lambda, theta, nscales, fscale, zfactor, warps, epsilon};
+  float *d0 = upload(c, I0, n), *d1 = upload(c, I1, n);
+  void *d_flow = NULL;
+  float *flow = (float *)malloc(2 * n * sizeof(float));
+  if (!flow || nlk_dev_alloc(c, &d_flow, 2 * n * sizeof(float))) die("Dual_TVL1_optic_flow_multiscale", c);
+  if (nlk_dev_tvl1_flow(c, (float *)d_flow, d0, d1, nxx, nyy, &P, NULL) ||
+      nlk_d2h(c, flow, d_flow, 2 * n * sizeof(float)))
+    die("Dual_TVL1_optic_flow_multiscale", c);
+  for (size_t i = 0; i < n; ++i) {
+    u1[i] = flow[2 * i];
+    u2[i] = flow[2 * i + 1];
+  }
+  free(flow);
+  nlk_dev_free(c, d0);
+  nlk_dev_free(c, d1);
+  nlk_dev_free(c, d_flow);
 }

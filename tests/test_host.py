@@ -23,13 +23,14 @@ def test_headers_declare_expected_symbols(built):
     assert api == sorted(built.API_SYMBOLS)
     abi = _declared("nlk_hip.h")
     assert abi == sorted(built.HIP_SYMBOLS)
+    assert _declared("tvl1flow.h") == sorted(built.TVL1_SYMBOLS)
 
 
 def test_libraries_export_every_declared_symbol(built):
     hip, api = built.hip(), built.api()
     for s in _declared("nlk_hip.h"):
         assert hasattr(hip, s), s
-    for s in _declared("nlkalman.h"):
+    for s in _declared("nlkalman.h") + _declared("tvl1flow.h"):
         assert hasattr(api, s), s
 
 
