@@ -8,17 +8,20 @@
 // Rom cells, double hypot); every expression keeps its operand types and association order
 // and contraction is off, so the results equal the CPU oracle's bit for bit as long as the
 // solver stops at the same iteration (the only reordered float sum is the convergence
-// measure: see k_tv_dual).
+// measure: see k_tv_level).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #define NLK_TV_MAXIT 300  // reference: tvl1flow_lib.c:24
+#define NLK_TV_THREADS 1024  // workgroup of the level kernel: 16 wavefronts = 64 x 16 pixels per tile
+#define NLK_TV_WAVES (NLK_TV_THREADS / 64)
 
-// device-side state of the fixed-point loop of one warp
+// device-side state of the solver
 struct NlkTvState {
-  int stop_iter;   // iterations n > stop_iter are no-ops (set by the iteration that converged)
-  int iters;       // last executed iteration
+  int iters;       // fixed-point iterations executed so far (all levels and warps)
+  int stop_iter;   // multi-launch driver: iterations n > stop_iter of the current warp are no-ops
+  int last;        // multi-launch driver: last executed iteration of the current warp
   float error;     // its mean squared update
 };
 
@@ -135,12 +138,6 @@ __global__ void k_tv_gauss(const float* __restrict__ in, float* __restrict__ out
   out[y * nx + x] = (float)sum;
 }
 
-__global__ void k_tv_reset(NlkTvState* st) {
-  st->stop_iter = NLK_TV_MAXIT;
-  st->iters = 0;
-  st->error = INFINITY;
-}
-
 __global__ void k_tv_init_minmax(int* mm) {
   mm[0] = 0x7FFFFFFF;
   mm[1] = (int)0x80000000;
@@ -157,48 +154,33 @@ __global__ void k_tv_zoom(const float* __restrict__ in, float* __restrict__ out,
   out[i1 * nxx + j1] = use_gain ? g * gain : g;
 }
 
-// ---- centred gradient (reference: mask.c:148-214)
-__global__ void k_tv_centered_grad(const float* __restrict__ f, float* __restrict__ dx,
-                                   float* __restrict__ dy, int nx, int ny) {
-#pragma clang fp contract(off)
-  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y * blockDim.y + threadIdx.y;
-  if (j >= nx || i >= ny) return;
-  const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
-  const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
-  dx[i * nx + j] = (float)(0.5 * (f[i * nx + jr] - f[i * nx + jl]));
-  dy[i * nx + j] = (float)(0.5 * (f[id * nx + j] - f[iu * nx + j]));
-}
+// ---- one pyramid level (reference: tvl1flow_lib.c:93-275): centred gradient of I1, then per
+// warp the sampling of I1 / I1x / I1y at x + u and the iterations {thresholding + divergence +
+// flow update; forward gradient + dual update} until the mean squared update drops below
+// epsilon^2. The per-pixel steps are the device functions below (the reference's arithmetic,
+// type for type; u and p are updated in place: each step writes only what it read at the own
+// pixel). Two drivers use them:
+//  * levels of up to NLK_TV_WG_PIXELS pixels run ENTIRELY inside one 1024-thread workgroup
+//    (k_tv_level_wg): all warps and iterations, phases separated by workgroup barriers, the stop
+//    test evaluated in the kernel. An iteration costs ~1 us there instead of two launches of
+//    ~5 us each, and nothing is read back;
+//  * larger levels launch one kernel per half iteration (k_tv_primal / k_tv_dual); the stop test
+//    also lives on the device (iterations after the converged one return at once) and the host
+//    looks at the state only between batches of iterations.
+// (A single persistent kernel with grid-wide barriers was measured too: on this multi-XCD part a
+// device-scope release/acquire per phase costs ~10 us, more than the launches it replaces.)
+struct NlkTvLevel {
+  const float *I0, *I1;
+  float *u1, *u2;
+  float *I1x, *I1y, *I1wx, *I1wy, *grad, *rho_c, *p11, *p12, *p21, *p22;
+  float* part;      // one partial sum of squared updates per workgroup
+  NlkTvState* st;   // iteration count of the level (accumulated)
+  int nx, ny, nwarps;
+  float l_t, theta, taut, eps2;
+};
 
-// ---- start of a warp: I1, I1x, I1y sampled at x + u (zero outside), |grad|^2 and the constant
-// part of rho (reference: tvl1flow_lib.c:144-162)
-__global__ void k_tv_warp(const float* __restrict__ I0, const float* __restrict__ I1,
-                          const float* __restrict__ I1x, const float* __restrict__ I1y,
-                          const float* __restrict__ u1, const float* __restrict__ u2,
-                          float* __restrict__ I1wx, float* __restrict__ I1wy,
-                          float* __restrict__ grad, float* __restrict__ rho_c, int nx, int ny) {
-#pragma clang fp contract(off)
-  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y * blockDim.y + threadIdx.y;
-  if (j >= nx || i >= ny) return;
-  const int p = i * nx + j;
-  const float a = u1[p], b = u2[p];
-  const NlkTvTaps t = nlk_tv_taps((float)(j + a), (float)(i + b), nx, ny);
-  float w = 0.f, wx = 0.f, wy = 0.f;
-  if (!t.out) {
-    w = nlk_tv_sample(I1, t, nx);
-    wx = nlk_tv_sample(I1x, t, nx);
-    wy = nlk_tv_sample(I1y, t, nx);
-  }
-  const float Ix2 = wx * wx, Iy2 = wy * wy;
-  I1wx[p] = wx;
-  I1wy[p] = wy;
-  grad[p] = Ix2 + Iy2;
-  rho_c[p] = w - wx * a - wy * b - I0[p];
-}
-
-// ---- iteration n, first half: thresholding step, divergence of the dual variables, new flow,
-// squared update (reference: tvl1flow_lib.c:172-230, mask.c:43-96). u is updated in place
-// (read and written at the own pixel only). Each workgroup leaves its partial sum of the
-// squared update in part[]; k_tv_dual adds them in a fixed order.
+// backward-difference divergence; the association order differs between the body, the
+// first/last column and the corners in the reference (mask.c:52-96) and is kept
 __device__ __forceinline__ float nlk_tv_div(const float* __restrict__ v1, const float* __restrict__ v2,
                                             int p, int i, int j, int nx, int ny) {
 #pragma clang fp contract(off)
@@ -213,91 +195,184 @@ __device__ __forceinline__ float nlk_tv_div(const float* __restrict__ v1, const 
   return lef ? v1[p] - v2[p - nx] : -v1[p - 1] - v2[p - nx];
 }
 
-__global__ void __launch_bounds__(256)
-k_tv_primal(const float* __restrict__ rho_c, const float* __restrict__ I1wx,
-            const float* __restrict__ I1wy, const float* __restrict__ grad,
-            float* __restrict__ u1, float* __restrict__ u2, const float* __restrict__ p11,
-            const float* __restrict__ p12, const float* __restrict__ p21,
-            const float* __restrict__ p22, float* __restrict__ part, const NlkTvState* __restrict__ st,
-            int n, int nx, int ny, float l_t, float theta) {
+// centred gradient (reference: mask.c:148-214) and the zero start of the dual variables (:137-141)
+__device__ __forceinline__ void nlk_tv_px_init(const NlkTvLevel& L, int i, int j) {
 #pragma clang fp contract(off)
-  if (n > st->stop_iter) return;
-  const int j = blockIdx.x * 32 + (threadIdx.x & 31), i = blockIdx.y * 8 + (threadIdx.x >> 5);
-  float e = 0.f;
-  if (j < nx && i < ny) {
-    const int p = i * nx + j;
-    const float a = u1[p], b = u2[p], gx = I1wx[p], gy = I1wy[p], g = grad[p];
-    const float rho = rho_c[p] + (gx * a + gy * b);
-    float d1, d2;
-    if (rho < -l_t * g) {
-      d1 = l_t * gx;
-      d2 = l_t * gy;
-    } else if (rho > l_t * g) {
-      d1 = -l_t * gx;
-      d2 = -l_t * gy;
-    } else if (g < 1E-10) {
-      d1 = d2 = 0;
-    } else {
-      const float fi = -rho / g;
-      d1 = fi * gx;
-      d2 = fi * gy;
-    }
-    const float v1 = a + d1, v2 = b + d2;
-    const float na = v1 + theta * nlk_tv_div(p11, p12, p, i, j, nx, ny);
-    const float nb = v2 + theta * nlk_tv_div(p21, p22, p, i, j, nx, ny);
-    u1[p] = na;
-    u2[p] = nb;
-    e = (na - a) * (na - a) + (nb - b) * (nb - b);
-  }
-  // fixed-order workgroup sum
-  __shared__ float red[4];
-  for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = e;
-  __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  const int nx = L.nx, ny = L.ny, p = i * nx + j;
+  const int jl = j > 0 ? j - 1 : 0, jr = j < nx - 1 ? j + 1 : nx - 1;
+  const int iu = i > 0 ? i - 1 : 0, id = i < ny - 1 ? i + 1 : ny - 1;
+  L.I1x[p] = (float)(0.5 * (L.I1[i * nx + jr] - L.I1[i * nx + jl]));
+  L.I1y[p] = (float)(0.5 * (L.I1[id * nx + j] - L.I1[iu * nx + j]));
+  L.p11[p] = L.p12[p] = L.p21[p] = L.p22[p] = 0.f;
 }
 
-// ---- iteration n, second half: forward gradient of the new flow and dual update (reference:
-// tvl1flow_lib.c:233-250, mask.c:98-141); hypot and 1 + taut*g are evaluated in double there.
-// Workgroup 0 also closes the iteration: it adds the partial sums of k_tv_primal (fixed order,
-// so a run is reproducible; the reference adds the pixels one by one in float, which rounds
-// differently in the last bits) and, if the update is small enough, makes the iterations
-// after n no-ops. The stop test is the reference's `error > epsilon^2 && n < MAX_ITERATIONS`.
-__global__ void __launch_bounds__(256)
-k_tv_dual(const float* __restrict__ u1, const float* __restrict__ u2, float* __restrict__ p11,
-          float* __restrict__ p12, float* __restrict__ p21, float* __restrict__ p22,
-          const float* __restrict__ part, int nparts, NlkTvState* __restrict__ st, int n, int nx,
-          int ny, float taut, float eps2) {
+// start of a warp: I1, I1x, I1y sampled at x + u (zero outside), |grad|^2 and the constant part
+// of rho (reference: tvl1flow_lib.c:144-162)
+__device__ __forceinline__ void nlk_tv_px_warp(const NlkTvLevel& L, int i, int j) {
 #pragma clang fp contract(off)
-  if (n > st->stop_iter) return;
-  const int j = blockIdx.x * 32 + (threadIdx.x & 31), i = blockIdx.y * 8 + (threadIdx.x >> 5);
-  if (j < nx && i < ny) {
-    const int p = i * nx + j;
-    const float a = u1[p], b = u2[p];
-    const float ax = j < nx - 1 ? u1[p + 1] - a : 0.f, ay = i < ny - 1 ? u1[p + nx] - a : 0.f;
-    const float bx = j < nx - 1 ? u2[p + 1] - b : 0.f, by = i < ny - 1 ? u2[p + nx] - b : 0.f;
-    const float g1 = (float)hypot((double)ax, (double)ay);
-    const float g2 = (float)hypot((double)bx, (double)by);
-    const float ng1 = (float)(1.0 + (double)(taut * g1));
-    const float ng2 = (float)(1.0 + (double)(taut * g2));
-    p11[p] = (p11[p] + taut * ax) / ng1;
-    p12[p] = (p12[p] + taut * ay) / ng1;
-    p21[p] = (p21[p] + taut * bx) / ng2;
-    p22[p] = (p22[p] + taut * by) / ng2;
+  const int nx = L.nx, p = i * nx + j;
+  const float a = L.u1[p], b = L.u2[p];
+  const NlkTvTaps t = nlk_tv_taps((float)(j + a), (float)(i + b), nx, L.ny);
+  float w = 0.f, wx = 0.f, wy = 0.f;
+  if (!t.out) {
+    w = nlk_tv_sample(L.I1, t, nx);
+    wx = nlk_tv_sample(L.I1x, t, nx);
+    wy = nlk_tv_sample(L.I1y, t, nx);
   }
+  const float Ix2 = wx * wx, Iy2 = wy * wy;
+  L.I1wx[p] = wx;
+  L.I1wy[p] = wy;
+  L.grad[p] = Ix2 + Iy2;
+  L.rho_c[p] = w - wx * a - wy * b - L.I0[p];
+}
+
+// first half of an iteration: thresholding step, divergence of the dual variables, new flow;
+// returns the squared update (reference: tvl1flow_lib.c:172-230)
+__device__ __forceinline__ float nlk_tv_px_primal(const NlkTvLevel& L, int i, int j) {
+#pragma clang fp contract(off)
+  const int nx = L.nx, p = i * nx + j;
+  const float l_t = L.l_t;
+  const float a = L.u1[p], b = L.u2[p], gx = L.I1wx[p], gy = L.I1wy[p], g = L.grad[p];
+  const float rho = L.rho_c[p] + (gx * a + gy * b);
+  float d1, d2;
+  if (rho < -l_t * g) {
+    d1 = l_t * gx;
+    d2 = l_t * gy;
+  } else if (rho > l_t * g) {
+    d1 = -l_t * gx;
+    d2 = -l_t * gy;
+  } else if (g < 1E-10) {
+    d1 = d2 = 0;
+  } else {
+    const float fi = -rho / g;
+    d1 = fi * gx;
+    d2 = fi * gy;
+  }
+  const float v1 = a + d1, v2 = b + d2;
+  const float na = v1 + L.theta * nlk_tv_div(L.p11, L.p12, p, i, j, nx, L.ny);
+  const float nb = v2 + L.theta * nlk_tv_div(L.p21, L.p22, p, i, j, nx, L.ny);
+  L.u1[p] = na;
+  L.u2[p] = nb;
+  return (na - a) * (na - a) + (nb - b) * (nb - b);
+}
+
+// second half: forward gradient of the new flow and dual update (reference: tvl1flow_lib.c:
+// 233-250, mask.c:98-141); hypot and 1 + taut*g are evaluated in double there
+__device__ __forceinline__ void nlk_tv_px_dual(const NlkTvLevel& L, int i, int j) {
+#pragma clang fp contract(off)
+  const int nx = L.nx, ny = L.ny, p = i * nx + j;
+  const float taut = L.taut;
+  const float a = L.u1[p], b = L.u2[p];
+  const float ax = j < nx - 1 ? L.u1[p + 1] - a : 0.f, ay = i < ny - 1 ? L.u1[p + nx] - a : 0.f;
+  const float bx = j < nx - 1 ? L.u2[p + 1] - b : 0.f, by = i < ny - 1 ? L.u2[p + nx] - b : 0.f;
+  // hypot() in double, rounded to float: the squares of floats are exact in double, so
+  // sqrt(x*x + y*y) carries two roundings of 2^-53 and gives the same float as the C library's
+  // hypot (no overflow / underflow scaling is needed for flow gradients)
+  const double dax = ax, day = ay, dbx = bx, dby = by;
+  const float g1 = (float)sqrt(dax * dax + day * day);
+  const float g2 = (float)sqrt(dbx * dbx + dby * dby);
+  const float ng1 = (float)(1.0 + (double)(taut * g1));
+  const float ng2 = (float)(1.0 + (double)(taut * g2));
+  L.p11[p] = (L.p11[p] + taut * ax) / ng1;
+  L.p12[p] = (L.p12[p] + taut * ay) / ng1;
+  L.p21[p] = (L.p21[p] + taut * bx) / ng2;
+  L.p22[p] = (L.p22[p] + taut * by) / ng2;
+}
+
+#define NLK_TV_WG_PIXELS 12288  // largest level solved by one workgroup (12 pixels per thread)
+
+// fixed-order sum of one float per thread over a workgroup of NLK_TV_THREADS
+__device__ __forceinline__ float nlk_tv_block_sum(float e, float* redf) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
+  __syncthreads();  // (redf may still be read from the previous call)
+  if (lane == 0) redf[wave] = e;
+  __syncthreads();
+  float bs = 0.f;
+  for (int k = 0; k < (int)(blockDim.x >> 6); ++k) bs += redf[k];
+  return bs;
+}
+
+__global__ void __launch_bounds__(NLK_TV_THREADS) k_tv_level_wg(NlkTvLevel L) {
+  __shared__ float redf[NLK_TV_WAVES];
+  const int npix = L.nx * L.ny;
+#define NLK_TV_ALL(body)                                         \
+  for (int p_ = threadIdx.x; p_ < npix; p_ += NLK_TV_THREADS) { \
+    const int i = p_ / L.nx, j = p_ - i * L.nx;                  \
+    body;                                                        \
+  }
+  NLK_TV_ALL(nlk_tv_px_init(L, i, j))
+  __syncthreads();
+  int total = 0;
+  for (int wi = 0; wi < L.nwarps; ++wi) {
+    NLK_TV_ALL(nlk_tv_px_warp(L, i, j))
+    __syncthreads();
+    float err = INFINITY;
+    int n = 0;
+    while (err > L.eps2 && n < NLK_TV_MAXIT) {  // reference: tvl1flow_lib.c:166
+      ++n;
+      float e = 0.f;
+      NLK_TV_ALL(e += nlk_tv_px_primal(L, i, j))
+      // fixed-order sum (the reference adds the pixels one by one in float, which rounds
+      // differently in the last bits); its barriers also separate the two halves
+      err = nlk_tv_block_sum(e, redf);
+      err /= (float)npix;
+      NLK_TV_ALL(nlk_tv_px_dual(L, i, j))
+      __syncthreads();
+    }
+    total += n;
+  }
+#undef NLK_TV_ALL
+  if (threadIdx.x == 0) L.st->iters += total;
+}
+
+// ---- multi-launch driver: 64 x 4 pixels per workgroup (a wavefront = 64 consecutive pixels)
+__global__ void __launch_bounds__(256) k_tv_init(NlkTvLevel L) {
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (j < L.nx && i < L.ny) nlk_tv_px_init(L, i, j);
+}
+
+__global__ void __launch_bounds__(256) k_tv_warp(NlkTvLevel L) {
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (j < L.nx && i < L.ny) nlk_tv_px_warp(L, i, j);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {  // a new fixed-point loop starts
+    L.st->stop_iter = NLK_TV_MAXIT;
+    L.st->last = 0;
+    L.st->error = INFINITY;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_tv_primal(NlkTvLevel L, int n) {
+  if (n > L.st->stop_iter) return;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
+  float e = 0.f;
+  if (j < L.nx && i < L.ny) e = nlk_tv_px_primal(L, i, j);
+  __shared__ float redf[4];
+  e = nlk_tv_block_sum(e, redf);
+  if (threadIdx.x == 0) L.part[blockIdx.y * gridDim.x + blockIdx.x] = e;
+}
+
+// Workgroup 0 also closes the iteration: it adds the partial sums of k_tv_primal in a fixed
+// order and, if the update is small enough, turns the iterations after n into no-ops (the
+// other workgroups of THIS launch still run: they test n > stop_iter, and stop_iter >= n).
+__global__ void __launch_bounds__(256) k_tv_dual(NlkTvLevel L, int n, int nparts) {
+  if (n > L.st->stop_iter) return;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (j < L.nx && i < L.ny) nlk_tv_px_dual(L, i, j);
   if (blockIdx.x == 0 && blockIdx.y == 0) {
     __shared__ double red[4];
     double s = 0.0;
-    for (int k = threadIdx.x; k < nparts; k += 256) s += (double)part[k];
+    for (int k = threadIdx.x; k < nparts; k += 256) s += (double)L.part[k];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
       float err = (float)((red[0] + red[1]) + (red[2] + red[3]));
-      err /= (float)(nx * ny);
-      st->iters = n;
-      st->error = err;
-      if (!(err > eps2)) st->stop_iter = n;  // (n == MAX is the host's loop bound)
+      err /= (float)(L.nx * L.ny);
+      L.st->last = n;
+      L.st->error = err;
+      L.st->iters += 1;
+      if (!(err > L.eps2)) L.st->stop_iter = n;  // reference: tvl1flow_lib.c:166
     }
   }
 }

@@ -39,41 +39,41 @@ int tv_gaussian(nlk_ctx* c, const float* in, float* out, float* tmp, int nx, int
 
 // one scale (reference: tvl1flow_lib.c:93-275)
 int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2, int nx, int ny,
-             const nlk_tvl1_params& P, float* work, float* part, NlkTvState* st, NlkTvState* host_st,
-             int* iters_total) {
+             const nlk_tvl1_params& P, float* work, float* part, NlkTvState* st) {
   const size_t n = (size_t)nx * ny;
-  float *I1x = work, *I1y = I1x + n, *I1wx = I1y + n, *I1wy = I1wx + n, *grad = I1wy + n;
-  float *rho_c = grad + n, *p11 = rho_c + n, *p12 = p11 + n, *p21 = p12 + n, *p22 = p21 + n;
-  const dim3 grid = tv_grid(nx, ny);
+  NlkTvLevel L;
+  L.I0 = I0; L.I1 = I1; L.u1 = u1; L.u2 = u2;
+  L.I1x = work; L.I1y = L.I1x + n; L.I1wx = L.I1y + n; L.I1wy = L.I1wx + n; L.grad = L.I1wy + n;
+  L.rho_c = L.grad + n; L.p11 = L.rho_c + n; L.p12 = L.p11 + n; L.p21 = L.p12 + n; L.p22 = L.p21 + n;
+  L.part = part; L.st = st;
+  L.nx = nx; L.ny = ny; L.nwarps = P.nwarps;
+  L.l_t = P.lambda * P.theta; L.theta = P.theta; L.taut = P.tau / P.theta; L.eps2 = P.epsilon * P.epsilon;
+  const size_t wg_max = getenv("NLK_TV_WG_PIXELS") ? (size_t)atoi(getenv("NLK_TV_WG_PIXELS")) : NLK_TV_WG_PIXELS;
+  if (n <= wg_max) {  // the whole level inside one workgroup
+    hipLaunchKernelGGL(k_tv_level_wg, dim3(1), dim3(NLK_TV_THREADS), 0, c->stream, L);
+    HIPCHK(c, hipGetLastError());
+    return NLK_OK;
+  }
+  const dim3 grid((nx + 63) / 64, (ny + 3) / 4);
   const int nparts = grid.x * grid.y;
-  const float l_t = P.lambda * P.theta, taut = P.tau / P.theta, eps2 = P.epsilon * P.epsilon;
-  hipLaunchKernelGGL(k_tv_centered_grad, grid, tv_block, 0, c->stream, I1, I1x, I1y, nx, ny);
-  HIPCHK(c, hipMemsetAsync(p11, 0, sizeof(float) * n * 4, c->stream));
+  hipLaunchKernelGGL(k_tv_init, grid, dim3(256), 0, c->stream, L);
+  const int batch = getenv("NLK_TV_BATCH") ? atoi(getenv("NLK_TV_BATCH")) : 12;
   for (int wi = 0; wi < P.nwarps; ++wi) {
-    hipLaunchKernelGGL(k_tv_warp, grid, tv_block, 0, c->stream, I0, I1, (const float*)I1x,
-                       (const float*)I1y, (const float*)u1, (const float*)u2, I1wx, I1wy, grad, rho_c, nx,
-                       ny);
-    hipLaunchKernelGGL(k_tv_reset, dim3(1), dim3(1), 0, c->stream, st);
-    // the loop's exit test lives on the device (k_tv_dual); the host launches iterations in
-    // batches and looks at the state between them, so no launch waits for a read-back
+    hipLaunchKernelGGL(k_tv_warp, grid, dim3(256), 0, c->stream, L);
+    // the host launches iterations in batches and looks at the state between them, so no
+    // launch waits for a read-back; iterations past the converged one return at once
     int launched = 0;
-    const int batch = getenv("NLK_TV_BATCH") ? atoi(getenv("NLK_TV_BATCH")) : 12;
     while (launched < NLK_TV_MAXIT) {
       const int upto = launched + batch < NLK_TV_MAXIT ? launched + batch : NLK_TV_MAXIT;
       for (int it = launched + 1; it <= upto; ++it) {
-        hipLaunchKernelGGL(k_tv_primal, grid, dim3(256), 0, c->stream, (const float*)rho_c,
-                           (const float*)I1wx, (const float*)I1wy, (const float*)grad, u1, u2,
-                           (const float*)p11, (const float*)p12, (const float*)p21, (const float*)p22, part,
-                           (const NlkTvState*)st, it, nx, ny, l_t, P.theta);
-        hipLaunchKernelGGL(k_tv_dual, grid, dim3(256), 0, c->stream, (const float*)u1, (const float*)u2,
-                           p11, p12, p21, p22, (const float*)part, nparts, st, it, nx, ny, taut, eps2);
+        hipLaunchKernelGGL(k_tv_primal, grid, dim3(256), 0, c->stream, L, it);
+        hipLaunchKernelGGL(k_tv_dual, grid, dim3(256), 0, c->stream, L, it, nparts);
       }
       launched = upto;
-      HIPCHK(c, hipMemcpyAsync(host_st, st, sizeof(NlkTvState), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->tv_host, st, sizeof(NlkTvState), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
-      if (host_st->stop_iter < NLK_TV_MAXIT || host_st->iters >= NLK_TV_MAXIT) break;
+      if (c->tv_host->stop_iter < NLK_TV_MAXIT || c->tv_host->last >= NLK_TV_MAXIT) break;
     }
-    if (iters_total) *iters_total += host_st->iters;
   }
   HIPCHK(c, hipGetLastError());
   return NLK_OK;
@@ -130,9 +130,9 @@ int nlk_dev_tvl1_flow(nlk_ctx* c, float* flow, const float* I0, const float* I1,
     pyr += (size_t)W[s] * H[s];
   }
   const size_t n0 = (size_t)w * h;
-  const dim3 g0 = tv_grid(w, h);
   // scratch: 4 pyramids (I0, I1, u1, u2) + 10 work images + 2 temporaries at full size + partial sums
-  const size_t floats = 4 * pyr + 12 * n0 + (size_t)g0.x * g0.y + 64;
+  const size_t nparts0 = (size_t)((w + 63) / 64) * ((h + 3) / 4);  // workgroups of an iteration kernel at full size
+  const size_t floats = 4 * pyr + 12 * n0 + nparts0 + 64;
   int rc = reserve(c, c->tv, sizeof(float) * floats);
   if (rc) return rc;
   if (!c->tv_host) HIPCHK(c, hipHostMalloc((void**)&c->tv_host, sizeof(NlkTvState)));
@@ -146,11 +146,12 @@ int nlk_dev_tvl1_flow(nlk_ctx* c, float* flow, const float* I0, const float* I1,
   float* work = q; q += 10 * n0;
   float* tmp = q; q += n0;
   float* tmp2 = q; q += n0;
-  float* part = q; q += (size_t)g0.x * g0.y;
+  float* part = q; q += nparts0;
   NlkTvState* st = (NlkTvState*)q;  // 64 floats reserved
   int* mm = (int*)(q + 8);
 
   // normalise both images to 0..255 with one common range, pre-smooth (reference: :376-381)
+  HIPCHK(c, hipMemsetAsync(st, 0, sizeof(NlkTvState), c->stream));
   hipLaunchKernelGGL(k_tv_init_minmax, dim3(1), dim3(1), 0, c->stream, mm);
   hipLaunchKernelGGL(k_tv_minmax, dim3(1024), dim3(256), 0, c->stream, I0, I1, (int)n0, mm);
   hipLaunchKernelGGL(k_tv_normalize, dim3((n0 + 255) / 256), dim3(256), 0, c->stream, I0, I1, I0s[0],
@@ -171,12 +172,10 @@ int nlk_dev_tvl1_flow(nlk_ctx* c, float* flow, const float* I0, const float* I1,
   HIPCHK(c, hipMemsetAsync(U1[ns - 1], 0, sizeof(float) * nc, c->stream));
   HIPCHK(c, hipMemsetAsync(U2[ns - 1], 0, sizeof(float) * nc, c->stream));
   // coarse to fine; scales finer than fscale only receive the upsampled flow (reference: :404-461)
-  int iters = 0;
   const float inv = (float)1.0 / P->zfactor;
   for (int s = ns - 1; s >= 0; --s) {
     if (s >= P->fscale)
-      if ((rc = tv_scale(c, I0s[s], I1s[s], U1[s], U2[s], W[s], H[s], *P, work, part, st, c->tv_host, &iters)))
-        return rc;
+      if ((rc = tv_scale(c, I0s[s], I1s[s], U1[s], U2[s], W[s], H[s], *P, work, part, st))) return rc;
     if (s == 0) break;
     const float fx = (float)W[s - 1] / W[s], fy = (float)H[s - 1] / H[s];  // zoom.c:94-95
     for (int k = 0; k < 2; ++k)
@@ -187,7 +186,11 @@ int nlk_dev_tvl1_flow(nlk_ctx* c, float* flow, const float* I0, const float* I1,
   hipLaunchKernelGGL(k_tv_interleave, dim3((n0 + 255) / 256), dim3(256), 0, c->stream, (const float*)U1[0],
                      (const float*)U2[0], flow, (int)n0);
   HIPCHK(c, hipGetLastError());
-  if (iterations) *iterations = iters;
+  if (iterations) {  // (the only read-back, and only when asked for)
+    HIPCHK(c, hipMemcpyAsync(c->tv_host, st, sizeof(NlkTvState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *iterations = c->tv_host->iters;
+  }
   return NLK_OK;
 }
 
