@@ -32,6 +32,9 @@ WORKLOADS = {
     "C3": (3840, 2160, 3, 40.0, 12, 2),
     # C5: the full per-frame chain flt1 -> flt2 -> smo1 on resident frames (single GPU only)
     "C5": (1920, 1080, 3, 20.0, 8, 1),
+    # F1: the optical flow the pipelines compute before every temporal call:
+    # tvl1flow with its default parameters between two noisy 1080p frames
+    "F1": (1920, 1080, 3, 20.0, 8, 1),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense f32 MFMA peak (= the f32 vector peak)
@@ -50,6 +53,125 @@ def cpu_baseline(O, o1, prev, sigma, p):
                  "kind": "port",
                  "sample": f"1 full frame {w}x{h}x{o1.shape[2]} FLT1-temporal, OpenMP over "
                            f"{nthr} threads, {dt:.2f} s wall"}
+
+
+def bench_flow(args, pkg, synth, ctx, torch, dist, rank, world, dev):
+    """Workload F1: one step = one multiscale TV-L1 flow between two resident gray frames.
+    The path does not shard (every iteration couples the whole image): N > 1 runs N independent
+    replicas on different frame pairs ("replicas only")."""
+    import ctypes as C
+    import numpy as np
+    w, h, ch, sigma, _, seed = WORKLOADS["F1"]
+    n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, seed + rank)
+    t0_, t1_ = torch.from_numpy(n0).to(dev), torch.from_numpy(n1).to(dev)
+    g0 = torch.empty((h, w), dtype=torch.float32, device=dev)
+    g1 = torch.empty_like(g0)
+    ctx.gray(g0.data_ptr(), t0_.data_ptr(), w, h, ch)
+    ctx.gray(g1.data_ptr(), t1_.data_ptr(), w, h, ch)
+    flow = torch.empty((h, w, 2), dtype=torch.float32, device=dev)
+    prm = pkg.tvl1_params(w, h)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    iters = 0
+    for _ in range(args.warmup):
+        iters = ctx.tvl1_flow(flow.data_ptr(), g0.data_ptr(), g1.data_ptr(), w, h, prm)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.L.nlk_dev_tvl1_flow(ctx.h, flow.data_ptr(), g0.data_ptr(), g1.data_ptr(), w, h,
+                                C.byref(prm), None)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank != 0:
+        return
+    ms = dt / args.steps * 1e3
+    # roofline of the dominant kernels (k_tv_primal + k_tv_dual at full size): a one-level run is
+    # nothing but their iterations (+ 5 warps); per iteration and pixel they read 16 and write
+    # 6 floats = 88 algorithmic bytes (DESIGN.md §5)
+    one = pkg.tvl1_params(w, h)
+    one.nscales = 1
+    it1 = ctx.tvl1_flow(flow.data_ptr(), g0.data_ptr(), g1.data_ptr(), w, h, one)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        ctx.L.nlk_dev_tvl1_flow(ctx.h, flow.data_ptr(), g0.data_ptr(), g1.data_ptr(), w, h, C.byref(one), None)
+    torch.cuda.synchronize()
+    t_iter = (time.perf_counter() - t1) / reps / max(it1, 1)
+    gbs = 88.0 * w * h / t_iter / 1e9
+    res = {"metric": "Mpix/s per flow (tvl1flow, 1080p, default parameters)", "value": round(world * w * h / (dt / args.steps) / 1e6, 3),
+           "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"F1: dual TV-L1 flow between two {w}x{h} noisy frames (sigma {sigma:g}), "
+                                  f"tau 0.25 lambda 0.15 theta 0.3, {prm.nscales} scales, 5 warps, epsilon 0.01",
+                      "parallelism": "single GPU" if world == 1 else f"{world} independent replicas",
+                      "iterations": iters},
+           "roofline": {"kernel": "k_tv_primal + k_tv_dual (one full-size iteration)", "bound": "hbm",
+                        "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                        "iteration_us": round(t_iter * 1e6, 2), "algorithmic_bytes_per_iteration": 88 * w * h,
+                        "note": "measured on a one-level run (wall time / iterations, launches and the "
+                                "per-batch state read-back included); the 182 MB working set of an "
+                                "iteration lives in the 256 MB Infinity Cache"}}
+    if not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as O
+        a, b = g0.cpu().numpy(), g1.cpu().numpy()
+        ref_so = os.path.join(ROOT, "oracle", "_ref", "libtvl1flow_ref.so")
+        fl = flow.cpu().numpy()
+        if os.path.exists(ref_so):  # the reference's own library (OpenMP), built by `make -C oracle ref`
+            L = C.CDLL(ref_so)
+            fp, i, f = C.POINTER(C.c_float), C.c_int, C.c_float
+            L.Dual_TVL1_optic_flow_multiscale.argtypes = [fp, fp, fp, fp, i, i, f, f, f, i, i, f, i, f, C.c_bool]
+            u, v = np.zeros((h, w), np.float32), np.zeros((h, w), np.float32)
+            tc = time.time()
+            L.Dual_TVL1_optic_flow_multiscale(a.ctypes.data_as(fp), b.ctypes.data_as(fp), u.ctypes.data_as(fp),
+                                              v.ctypes.data_as(fp), w, h, prm.tau, prm.lam, prm.theta, prm.nscales,
+                                              prm.fscale, prm.zfactor, prm.nwarps, prm.epsilon, False)
+            dtc = time.time() - tc
+            kind, cores = "reference", min(O.max_threads(), os.cpu_count() or 1)
+            sample = f"1 full flow {w}x{h}, lib/tvl1flow built from the reference sources, OpenMP, {dtc:.2f} s wall"
+        else:
+            sw, sh = 480, 270  # bounded sample for the single-threaded restatement
+            a, b = np.ascontiguousarray(a[:sh, :sw]), np.ascontiguousarray(b[:sh, :sw])
+            tc = time.time()
+            u, v = O.tvl1_flow(a, b)
+            dtc = time.time() - tc
+            fl = None
+            kind, cores = "port", 1
+            sample = f"1 flow on a {sw}x{sh} crop, single-threaded restatement, {dtc:.2f} s wall"
+            w_, h_ = sw, sh
+        npx = (w * h) if kind == "reference" else sw * sh
+        res["cpu_baseline"] = {"value": round(npx / dtc / 1e6, 4), "unit": "Mpix/s", "cores": cores,
+                               "kind": kind, "sample": sample}
+        if fl is not None:
+            # (the threaded reference adds its convergence measure in a thread-dependent order, so
+            # its own result depends on the thread count; the strict check is the crop below)
+            res["max_abs_vs_threaded_reference"] = round(
+                float(max(np.abs(fl[..., 0] - u).max(), np.abs(fl[..., 1] - v).max())), 4)
+        res["speedup_vs_cpu"] = round(res["value"] / world / res["cpu_baseline"]["value"], 1)
+        # parity: the same call on a 480x270 crop against the single-threaded oracle (= the
+        # single-threaded reference, bit for bit: tests/test_tvl1.py)
+        cw, chh = 480, 270
+        ca = np.ascontiguousarray(g0.cpu().numpy()[:chh, :cw])
+        cb = np.ascontiguousarray(g1.cpu().numpy()[:chh, :cw])
+        cu, cv = O.tvl1_flow(ca, cb)
+        ta, tb = torch.from_numpy(ca).to(dev), torch.from_numpy(cb).to(dev)
+        tf = torch.empty((chh, cw, 2), dtype=torch.float32, device=dev)
+        ctx.tvl1_flow(tf.data_ptr(), ta.data_ptr(), tb.data_ptr(), cw, chh, pkg.tvl1_params(cw, chh))
+        cf = tf.cpu().numpy()
+        res["parity_crop_480x270"] = {
+            "max_abs": round(float(max(np.abs(cf[..., 0] - cu).max(), np.abs(cf[..., 1] - cv).max())), 6),
+            "bit_exact": bool(np.array_equal(cf[..., 0], cu) and np.array_equal(cf[..., 1], cv))}
+    print(json.dumps(res))
 
 
 def main():
@@ -89,6 +211,11 @@ def main():
 
     ctx = pkg.Context(local)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    if args.workload == "F1":
+        bench_flow(args, pkg, synth, ctx, torch, dist, rank, world, dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     # ---- synthetic inputs (every rank builds the same frames; cheap)
     n0, n1, c1 = synth.noisy_pair(w, h, ch, sigma, seed)
