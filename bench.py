@@ -35,6 +35,9 @@ WORKLOADS = {
     # F1: the optical flow the pipelines compute before every temporal call:
     # tvl1flow with its default parameters between two noisy 1080p frames
     "F1": (1920, 1080, 3, 20.0, 8, 1),
+    # S1: one frame of the pipelines' forward recursion, frames resident:
+    # flow + occlusion mask + 2 warps + FLT1 + FLT2 (bwd-nlkalman_amd/sequence.py)
+    "S1": (1920, 1080, 3, 20.0, 8, 1),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense f32 MFMA peak (= the f32 vector peak)
@@ -174,6 +177,48 @@ def bench_flow(args, pkg, synth, ctx, torch, dist, rank, world, dev):
     print(json.dumps(res))
 
 
+def bench_sequence(args, pkg, synth, ctx, torch, rank, world, dev):
+    """Workload S1: one step = one frame of the forward recursion of scripts/nlkalman-seq.sh on
+    resident frames (tvl1flow lambda 0.40 fscale 1 -> mask 0.75 -> warp + FLT1 -> warp + FLT2)."""
+    import numpy as np
+    seq = importlib.import_module("bwd-nlkalman_amd.sequence")
+    if world != 1:
+        raise SystemExit("workload S1 is single-GPU (the recursion over frames is sequential)")
+    w, h, ch, sigma, _, seed = WORKLOADS["S1"]
+    # a short moving sequence with independent noise per frame, cycled (pushing one noisy frame
+    # repeatedly would feed the filter its own noise realisation as "previous frame")
+    nfr = 4
+    cleans = [synth.clean_frame(w, h, ch, t) for t in range(nfr)]
+    noisy = [torch.from_numpy(synth.awgn(cleans[t], sigma, seed + t)).to(dev) for t in range(nfr)]
+    sf = seq.SequenceFilter(ctx, w, h, ch, sigma, keep_history=False)
+    k = 0
+    for _ in range(1 + args.warmup):
+        sf.push(noisy[k % nfr].data_ptr())
+        k += 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sf.push(noisy[k % nfr].data_ptr())
+        k += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c1, n1 = cleans[(k - 1) % nfr], noisy[(k - 1) % nfr].cpu().numpy()
+    ms = dt / args.steps * 1e3
+    out = sf.download_rgb(sf.flt2)
+    res = {"metric": "Mpix/s per frame (flow + mask + nlkalman-flt x2, 1080p sigma=20, frames resident)",
+           "value": round(w * h / (dt / args.steps) / 1e6, 3), "unit": "Mpix/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"S1: {w}x{h}x{ch} sigma={sigma:g}, per frame: TV-L1 flow (lambda 0.40, fscale 1) "
+                                  "to the previous FLT2 output, occlusion mask (0.75), warp + FLT1, warp + FLT2 "
+                                  "(defaults of nlkalman_default_params), nothing leaves HBM",
+                      "parallelism": "single GPU",
+                      "flow_iterations_last_frame": sf.flow_iterations[-1]},
+           "psnr_flt2_db": round(float(synth.psnr(out, c1)), 4),
+           "psnr_noisy_db": round(float(synth.psnr(n1, c1)), 4)}
+    print(json.dumps(res))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,6 +256,9 @@ def main():
 
     ctx = pkg.Context(local)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    if args.workload == "S1":
+        bench_sequence(args, pkg, synth, ctx, torch, rank, world, dev)
+        return
     if args.workload == "F1":
         bench_flow(args, pkg, synth, ctx, torch, dist, rank, world, dev)
         if world > 1:

@@ -279,6 +279,9 @@ class Context:
     def free(self, dptr):
         self._chk(self.L.nlk_dev_free(self.h, dptr))
 
+    def d2d(self, d_dst, d_src, nbytes):
+        self._chk(self.L.nlk_d2d(self.h, d_dst, d_src, nbytes))
+
     def upload(self, arr):
         arr = np.ascontiguousarray(arr)
         d = self.alloc(arr.nbytes)
