@@ -179,20 +179,70 @@ struct NlkTvLevel {
   float l_t, theta, taut, eps2;
 };
 
+// ---- arithmetic cores, shared by every driver (identical rounding everywhere)
 // backward-difference divergence; the association order differs between the body, the
-// first/last column and the corners in the reference (mask.c:52-96) and is kept
+// first/last column and the corners in the reference (mask.c:52-96) and is kept. v1l = v1 of
+// the left neighbour, v2u = v2 of the upper one (ignored where the image has none)
+__device__ __forceinline__ float nlk_tv_div_core(float v1c, float v1l, float v2c, float v2u, bool top,
+                                                 bool bot, bool lef, bool rig) {
+#pragma clang fp contract(off)
+  if (!lef && !rig) {
+    const float ax = v1c - v1l;
+    if (!top && !bot) return ax + (v2c - v2u);
+    return top ? ax + v2c : ax - v2u;
+  }
+  if (!top && !bot) return lef ? v1c + v2c - v2u : -v1l + v2c - v2u;
+  if (top) return lef ? v1c + v2c : -v1l + v2c;
+  return lef ? v1c - v2u : -v1l - v2u;
+}
+
+// thresholding step + flow update (reference: tvl1flow_lib.c:172-230)
+__device__ __forceinline__ void nlk_tv_primal_core(float rho_c, float gx, float gy, float g, float a,
+                                                   float b, float dv1, float dv2, float l_t, float theta,
+                                                   float& na, float& nb) {
+#pragma clang fp contract(off)
+  const float rho = rho_c + (gx * a + gy * b);
+  float d1, d2;
+  if (rho < -l_t * g) {
+    d1 = l_t * gx;
+    d2 = l_t * gy;
+  } else if (rho > l_t * g) {
+    d1 = -l_t * gx;
+    d2 = -l_t * gy;
+  } else if (g < 1E-10) {
+    d1 = d2 = 0;
+  } else {
+    const float fi = -rho / g;
+    d1 = fi * gx;
+    d2 = fi * gy;
+  }
+  const float v1 = a + d1, v2 = b + d2;
+  na = v1 + theta * dv1;
+  nb = v2 + theta * dv2;
+}
+
+// dual update from the forward differences of the new flow (reference: tvl1flow_lib.c:233-250);
+// hypot and 1 + taut*g are evaluated in double there. hypot() in double, rounded to float: the
+// squares of floats are exact in double, so sqrt(x*x + y*y) carries two roundings of 2^-53 and
+// gives the same float as the C library's hypot (no scaling is needed for flow gradients)
+__device__ __forceinline__ void nlk_tv_dual_core(float& p11, float& p12, float& p21, float& p22, float ax,
+                                                 float ay, float bx, float by, float taut) {
+#pragma clang fp contract(off)
+  const double dax = ax, day = ay, dbx = bx, dby = by;
+  const float g1 = (float)sqrt(dax * dax + day * day);
+  const float g2 = (float)sqrt(dbx * dbx + dby * dby);
+  const float ng1 = (float)(1.0 + (double)(taut * g1));
+  const float ng2 = (float)(1.0 + (double)(taut * g2));
+  p11 = (p11 + taut * ax) / ng1;
+  p12 = (p12 + taut * ay) / ng1;
+  p21 = (p21 + taut * bx) / ng2;
+  p22 = (p22 + taut * by) / ng2;
+}
+
 __device__ __forceinline__ float nlk_tv_div(const float* __restrict__ v1, const float* __restrict__ v2,
                                             int p, int i, int j, int nx, int ny) {
-#pragma clang fp contract(off)
   const bool top = i == 0, bot = i == ny - 1, lef = j == 0, rig = j == nx - 1;
-  if (!lef && !rig) {
-    const float ax = v1[p] - v1[p - 1];
-    if (!top && !bot) return ax + (v2[p] - v2[p - nx]);
-    return top ? ax + v2[p] : ax - v2[p - nx];
-  }
-  if (!top && !bot) return lef ? v1[p] + v2[p] - v2[p - nx] : -v1[p - 1] + v2[p] - v2[p - nx];
-  if (top) return lef ? v1[p] + v2[p] : -v1[p - 1] + v2[p];
-  return lef ? v1[p] - v2[p - nx] : -v1[p - 1] - v2[p - nx];
+  return nlk_tv_div_core(v1[p], lef ? 0.f : v1[p - 1], v2[p], top ? 0.f : v2[p - nx], top, bot, lef, rig);
 }
 
 // centred gradient (reference: mask.c:148-214) and the zero start of the dual variables (:137-141)
@@ -226,57 +276,33 @@ __device__ __forceinline__ void nlk_tv_px_warp(const NlkTvLevel& L, int i, int j
   L.rho_c[p] = w - wx * a - wy * b - L.I0[p];
 }
 
-// first half of an iteration: thresholding step, divergence of the dual variables, new flow;
-// returns the squared update (reference: tvl1flow_lib.c:172-230)
+// first half of an iteration at one pixel of the level's arrays; returns the squared update
 __device__ __forceinline__ float nlk_tv_px_primal(const NlkTvLevel& L, int i, int j) {
 #pragma clang fp contract(off)
   const int nx = L.nx, p = i * nx + j;
-  const float l_t = L.l_t;
-  const float a = L.u1[p], b = L.u2[p], gx = L.I1wx[p], gy = L.I1wy[p], g = L.grad[p];
-  const float rho = L.rho_c[p] + (gx * a + gy * b);
-  float d1, d2;
-  if (rho < -l_t * g) {
-    d1 = l_t * gx;
-    d2 = l_t * gy;
-  } else if (rho > l_t * g) {
-    d1 = -l_t * gx;
-    d2 = -l_t * gy;
-  } else if (g < 1E-10) {
-    d1 = d2 = 0;
-  } else {
-    const float fi = -rho / g;
-    d1 = fi * gx;
-    d2 = fi * gy;
-  }
-  const float v1 = a + d1, v2 = b + d2;
-  const float na = v1 + L.theta * nlk_tv_div(L.p11, L.p12, p, i, j, nx, L.ny);
-  const float nb = v2 + L.theta * nlk_tv_div(L.p21, L.p22, p, i, j, nx, L.ny);
+  const float a = L.u1[p], b = L.u2[p];
+  float na, nb;
+  nlk_tv_primal_core(L.rho_c[p], L.I1wx[p], L.I1wy[p], L.grad[p], a, b,
+                     nlk_tv_div(L.p11, L.p12, p, i, j, nx, L.ny), nlk_tv_div(L.p21, L.p22, p, i, j, nx, L.ny),
+                     L.l_t, L.theta, na, nb);
   L.u1[p] = na;
   L.u2[p] = nb;
   return (na - a) * (na - a) + (nb - b) * (nb - b);
 }
 
-// second half: forward gradient of the new flow and dual update (reference: tvl1flow_lib.c:
-// 233-250, mask.c:98-141); hypot and 1 + taut*g are evaluated in double there
+// second half: forward gradient of the new flow (reference: mask.c:98-141) and dual update
 __device__ __forceinline__ void nlk_tv_px_dual(const NlkTvLevel& L, int i, int j) {
 #pragma clang fp contract(off)
   const int nx = L.nx, ny = L.ny, p = i * nx + j;
-  const float taut = L.taut;
   const float a = L.u1[p], b = L.u2[p];
   const float ax = j < nx - 1 ? L.u1[p + 1] - a : 0.f, ay = i < ny - 1 ? L.u1[p + nx] - a : 0.f;
   const float bx = j < nx - 1 ? L.u2[p + 1] - b : 0.f, by = i < ny - 1 ? L.u2[p + nx] - b : 0.f;
-  // hypot() in double, rounded to float: the squares of floats are exact in double, so
-  // sqrt(x*x + y*y) carries two roundings of 2^-53 and gives the same float as the C library's
-  // hypot (no overflow / underflow scaling is needed for flow gradients)
-  const double dax = ax, day = ay, dbx = bx, dby = by;
-  const float g1 = (float)sqrt(dax * dax + day * day);
-  const float g2 = (float)sqrt(dbx * dbx + dby * dby);
-  const float ng1 = (float)(1.0 + (double)(taut * g1));
-  const float ng2 = (float)(1.0 + (double)(taut * g2));
-  L.p11[p] = (L.p11[p] + taut * ax) / ng1;
-  L.p12[p] = (L.p12[p] + taut * ay) / ng1;
-  L.p21[p] = (L.p21[p] + taut * bx) / ng2;
-  L.p22[p] = (L.p22[p] + taut * by) / ng2;
+  float p11 = L.p11[p], p12 = L.p12[p], p21 = L.p21[p], p22 = L.p22[p];
+  nlk_tv_dual_core(p11, p12, p21, p22, ax, ay, bx, by, L.taut);
+  L.p11[p] = p11;
+  L.p12[p] = p12;
+  L.p21[p] = p21;
+  L.p22[p] = p22;
 }
 
 #define NLK_TV_WG_PIXELS 12288  // largest level solved by one workgroup (12 pixels per thread)
