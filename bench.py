@@ -95,9 +95,10 @@ def bench_flow(args, pkg, synth, ctx, torch, dist, rank, world, dev):
     if rank != 0:
         return
     ms = dt / args.steps * 1e3
-    # roofline of the dominant kernels (k_tv_primal + k_tv_dual at full size): a one-level run is
-    # nothing but their iterations (+ 5 warps); per iteration and pixel they read 16 and write
-    # 6 floats = 88 algorithmic bytes
+    # roofline of the dominant kernel (k_tv_block at full size): a one-level run is nothing but
+    # its iterations (+ 5 warps). Algorithmic bytes: an iteration reads 16 and writes 6 floats per
+    # pixel = 88 B; the kernel runs 4 iterations per launch on LDS tiles, so its real
+    # traffic is about a quarter of that and it is bound by LDS + VALU instead
     one = pkg.tvl1_params(w, h)
     one.nscales = 1
     it1 = ctx.tvl1_flow(flow.data_ptr(), g0.data_ptr(), g1.data_ptr(), w, h, one)
@@ -117,13 +118,14 @@ def bench_flow(args, pkg, synth, ctx, torch, dist, rank, world, dev):
                                   f"tau 0.25 lambda 0.15 theta 0.3, {prm.nscales} scales, 5 warps, epsilon 0.01",
                       "parallelism": "single GPU" if world == 1 else f"{world} independent replicas",
                       "iterations": iters},
-           "roofline": {"kernel": "k_tv_primal + k_tv_dual (one full-size iteration)", "bound": "hbm",
+           "roofline": {"kernel": "k_tv_block (full-size level, per iteration)", "bound": "hbm",
                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                         "iteration_us": round(t_iter * 1e6, 2), "algorithmic_bytes_per_iteration": 88 * w * h,
-                        "note": "measured on a one-level run (wall time / iterations, launches and the "
-                                "per-batch state read-back included); the 182 MB working set of an "
-                                "iteration lives in the 256 MB Infinity Cache"}}
+                        "note": "measured on a one-level run (wall time / iterations; launches, redone "
+                                "batches and state read-backs included). Algorithmic bytes of the plain "
+                                "recursion; temporal blocking (4 iterations per launch, halo recomputed) "
+                                "moves ~4x fewer"}}
     if not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle as O

@@ -23,6 +23,8 @@ struct NlkTvState {
   int stop_iter;   // multi-launch driver: iterations n > stop_iter of the current warp are no-ops
   int last;        // multi-launch driver: last executed iteration of the current warp
   float error;     // its mean squared update
+  int redo;        // blocked driver: iterations of batch redo_n0 to recompute (it over-ran the stop)
+  int redo_n0;
 };
 
 // ---- sampling (reference: bicubic_interpolation.c:26-41, 100-131, 140-236)
@@ -160,7 +162,7 @@ __global__ void k_tv_zoom(const float* __restrict__ in, float* __restrict__ out,
 // epsilon^2. The per-pixel steps are the device functions below (the reference's arithmetic,
 // type for type; u and p are updated in place: each step writes only what it read at the own
 // pixel). Two drivers use them:
-//  * levels of up to NLK_TV_WG_PIXELS pixels run ENTIRELY inside one 1024-thread workgroup
+//  * the smallest levels (up to NLK_TV_WG_PIXELS pixels) run ENTIRELY inside one 1024-thread workgroup
 //    (k_tv_level_wg): all warps and iterations, phases separated by workgroup barriers, the stop
 //    test evaluated in the kernel. An iteration costs ~1 us there instead of two launches of
 //    ~5 us each, and nothing is read back;
@@ -305,7 +307,7 @@ __device__ __forceinline__ void nlk_tv_px_dual(const NlkTvLevel& L, int i, int j
   L.p22[p] = p22;
 }
 
-#define NLK_TV_WG_PIXELS 12288  // largest level solved by one workgroup (12 pixels per thread)
+#define NLK_TV_WG_PIXELS 2100  // largest level solved by one workgroup (measured: 60 x 34 yes, 120 x 68 no)
 
 // fixed-order sum of one float per thread over a workgroup of NLK_TV_THREADS
 __device__ __forceinline__ float nlk_tv_block_sum(float e, float* redf) {
@@ -365,6 +367,8 @@ __global__ void __launch_bounds__(256) k_tv_warp(NlkTvLevel L) {
     L.st->stop_iter = NLK_TV_MAXIT;
     L.st->last = 0;
     L.st->error = INFINITY;
+    L.st->redo = 0;
+    L.st->redo_n0 = -1;
   }
 }
 
@@ -400,6 +404,159 @@ __global__ void __launch_bounds__(256) k_tv_dual(NlkTvLevel L, int n, int nparts
       L.st->iters += 1;
       if (!(err > L.eps2)) L.st->stop_iter = n;  // reference: tvl1flow_lib.c:166
     }
+  }
+}
+
+// ---- blocked driver: NLK_TV_K iterations per launch (temporal blocking). On the levels that
+// do not fit one workgroup a launch costs ~4 us whatever it does, and a full-size iteration
+// moves 88 B per pixel through the caches; both go down by running K iterations on a tile
+// held in LDS with a halo of K pixels (one iteration needs its neighbours' state one pixel
+// further in every direction: p from the left / top for the divergence, u from the right /
+// bottom for the gradient). Every region pixel is recomputed in every half iteration; what is
+// computed from stale halo data never reaches the tile. The tile's pixels get exactly the
+// values of the plain recursion.
+//   k_tv_block  reads state `in` (u, p after n0 iterations), writes `out` (after n0 + count)
+//               and one partial sum of squared updates per iteration and workgroup;
+//   k_tv_decide adds them in a fixed order, finds the first iteration that satisfies the stop
+//               test and, if the batch ran past it, asks for that batch to be redone from `in`
+//               with fewer iterations (k_tv_block with fix = 1: a no-op otherwise).
+#ifndef NLK_TV_K
+#define NLK_TV_K 4
+#endif
+#define NLK_TV_TW 64
+#define NLK_TV_TH 16
+#define NLK_TV_RW (NLK_TV_TW + 2 * NLK_TV_K)
+#define NLK_TV_RH (NLK_TV_TH + 2 * NLK_TV_K)
+#define NLK_TV_BT 1024  // threads of a k_tv_block workgroup: the coarse levels have few tiles, so a tile
+                        // must finish fast rather than leave room for others
+#define NLK_TV_RPT ((NLK_TV_RW * NLK_TV_RH + NLK_TV_BT - 1) / NLK_TV_BT)  // region pixels per thread
+
+struct NlkTvBuf {
+  float *u1, *u2, *p11, *p12, *p21, *p22;
+};
+
+__global__ void __launch_bounds__(NLK_TV_BT)
+k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int fix) {
+#pragma clang fp contract(off)
+  if (fix) {
+    if (L.st->redo_n0 != n0 || L.st->redo == 0) return;
+    count = L.st->redo;
+  } else if (n0 >= L.st->stop_iter) {
+    return;
+  }
+  __shared__ float s_u1[NLK_TV_RW * NLK_TV_RH], s_u2[NLK_TV_RW * NLK_TV_RH];
+  __shared__ float s_p11[NLK_TV_RW * NLK_TV_RH], s_p12[NLK_TV_RW * NLK_TV_RH];
+  __shared__ float s_p21[NLK_TV_RW * NLK_TV_RH], s_p22[NLK_TV_RW * NLK_TV_RH];
+  __shared__ float redf[NLK_TV_BT / 64];
+  const int nx = L.nx, ny = L.ny;
+  const int rx0 = blockIdx.x * NLK_TV_TW - NLK_TV_K, ry0 = blockIdx.y * NLK_TV_TH - NLK_TV_K;
+  const int nblocks = gridDim.x * gridDim.y, block = blockIdx.y * gridDim.x + blockIdx.x;
+  // the region pixels of this thread: index in the region, in the image, constants of the warp
+  int gidx[NLK_TV_RPT];
+  bool on[NLK_TV_RPT], mine[NLK_TV_RPT];
+  float rc[NLK_TV_RPT], gx[NLK_TV_RPT], gy[NLK_TV_RPT], gr[NLK_TV_RPT];
+#pragma unroll
+  for (int m = 0; m < NLK_TV_RPT; ++m) {
+    const int r = threadIdx.x + NLK_TV_BT * m;
+    const int ly = r / NLK_TV_RW, lx = r - ly * NLK_TV_RW;
+    const int j = rx0 + lx, i = ry0 + ly;
+    on[m] = r < NLK_TV_RW * NLK_TV_RH && j >= 0 && j < nx && i >= 0 && i < ny;
+    mine[m] = on[m] && lx >= NLK_TV_K && lx < NLK_TV_K + NLK_TV_TW && ly >= NLK_TV_K && ly < NLK_TV_K + NLK_TV_TH;
+    gidx[m] = on[m] ? i * nx + j : 0;
+    rc[m] = L.rho_c[gidx[m]]; gx[m] = L.I1wx[gidx[m]]; gy[m] = L.I1wy[gidx[m]]; gr[m] = L.grad[gidx[m]];
+    if (r < NLK_TV_RW * NLK_TV_RH) {
+      s_u1[r] = on[m] ? in.u1[gidx[m]] : 0.f;
+      s_u2[r] = on[m] ? in.u2[gidx[m]] : 0.f;
+      s_p11[r] = on[m] ? in.p11[gidx[m]] : 0.f;
+      s_p12[r] = on[m] ? in.p12[gidx[m]] : 0.f;
+      s_p21[r] = on[m] ? in.p21[gidx[m]] : 0.f;
+      s_p22[r] = on[m] ? in.p22[gidx[m]] : 0.f;
+    }
+  }
+  __syncthreads();
+  for (int k = 0; k < count; ++k) {
+    float e = 0.f;
+#pragma unroll
+    for (int m = 0; m < NLK_TV_RPT; ++m) {
+      if (!on[m]) continue;
+      const int r = threadIdx.x + NLK_TV_BT * m;
+      const int ly = r / NLK_TV_RW, lx = r - ly * NLK_TV_RW;
+      const int j = rx0 + lx, i = ry0 + ly;
+      const bool top = i == 0, bot = i == ny - 1, lef = j == 0, rig = j == nx - 1;
+      const int rl = lx > 0 ? r - 1 : r, ru = ly > 0 ? r - NLK_TV_RW : r;  // (region edge: value unused or stale halo)
+      const float a = s_u1[r], b = s_u2[r];
+      float na, nb;
+      nlk_tv_primal_core(rc[m], gx[m], gy[m], gr[m], a, b,
+                         nlk_tv_div_core(s_p11[r], s_p11[rl], s_p12[r], s_p12[ru], top, bot, lef, rig),
+                         nlk_tv_div_core(s_p21[r], s_p21[rl], s_p22[r], s_p22[ru], top, bot, lef, rig),
+                         L.l_t, L.theta, na, nb);
+      s_u1[r] = na;  // (u is read at the own pixel only in this half)
+      s_u2[r] = nb;
+      if (mine[m]) e += (na - a) * (na - a) + (nb - b) * (nb - b);
+    }
+    e = nlk_tv_block_sum(e, redf);  // (its barriers also publish the new u)
+    if (threadIdx.x == 0) L.part[k * nblocks + block] = e;
+#pragma unroll
+    for (int m = 0; m < NLK_TV_RPT; ++m) {
+      if (!on[m]) continue;
+      const int r = threadIdx.x + NLK_TV_BT * m;
+      const int ly = r / NLK_TV_RW, lx = r - ly * NLK_TV_RW;
+      const int j = rx0 + lx, i = ry0 + ly;
+      const int rr = lx < NLK_TV_RW - 1 ? r + 1 : r, rd = ly < NLK_TV_RH - 1 ? r + NLK_TV_RW : r;
+      const float a = s_u1[r], b = s_u2[r];
+      const float ax = j < nx - 1 ? s_u1[rr] - a : 0.f, ay = i < ny - 1 ? s_u1[rd] - a : 0.f;
+      const float bx = j < nx - 1 ? s_u2[rr] - b : 0.f, by = i < ny - 1 ? s_u2[rd] - b : 0.f;
+      float p11 = s_p11[r], p12 = s_p12[r], p21 = s_p21[r], p22 = s_p22[r];
+      nlk_tv_dual_core(p11, p12, p21, p22, ax, ay, bx, by, L.taut);
+      s_p11[r] = p11;  // (p is read at the own pixel only in this half)
+      s_p12[r] = p12;
+      s_p21[r] = p21;
+      s_p22[r] = p22;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int m = 0; m < NLK_TV_RPT; ++m) {
+    if (!mine[m]) continue;
+    const int r = threadIdx.x + NLK_TV_BT * m;
+    out.u1[gidx[m]] = s_u1[r];
+    out.u2[gidx[m]] = s_u2[r];
+    out.p11[gidx[m]] = s_p11[r];
+    out.p12[gidx[m]] = s_p12[r];
+    out.p21[gidx[m]] = s_p21[r];
+    out.p22[gidx[m]] = s_p22[r];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_tv_decide(NlkTvLevel L, int n0, int count, int nblocks) {
+  if (n0 >= L.st->stop_iter) return;
+  __shared__ double red[4];
+  __shared__ float errs[NLK_TV_K];
+  for (int k = 0; k < count; ++k) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += (double)L.part[k * nblocks + b];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float err = (float)((red[0] + red[1]) + (red[2] + red[3]));
+      errs[k] = err / (float)(L.nx * L.ny);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int done = count;
+    for (int k = 0; k < count; ++k)
+      if (!(errs[k] > L.eps2)) {  // reference: tvl1flow_lib.c:166
+        done = k + 1;
+        L.st->stop_iter = n0 + done;
+        if (done < count) { L.st->redo = done; L.st->redo_n0 = n0; }
+        break;
+      }
+    L.st->iters += done;
+    L.st->last = n0 + done;
+    L.st->error = errs[done - 1];
   }
 }
 

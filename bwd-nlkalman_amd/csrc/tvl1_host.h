@@ -39,7 +39,7 @@ int tv_gaussian(nlk_ctx* c, const float* in, float* out, float* tmp, int nx, int
 
 // one scale (reference: tvl1flow_lib.c:93-275)
 int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2, int nx, int ny,
-             const nlk_tvl1_params& P, float* work, float* part, NlkTvState* st) {
+             const nlk_tvl1_params& P, float* work, float* alt, float* part, NlkTvState* st) {
   const size_t n = (size_t)nx * ny;
   NlkTvLevel L;
   L.I0 = I0; L.I1 = I1; L.u1 = u1; L.u2 = u2;
@@ -57,23 +57,65 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
   const dim3 grid((nx + 63) / 64, (ny + 3) / 4);
   const int nparts = grid.x * grid.y;
   hipLaunchKernelGGL(k_tv_init, grid, dim3(256), 0, c->stream, L);
-  const int batch = getenv("NLK_TV_BATCH") ? atoi(getenv("NLK_TV_BATCH")) : 12;
+  if (getenv("NLK_TV_UNBLOCKED")) {  // one launch per half iteration (kept for comparison)
+    const int batch = getenv("NLK_TV_BATCH") ? atoi(getenv("NLK_TV_BATCH")) : 12;
+    for (int wi = 0; wi < P.nwarps; ++wi) {
+      hipLaunchKernelGGL(k_tv_warp, grid, dim3(256), 0, c->stream, L);
+      int launched = 0;
+      while (launched < NLK_TV_MAXIT) {
+        const int upto = launched + batch < NLK_TV_MAXIT ? launched + batch : NLK_TV_MAXIT;
+        for (int it = launched + 1; it <= upto; ++it) {
+          hipLaunchKernelGGL(k_tv_primal, grid, dim3(256), 0, c->stream, L, it);
+          hipLaunchKernelGGL(k_tv_dual, grid, dim3(256), 0, c->stream, L, it, nparts);
+        }
+        launched = upto;
+        HIPCHK(c, hipMemcpyAsync(c->tv_host, st, sizeof(NlkTvState), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->tv_host->stop_iter < NLK_TV_MAXIT || c->tv_host->last >= NLK_TV_MAXIT) break;
+      }
+    }
+    HIPCHK(c, hipGetLastError());
+    return NLK_OK;
+  }
+  // blocked driver: NLK_TV_K iterations per launch between two state buffers. A = the level's
+  // own arrays, B = a second set; the host launches batches ahead and reads the state every
+  // few batches; batches after the converged one are no-ops, so the final state sits in the
+  // buffer written by batch ceil(stop / K).
+  NlkTvBuf A = {u1, u2, L.p11, L.p12, L.p21, L.p22};
+  NlkTvBuf B = {alt, alt + n, alt + 2 * n, alt + 3 * n, alt + 4 * n, alt + 5 * n};
+  const dim3 bgrid((nx + NLK_TV_TW - 1) / NLK_TV_TW, (ny + NLK_TV_TH - 1) / NLK_TV_TH);
+  const int nblocks = bgrid.x * bgrid.y;
+  const int look = getenv("NLK_TV_LOOK") ? atoi(getenv("NLK_TV_LOOK")) : 4;  // batches between two looks at the state
   for (int wi = 0; wi < P.nwarps; ++wi) {
     hipLaunchKernelGGL(k_tv_warp, grid, dim3(256), 0, c->stream, L);
-    // the host launches iterations in batches and looks at the state between them, so no
-    // launch waits for a read-back; iterations past the converged one return at once
-    int launched = 0;
-    while (launched < NLK_TV_MAXIT) {
-      const int upto = launched + batch < NLK_TV_MAXIT ? launched + batch : NLK_TV_MAXIT;
-      for (int it = launched + 1; it <= upto; ++it) {
-        hipLaunchKernelGGL(k_tv_primal, grid, dim3(256), 0, c->stream, L, it);
-        hipLaunchKernelGGL(k_tv_dual, grid, dim3(256), 0, c->stream, L, it, nparts);
+    NlkTvBuf cur = {L.u1, L.u2, L.p11, L.p12, L.p21, L.p22};
+    const bool cur_is_a = cur.u1 == A.u1;
+    NlkTvBuf oth = cur_is_a ? B : A;
+    int n0 = 0, batches = 0;
+    while (n0 < NLK_TV_MAXIT) {
+      for (int q = 0; q < look && n0 < NLK_TV_MAXIT; ++q) {
+        const int count = NLK_TV_MAXIT - n0 < NLK_TV_K ? NLK_TV_MAXIT - n0 : NLK_TV_K;
+        hipLaunchKernelGGL(k_tv_block, bgrid, dim3(NLK_TV_BT), 0, c->stream, L, cur, oth, n0, count, 0);
+        hipLaunchKernelGGL(k_tv_decide, dim3(1), dim3(256), 0, c->stream, L, n0, count, nblocks);
+        hipLaunchKernelGGL(k_tv_block, bgrid, dim3(NLK_TV_BT), 0, c->stream, L, cur, oth, n0, count, 1);
+        const NlkTvBuf t = cur; cur = oth; oth = t;
+        n0 += count;
+        ++batches;
       }
-      launched = upto;
       HIPCHK(c, hipMemcpyAsync(c->tv_host, st, sizeof(NlkTvState), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       if (c->tv_host->stop_iter < NLK_TV_MAXIT || c->tv_host->last >= NLK_TV_MAXIT) break;
     }
+    // where the state of iteration `last` lives: written by batch ceil(last / K), batches alternate
+    const int used = (c->tv_host->last + NLK_TV_K - 1) / NLK_TV_K;
+    const bool final_is_start = (used % 2) == 0;
+    const NlkTvBuf fin = final_is_start ? (cur_is_a ? A : B) : (cur_is_a ? B : A);
+    L.u1 = fin.u1; L.u2 = fin.u2; L.p11 = fin.p11; L.p12 = fin.p12; L.p21 = fin.p21; L.p22 = fin.p22;
+    (void)batches;
+  }
+  if (L.u1 != u1) {  // the level's flow belongs in the pyramid arrays
+    HIPCHK(c, hipMemcpyAsync(u1, L.u1, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(u2, L.u2, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
   }
   HIPCHK(c, hipGetLastError());
   return NLK_OK;
@@ -132,7 +174,7 @@ int nlk_dev_tvl1_flow(nlk_ctx* c, float* flow, const float* I0, const float* I1,
   const size_t n0 = (size_t)w * h;
   // scratch: 4 pyramids (I0, I1, u1, u2) + 10 work images + 2 temporaries at full size + partial sums
   const size_t nparts0 = (size_t)((w + 63) / 64) * ((h + 3) / 4);  // workgroups of an iteration kernel at full size
-  const size_t floats = 4 * pyr + 12 * n0 + nparts0 + 64;
+  const size_t floats = 4 * pyr + 18 * n0 + NLK_TV_K * nparts0 + 64;
   int rc = reserve(c, c->tv, sizeof(float) * floats);
   if (rc) return rc;
   if (!c->tv_host) HIPCHK(c, hipHostMalloc((void**)&c->tv_host, sizeof(NlkTvState)));
@@ -146,7 +188,8 @@ int nlk_dev_tvl1_flow(nlk_ctx* c, float* flow, const float* I0, const float* I1,
   float* work = q; q += 10 * n0;
   float* tmp = q; q += n0;
   float* tmp2 = q; q += n0;
-  float* part = q; q += nparts0;
+  float* alt = q; q += 6 * n0;  // second state buffer of the blocked driver
+  float* part = q; q += NLK_TV_K * nparts0;
   NlkTvState* st = (NlkTvState*)q;  // 64 floats reserved
   int* mm = (int*)(q + 8);
 
@@ -175,7 +218,7 @@ int nlk_dev_tvl1_flow(nlk_ctx* c, float* flow, const float* I0, const float* I1,
   const float inv = (float)1.0 / P->zfactor;
   for (int s = ns - 1; s >= 0; --s) {
     if (s >= P->fscale)
-      if ((rc = tv_scale(c, I0s[s], I1s[s], U1[s], U2[s], W[s], H[s], *P, work, part, st))) return rc;
+      if ((rc = tv_scale(c, I0s[s], I1s[s], U1[s], U2[s], W[s], H[s], *P, work, alt, part, st))) return rc;
     if (s == 0) break;
     const float fx = (float)W[s - 1] / W[s], fy = (float)H[s - 1] / H[s];  // zoom.c:94-95
     for (int k = 0; k < 2; ++k)
