@@ -51,6 +51,7 @@ class SequenceFilter:
         self.d_flow = a(w * h * 8)
         self.flt1, self.flt2 = None, None   # previous outputs (opponent space, device)
         self.history = [] if keep_history else None  # flt2 of every frame, for smooth()
+        self._pool = []                      # released frame buffers (no hipMalloc / hipFree per frame)
         self.t = 0
         self.flow_iterations = []
 
@@ -70,7 +71,7 @@ class SequenceFilter:
         c, w, h, ch, sg = self.ctx, self.w, self.h, self.ch, self.sigma
         c.d2d(self.d_noisy, d_noisy_rgb, self.nbytes)
         c.rgb2opp(self.d_noisy, w, h, ch)
-        n1, n2 = c.alloc(self.nbytes), c.alloc(self.nbytes)
+        n1, n2 = self._frame(), self._frame()
         if self.t == 0:
             c.filter_frame(n1, self.d_noisy, None, None, w, h, ch, sg, self.f1)
             c.filter_frame(n2, self.d_noisy, None, n1, w, h, ch, sg, self.f2)
@@ -81,13 +82,16 @@ class SequenceFilter:
             c.warp_bicubic(self.d_warp, self.flt2, self.d_flow, self.d_occ, w, h, ch)
             c.filter_frame(n2, self.d_noisy, self.d_warp, n1, w, h, ch, sg, self.f2)
         if self.flt1:
-            c.free(self.flt1)
+            self._pool.append(self.flt1)
         if self.flt2 and self.history is None:
-            c.free(self.flt2)
+            self._pool.append(self.flt2)
         self.flt1, self.flt2 = n1, n2
         if self.history is not None:
             self.history.append(n2)
         self.t += 1
+
+    def _frame(self):
+        return self._pool.pop() if self._pool else self.ctx.alloc(self.nbytes)
 
     def smooth(self, of_lambda=None, of_fscale=None, occ_th=None):
         """Backward pass over the kept flt2 frames; returns the list of smoothed frames
