@@ -110,6 +110,11 @@ def bench_flow(args, pkg, synth, ctx, torch, dist, rank, world, dev):
     torch.cuda.synchronize()
     t_iter = (time.perf_counter() - t1) / reps / max(it1, 1)
     gbs = 88.0 * w * h / t_iter / 1e9
+    traffic = None  # HBM-side bytes per iteration from the committed PMC passes (profiles/r01_traffic.json)
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if world == 1 and os.path.exists(tpath):
+        tb = json.load(open(tpath))["kernels"].get("k_tv_block", {}).get("traffic_bytes")
+        traffic = tb / 4 if tb else None  # a launch = 4 iterations
     res = {"metric": "Mpix/s per flow (tvl1flow, 1080p, default parameters)", "value": round(world * w * h / (dt / args.steps) / 1e6, 3),
            "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -120,7 +125,7 @@ def bench_flow(args, pkg, synth, ctx, torch, dist, rank, world, dev):
                       "iterations": iters},
            "roofline": {"kernel": "k_tv_block (full-size level, per iteration)", "bound": "hbm",
                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "iteration_us": round(t_iter * 1e6, 2), "algorithmic_bytes_per_iteration": 88 * w * h,
                         "note": "measured on a one-level run (wall time / iterations; launches, redone "
                                 "batches and state read-backs included). Algorithmic bytes of the plain "
