@@ -387,16 +387,17 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
 #pragma unroll
       for (int q = 0; q < 4; ++q) Y[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
       if (SMO) {
-        float Fp[4][4];
+        // (one folded operand set at a time: image member first, then its previous-frame patch)
         nlk_f4 Yp[4];
-        nlk_fold(Rp, Fp);
+        __builtin_amdgcn_sched_barrier(0);
+        nlk_mfma_fwd<true>(F, dA, Y);
+        nlk_fold(Rp, F);
         nlk_rows_load(psrc + offn, g.w, g4, Rp);
         offn = member_off(n0 + 8);
         __builtin_amdgcn_sched_barrier(0);
-        nlk_mfma_fwd<true>(F, dA, Y);
 #pragma unroll
         for (int q = 0; q < 4; ++q) Yp[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
-        nlk_mfma_fwd<true>(Fp, dA, Yp);
+        nlk_mfma_fwd<true>(F, dA, Yp);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const nlk_f4 gq = *reinterpret_cast<const nlk_f4*>(st_g + 16 * q);
