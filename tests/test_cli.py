@@ -67,6 +67,19 @@ def test_help_and_usage(tools):
         assert flag in r.stdout, flag
 
 
+def test_sequence_tool_usage_and_missing_frames(tools, tmp_path):
+    """bin/nlkalman-seq (one-process scripts/nlkalman-seq.sh): argument errors are reported
+    before any GPU work, with the script's own message for a missing frame (:19-28)."""
+    r = run("nlkalman-seq")
+    assert r.returncode == 1 and "SEQ FFR LFR SIG OUT [STP [FPM [SPM [OPM]]]]" in r.stderr
+    r = run("nlkalman-seq", tmp_path / "%03d.tif", 1, 3, 20, tmp_path / "out")
+    assert r.returncode == 1 and r.stdout.startswith("ERROR: ") and "001.tif not found" in r.stdout
+    r = run("nlkalman-seq", tmp_path / "%03d.tif", 1, 3, 20, tmp_path / "out", 1, "", "", "1 2 3")
+    assert r.returncode == 1 and "OPM must hold 6 numbers" in r.stderr
+    r = run("nlkalman-seq", tmp_path / "%03d.tif", 1, 3, 20, tmp_path / "out", 1, "--f9_p 3")
+    assert r.returncode == 1
+
+
 def test_error_paths(tools):
     r = run("nlkalman-flt", "--bogus")
     assert r.returncode == 1 and "unknown option `--bogus`" in r.stderr and "Usage:" in r.stdout

@@ -106,3 +106,49 @@ def test_sequence_without_history_frees_frames(ctx, built, synth):
     assert np.isfinite(ctx.download(sf.flt2, (H, W, 1))).all()
     with pytest.raises(RuntimeError):
         sf.smooth()
+
+
+def test_one_process_tool_equals_the_driver(ctx, built, O, synth, tmp_path):
+    """bin/nlkalman-seq = scripts/nlkalman-seq.sh in one process: same positional arguments, same
+    files in the output folder; its frames equal the Python driver's (same C-ABI calls)."""
+    import os
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_cli import run
+    seq = importlib.import_module("bwd-nlkalman_amd.sequence")
+    frames = _frames(synth)
+    src = tmp_path / "in"
+    src.mkdir()
+    # float TIFF inputs: PFM written here (top row first, no flip), converted by nlk-imgconv
+    from test_cli import rpfm, wpfm
+    for t, f in enumerate(frames):
+        wpfm(src / f"{t + 3:03d}.pfm", f)
+        r = run("nlk-imgconv", src / f"{t + 3:03d}.pfm", src / f"{t + 3:03d}.tif")
+        assert r.returncode == 0, r.stderr
+    out = tmp_path / "out"
+    r = run("nlkalman-seq", src / "%03d.tif", 3, 3 + NF - 1, SIGMA, out, 1, "", "", "0 0.40 0.75 0 0.40 0.75")
+    assert r.returncode == 0, r.stderr + r.stdout
+    names = sorted(os.listdir(out))
+    for t in range(3, 3 + NF):
+        assert f"flt1-{t:03d}.tif" in names and f"flt2-{t:03d}.tif" in names and f"smo1-{t:03d}.tif" in names
+    assert "bflo1-004.flo" in names and "bocc1-004.png" in names and "fflo-003.flo" in names and "focc-003.png" in names
+    assert "bflo1-003.flo" not in names
+
+    def rd(name):
+        r2 = run("nlk-imgconv", out / name, tmp_path / "x.pfm")
+        assert r2.returncode == 0, r2.stderr
+        return rpfm(tmp_path / "x.pfm")
+    sf = seq.SequenceFilter(ctx, W, H, CH, SIGMA, of_lambda=0.40, of_fscale=0, occ_th=0.75)
+    for f in frames:
+        d = ctx.upload(f)
+        sf.push(d)
+        ctx.free(d)
+    smo = sf.smooth()
+    want2 = sf.download_rgb(sf.flt2)
+    cases.assert_close(rd(f"flt2-{3 + NF - 1:03d}.tif"), want2, "flt2 of the last frame", flips=10)
+    cases.assert_close(rd("smo1-003.tif"), sf.download_rgb(smo[0]), "smo1 of the first frame", flips=10)
+    # usage / error paths need no GPU work
+    assert run("nlkalman-seq").returncode == 1
+    r = run("nlkalman-seq", src / "%03d.tif", 3, 9, SIGMA, out)
+    assert r.returncode == 1 and "not found" in r.stdout
