@@ -48,8 +48,10 @@ __device__ inline void nlk_wave_lds_fence() {
 
 // Distances + selection for one target whose window holds n <= 64*M candidates.
 // Leaves the k kept candidates, sorted, in sel[0..k).
+// (forced inline: as a real call the LDS tile pointer becomes a generic one, the candidate reads
+// turn into FLAT loads and the spatial search runs 3x slower)
 template <int PSZ, int CH, int M>
-__device__ inline void nlk_match_target(const float* __restrict__ tile, int plane, int rwp,
+__device__ __forceinline__ void nlk_match_target(const float* __restrict__ tile, int plane, int rwp,
                                         const float* __restrict__ tgt, int tplane, int trw,
                                         int cbase, int nwx, int n, int k, int x0, int y0,
                                         uint64_t* __restrict__ surv, uint32_t* __restrict__ sel,
@@ -167,7 +169,7 @@ __device__ inline void nlk_match_target(const float* __restrict__ tile, int plan
 // Group membership, records and mark word of one target whose sorted k-NN list is in sel[0..k)
 // (reference: src/nlkalman.c:725-732, 779-793, 857, 931; smoother :1669-1676, :1844).
 template <int PSZ>
-__device__ inline void nlk_match_epilogue(const NlkGeom& g, size_t t, int px, int py, int prev_p,
+__device__ __forceinline__ void nlk_match_epilogue(const NlkGeom& g, size_t t, int px, int py, int prev_p,
                                           int k, const uint32_t* __restrict__ sel,
                                           uint32_t* __restrict__ grp,
                                           const uint8_t* __restrict__ vmap,
