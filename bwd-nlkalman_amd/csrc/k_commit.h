@@ -109,7 +109,8 @@ k_mask_commit(const uint64_t* __restrict__ marks, uint8_t* __restrict__ active, 
 // the last R lanes of a wavefront publish their masks through an LDS ring, and
 // the next wavefront (which runs one phase of 16 steps behind) polls a progress
 // word once per phase before consuming them. A step is ~40 instructions instead of an LDS
-// round trip + atomics + workgroup barrier.
+// round trip + atomics + workgroup barrier. The step itself is branch-free bit arithmetic on
+// 32-bit registers (the mark word is pre-shifted when it is fetched).
 // ---------------------------------------------------------------------------
 #define NLK_CW_RING 64  // steps of edge data kept per wavefront
 
@@ -129,16 +130,23 @@ k_mask_commit_wave(const uint64_t* __restrict__ marks, uint8_t* __restrict__ act
   if (lane == 0) prog[wave] = 0;
   __syncthreads();
   const int nsteps = ngx + skew * (ngy - 1);
+  // mark words are fetched one phase ahead as they are (nothing may consume a loaded value
+  // before the phase that uses it, or every load is waited for on the spot); 0 outside the grid,
+  // so such steps mark nothing
   auto fetch = [&](int s) -> uint64_t {
     const int i = s - skew * j;
     return (j < ngy && i >= 0 && i < ngx) ? marks[(size_t)j * ngx + i] : 0ull;
   };
+  // forward part of a mark word: the bits after the target itself (same row, then the rows
+  // below), at most R + R*side <= 24 of them
+  auto fwd_bits = [&](uint64_t mw) -> uint32_t { return (uint32_t)(mw >> (centre + 1)); };
   auto ld_prog = [&](int w) {
     return __hip_atomic_load(&prog[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
-  uint64_t A[S], B[S];
+  uint32_t A[S];
+  uint64_t B[S];
 #pragma unroll
-  for (int e = 0; e < S; ++e) A[e] = fetch(e);
+  for (int e = 0; e < S; ++e) A[e] = fwd_bits(fetch(e));
   uint32_t pend = 0;  // bit b: column (current + b) of this row is already marked
   uint32_t outp = 0;  // row masks this lane produced in the previous step, `side` bits per dj
   for (int s0 = 0; s0 < nsteps; s0 += S) {
@@ -173,24 +181,22 @@ k_mask_commit_wave(const uint64_t* __restrict__ marks, uint8_t* __restrict__ act
 #pragma unroll
     for (int e = 0; e < S; ++e) {
       const int s = s0 + e;
-      // ---- marks produced one step ago by the R rows above (inside this wavefront by DPP)
+      // ---- marks produced one step ago by the R rows above (inside this wavefront by DPP;
+      // wave_shr zero-fills, so the first lanes receive nothing from beyond the wavefront)
       uint32_t sh = outp, inc = above[e];
 #pragma unroll
       for (int dj = 1; dj <= R; ++dj) {
         sh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sh, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
-        const uint32_t m = (sh >> ((dj - 1) * side)) & rowmask;
-        inc |= (lane >= dj ? m : 0u) << (skew * dj - 1 - R);
+        inc |= ((sh >> ((dj - 1) * side)) & rowmask) << (skew * dj - 1 - R);
       }
       pend |= inc;
-      // ---- decide this row's target of step s
-      const int i = s - skew * j;
-      const bool in = j < ngy && i >= 0 && i < ngx;
-      const bool act = in && !(pend & 1u);
-      flags[e / 4] |= (uint32_t)act << (8 * (e % 4));
-      const uint64_t fwd = act ? (A[e] >> (centre + 1)) : 0ull;
-      const uint32_t own = (uint32_t)fwd & ((1u << R) - 1u);   // same row, columns i+1 .. i+R
-      outp = (uint32_t)(fwd >> R) & ((1u << (R * side)) - 1u);  // rows below, side bits per dj
-      pend = (pend >> 1) | own;
+      // ---- decide this row's target of step s: pure bit arithmetic, no compare / select
+      // (outside the grid the mark word is 0 and the decision is never stored)
+      const uint32_t act = ~pend & 1u;
+      flags[e / 4] |= act << (8 * (e % 4));
+      const uint32_t fwd = A[e] & (0u - act);
+      outp = (fwd >> R) & ((1u << (R * side)) - 1u);  // rows below, side bits per dj
+      pend = (pend >> 1) | (fwd & ((1u << R) - 1u));  // same row, columns i+1 .. i+R
       if (lane >= 64 - R) edge[wave][s % NLK_CW_RING][lane - (64 - R)] = outp;
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);  // this phase's edge words are in LDS
@@ -213,6 +219,12 @@ k_mask_commit_wave(const uint64_t* __restrict__ marks, uint8_t* __restrict__ act
       }
     }
 #pragma unroll
-    for (int e = 0; e < S; ++e) A[e] = B[e];
+    for (int e = 0; e < S; ++e) {
+      // (opaque to the optimiser: it would otherwise sink this shift into the conditional load
+      // above, and wait for each of the 16 loads on the spot)
+      uint32_t lo = (uint32_t)B[e], hi = (uint32_t)(B[e] >> 32);
+      asm volatile("" : "+v"(lo), "+v"(hi));
+      A[e] = fwd_bits(((uint64_t)hi << 32) | lo);
+    }
   }
 }
