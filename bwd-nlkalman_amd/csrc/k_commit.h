@@ -114,9 +114,24 @@ k_mask_commit(const uint64_t* __restrict__ marks, uint8_t* __restrict__ active, 
 // ---------------------------------------------------------------------------
 #define NLK_CW_RING 64  // steps of edge data kept per wavefront
 
+// Pre-pass: the forward part of every mark word (the bits after the target itself: same row,
+// then the rows below; at most R + R*side <= 24 bits), stored by STEP of the replay:
+// skewed[(i + (R+1)*j) * rows + j]. Lane j of k_mask_commit_wave then reads word s*rows + j at
+// step s: one coalesced, unconditional 256-byte load per wavefront instead of 64 cache lines
+// under a branch (entries outside the grid stay 0 and mark nothing).
+template <int R>
+__global__ void k_marks_skew(const uint64_t* __restrict__ marks, uint32_t* __restrict__ skewed, int ngx,
+                             int ngy, int rows) {
+  constexpr int side = 2 * R + 1, centre = R * side + R;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ngx * ngy) return;
+  const int j = t / ngx, i = t - j * ngx;
+  skewed[(size_t)(i + (R + 1) * j) * rows + j] = (uint32_t)(marks[t] >> (centre + 1));
+}
+
 template <int R>
 __global__ void __launch_bounds__(1024)
-k_mask_commit_wave(const uint64_t* __restrict__ marks, uint8_t* __restrict__ active, int ngx,
+k_mask_commit_wave(const uint32_t* __restrict__ skewed, uint8_t* __restrict__ active, int ngx,
                    int ngy) {
   constexpr int side = 2 * R + 1, skew = R + 1, centre = R * side + R;
   constexpr uint32_t rowmask = (1u << side) - 1u;
@@ -130,23 +145,14 @@ k_mask_commit_wave(const uint64_t* __restrict__ marks, uint8_t* __restrict__ act
   if (lane == 0) prog[wave] = 0;
   __syncthreads();
   const int nsteps = ngx + skew * (ngy - 1);
-  // mark words are fetched one phase ahead as they are (nothing may consume a loaded value
-  // before the phase that uses it, or every load is waited for on the spot); 0 outside the grid,
-  // so such steps mark nothing
-  auto fetch = [&](int s) -> uint64_t {
-    const int i = s - skew * j;
-    return (j < ngy && i >= 0 && i < ngx) ? marks[(size_t)j * ngx + i] : 0ull;
-  };
-  // forward part of a mark word: the bits after the target itself (same row, then the rows
-  // below), at most R + R*side <= 24 of them
-  auto fwd_bits = [&](uint64_t mw) -> uint32_t { return (uint32_t)(mw >> (centre + 1)); };
+  // (blockDim.x = rows of the skewed array; it holds 2 phases of zero rows past the last step)
+  auto fetch = [&](int s) -> uint32_t { return skewed[(size_t)s * blockDim.x + j]; };
   auto ld_prog = [&](int w) {
     return __hip_atomic_load(&prog[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
-  uint32_t A[S];
-  uint64_t B[S];
+  uint32_t A[S], B[S];
 #pragma unroll
-  for (int e = 0; e < S; ++e) A[e] = fwd_bits(fetch(e));
+  for (int e = 0; e < S; ++e) A[e] = fetch(e);
   uint32_t pend = 0;  // bit b: column (current + b) of this row is already marked
   uint32_t outp = 0;  // row masks this lane produced in the previous step, `side` bits per dj
   for (int s0 = 0; s0 < nsteps; s0 += S) {
@@ -219,12 +225,6 @@ k_mask_commit_wave(const uint64_t* __restrict__ marks, uint8_t* __restrict__ act
       }
     }
 #pragma unroll
-    for (int e = 0; e < S; ++e) {
-      // (opaque to the optimiser: it would otherwise sink this shift into the conditional load
-      // above, and wait for each of the 16 loads on the spot)
-      uint32_t lo = (uint32_t)B[e], hi = (uint32_t)(B[e] >> 32);
-      asm volatile("" : "+v"(lo), "+v"(hi));
-      A[e] = fwd_bits(((uint64_t)hi << 32) | lo);
-    }
+    for (int e = 0; e < S; ++e) A[e] = B[e];
   }
 }

@@ -39,6 +39,7 @@ struct nlk_ctx {
   hipStream_t stream = nullptr;
   char err[512] = "";
   Buf pl_cur, pl_prev, pl_basic, rowok, vmap, topk, tinfo, gcoords, marks, active, acc, tabs, wide;
+  Buf skew;                       // mark words in replay-step order (k_marks_skew)
   Buf tv;                         // TV-L1 pyramids and work images
   NlkTvState* tv_host = nullptr;  // pinned: the solver state read back between iteration batches
   int tabs_psz = 0;
@@ -337,7 +338,7 @@ void nlk_ctx_destroy(nlk_ctx* c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   Buf* bufs[] = {&c->pl_cur, &c->pl_prev, &c->pl_basic, &c->rowok, &c->vmap, &c->topk,
-                 &c->tinfo, &c->gcoords, &c->marks, &c->active, &c->acc, &c->tabs, &c->wide, &c->tv};
+                 &c->tinfo, &c->gcoords, &c->marks, &c->active, &c->acc, &c->tabs, &c->wide, &c->tv, &c->skew};
   for (Buf* b : bufs)
     if (b->p) hipFree(b->p);
   if (c->tv_host) (void)hipHostFree(c->tv_host);
@@ -595,8 +596,16 @@ static int run_commit(nlk_ctx* c, const uint64_t* marks, uint8_t* active, int ng
     HIPCHK(c, hipMemsetAsync(active, 1, (size_t)ngrid, c->stream));
   } else if (ngy <= 1024 && R <= 3 && !getenv("NLK_COMMIT_LDS")) {
     const int threads = ((ngy + 63) / 64) * 64;
+    const int nsteps = ngx + (R + 1) * (ngy - 1);
+    const size_t sk_bytes = sizeof(uint32_t) * (size_t)(nsteps + 2 * 16 + 16) * threads;
+    int rc = reserve(c, c->skew, sk_bytes);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->skew.p, 0, sk_bytes, c->stream));
+    auto pre = R == 1 ? k_marks_skew<1> : (R == 2 ? k_marks_skew<2> : k_marks_skew<3>);
+    hipLaunchKernelGGL(pre, dim3((ngrid + 255) / 256), dim3(256), 0, c->stream, marks, (uint32_t*)c->skew.p,
+                       ngx, ngy, threads);
     auto kern = R == 1 ? k_mask_commit_wave<1> : (R == 2 ? k_mask_commit_wave<2> : k_mask_commit_wave<3>);
-    hipLaunchKernelGGL(kern, dim3(1), dim3(threads), 0, c->stream, marks, active, ngx, ngy);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(threads), 0, c->stream, (const uint32_t*)c->skew.p, active, ngx, ngy);
     HIPCHK(c, hipGetLastError());
   } else {
     const int rpt = (ngy + 1023) / 1024;
