@@ -435,16 +435,18 @@ def test_randomised_parameters_and_shapes(ctx, built, O):
     size, clipped windows, k larger than the window, group sizes above k, NaN
     holes, second-iteration and smoother calls. Integer records exact, pixels
     within tolerance, for each of them."""
-    rng = np.random.default_rng(2024)
+    # (NLK_RANDOM_SEED / NLK_RANDOM_COUNT run other or longer sequences, e.g. as a soak test)
+    rng = np.random.default_rng(int(os.environ.get("NLK_RANDOM_SEED", 2024)))
+    want = int(os.environ.get("NLK_RANDOM_COUNT", 40))
     done = 0
-    for it in range(200):
-        if done == 40:
+    for it in range(5 * want):
+        if done == want:
             break
         psz = int(rng.choice([4, 6, 8, 8, 8, 10, 12, 12, 16]))
         step = psz // 2
         ch = int(rng.choice([1, 3]))
-        w = int(rng.integers(psz, 90))
-        h = int(rng.integers(psz, 70))
+        w = int(rng.integers(psz, int(os.environ.get("NLK_RANDOM_MAXW", 90))))
+        h = int(rng.integers(psz, int(os.environ.get("NLK_RANDOM_MAXH", 70))))
         smoother = rng.random() < 0.25
         wsz_t = int(rng.integers(1, min(15, 3 * step + step - 1) + 1))
         wsz_x = int(rng.integers(1, min(15, 3 * step + step - 1) + 1))
@@ -479,4 +481,4 @@ def test_randomised_parameters_and_shapes(ctx, built, O):
         _check_records(rec, tr, what)
         cases.assert_close(g, r, what, maxabs=5e-3, rmse=5e-4)
         done += 1
-    assert done == 40
+    assert done == want
