@@ -108,9 +108,9 @@ k_mask_commit(const uint64_t* __restrict__ marks, uint8_t* __restrict__ active, 
 // (R+1)^2 columns; a row's own forward marks go into the same register. Only
 // the last R lanes of a wavefront publish their masks through an LDS ring, and
 // the next wavefront (which runs one phase of 16 steps behind) polls a progress
-// word once per phase before consuming them. A step is ~40 instructions instead of an LDS
-// round trip + atomics + workgroup barrier. The step itself is branch-free bit arithmetic on
-// 32-bit registers (the mark word is pre-shifted when it is fetched).
+// word once per phase before consuming them. A step is 13 branch-free instructions on
+// 32-bit registers (the forward bits of the mark words arrive pre-shifted and ordered by step from
+// k_marks_skew) instead of an LDS round trip + atomics + workgroup barrier.
 // ---------------------------------------------------------------------------
 #define NLK_CW_RING 64  // steps of edge data kept per wavefront
 

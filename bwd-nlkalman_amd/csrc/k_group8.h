@@ -17,7 +17,7 @@
 // Group members are re-transformed once the gains are known (two members per
 // step in the filter: one in the sel = 0 lanes, one in the sel = 1 lanes).
 //
-// Aggregation. A workgroup is ONE wavefront that owns a tile of 4 x 4 targets
+// Aggregation. A workgroup is ONE wavefront that owns a tile of 4 x 1 targets
 // and a private LDS accumulator tile (ch value planes + 1 weight plane, covering
 // the tile plus the search halo). Being private, the tile is updated with plain
 // ds_read / add / ds_write (LDS float atomics retire about one lane per clock on
