@@ -29,7 +29,7 @@ HIP_SYMBOLS = [
     "nlk_dev_frame_accumulate", "nlk_dev_frame_normalize", "nlk_ctx_read_records",
     "nlk_dev_strip_match", "nlk_dev_mask_commit", "nlk_dev_strip_group",
     "nlk_tvl1_default_params", "nlk_tvl1_scales", "nlk_dev_tvl1_flow", "nlk_dev_gray",
-    "nlk_dev_occlusion_mask",
+    "nlk_dev_occlusion_mask", "nlk_dev_image_dct", "nlk_dev_copy_block",
 ]
 API_SYMBOLS = [
     "rgb2opp", "opp2rgb", "warp_bicubic", "nlkalman_default_params",
@@ -126,6 +126,8 @@ def hip():
         L.nlk_dev_tvl1_flow.argtypes = [vp, fp, fp, fp, i, i, C.POINTER(Tvl1Params), C.POINTER(i)]
         L.nlk_dev_gray.argtypes = [vp, fp, fp, i, i, i]
         L.nlk_dev_occlusion_mask.argtypes = [vp, fp, fp, i, i, f]
+        L.nlk_dev_image_dct.argtypes = [vp, fp, i, i, i, i]
+        L.nlk_dev_copy_block.argtypes = [vp, fp, i, fp, i, i, i, i]
         _hip = L
     return _hip
 
@@ -322,6 +324,12 @@ class Context:
 
     def occlusion_mask(self, d_mask, d_flow, w, h, th):
         self._chk(self.L.nlk_dev_occlusion_mask(self.h, d_mask, d_flow, w, h, float(th)))
+
+    def image_dct(self, d_img, w, h, ch, inverse=False):
+        self._chk(self.L.nlk_dev_image_dct(self.h, d_img, w, h, ch, int(inverse)))
+
+    def copy_block(self, d_dst, dw, d_src, sw, ch, bw, bh):
+        self._chk(self.L.nlk_dev_copy_block(self.h, d_dst, dw, d_src, sw, ch, bw, bh))
 
     def frame_accumulate(self, d_acc, d_cur, d_prev, d_basic, w, h, ch, sigma, params, oy,
                          ngy, smoother=False):

@@ -20,6 +20,7 @@
 #include "k_group12.h"
 #include "k_match.h"
 #include "k_tvl1.h"
+#include "k_ms.h"
 #include "nlk_common.h"
 
 namespace {
@@ -40,6 +41,7 @@ struct nlk_ctx {
   char err[512] = "";
   Buf pl_cur, pl_prev, pl_basic, rowok, vmap, topk, tinfo, gcoords, marks, active, acc, tabs, wide;
   Buf skew;                       // mark words in replay-step order (k_marks_skew)
+  Buf ms;                         // whole-image DCT: temporary image + the two basis matrices
   Buf tv;                         // TV-L1 pyramids and work images
   NlkTvState* tv_host = nullptr;  // pinned: the solver state read back between iteration batches
   int tabs_psz = 0;
@@ -338,7 +340,7 @@ void nlk_ctx_destroy(nlk_ctx* c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   Buf* bufs[] = {&c->pl_cur, &c->pl_prev, &c->pl_basic, &c->rowok, &c->vmap, &c->topk,
-                 &c->tinfo, &c->gcoords, &c->marks, &c->active, &c->acc, &c->tabs, &c->wide, &c->tv, &c->skew};
+                 &c->tinfo, &c->gcoords, &c->marks, &c->active, &c->acc, &c->tabs, &c->wide, &c->tv, &c->skew, &c->ms};
   for (Buf* b : bufs)
     if (b->p) hipFree(b->p);
   if (c->tv_host) (void)hipHostFree(c->tv_host);
@@ -750,3 +752,4 @@ int nlk_ctx_read_records(nlk_ctx* c, int* ngrid, int* kmax, int* gmax, unsigned 
 }  // extern "C"
 
 #include "tvl1_host.h"
+#include "ms_host.h"

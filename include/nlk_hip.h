@@ -26,6 +26,8 @@
  *   nlk_dev_gray                        lib/iio/iio.c:1048-1056 (what the flow tool's
  *                                       reader does to a colour image)
  *   nlk_dev_occlusion_mask              scripts/nlkalman-seq.sh:70-73 (plambda)
+ *   nlk_dev_image_dct / nlk_dev_copy_block  lib/multiscale/multiscaler.cpp:21-107 and the
+ *                                       coefficient copies of decompose / recompose
  */
 #ifndef NLK_HIP_H
 #define NLK_HIP_H
@@ -120,6 +122,15 @@ int nlk_dev_tvl1_flow(nlk_ctx *ctx, float *flow, const float *I0, const float *I
 int nlk_dev_gray(nlk_ctx *ctx, float *gray, const float *im, int w, int h, int ch);
 /* 255 where |backward-difference divergence of the flow| > th, else 0 */
 int nlk_dev_occlusion_mask(nlk_ctx *ctx, float *mask, const float *flow, int w, int h, float th);
+
+/* ---- multiscale wrapper (reference: lib/multiscale/multiscaler.cpp:21-107).
+ * nlk_dev_image_dct: in-place whole-image DCT of an HWC image — forward = FFTW REDFT10 in both
+ * directions divided by 4*w*h (dct_inplace), inverse = REDFT01 (idct_inplace).
+ * nlk_dev_copy_block: the top-left bw x bh block of coefficients of `src` (row length sw)
+ * into `dst` (row length dw): what decompose / recompose / merge_coarse do between transforms
+ * (decompose.cpp:40-46, recompose.cpp:43-49, merge_coarse.cpp:37-43). */
+int nlk_dev_image_dct(nlk_ctx *ctx, float *img, int w, int h, int ch, int inverse);
+int nlk_dev_copy_block(nlk_ctx *ctx, float *dst, int dw, const float *src, int sw, int ch, int bw, int bh);
 
 /* Row-strip form used by the multi-GPU driver. The images are a strip of the
  * frame (h rows) that already contains the search halo; targets are the patch

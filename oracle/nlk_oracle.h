@@ -70,4 +70,7 @@ void tvl1o_flow(const float *I0, const float *I1, float *u1, float *u2, int nx, 
                 float lambda, float theta, int nscales, int fscale, float zfactor, int warps,
                 float epsilon);
 void tvl1o_occlusion_mask(const float *flow, float *mask, int nx, int ny, float th);
+
+/* ---- multiscale wrapper (ms_oracle.c; reference: lib/multiscale/multiscaler.cpp) */
+void mso_image_dct(float *img, int w, int h, int ch, int inverse);
 #endif

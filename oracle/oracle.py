@@ -39,7 +39,7 @@ class Trace(C.Structure):
 def build():
     """Compile oracle/libnlk_oracle.so if missing or stale."""
     so = os.path.join(_HERE, "libnlk_oracle.so")
-    src = [os.path.join(_HERE, f) for f in ("nlk_oracle.c", "tvl1_oracle.c", "nlk_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("nlk_oracle.c", "tvl1_oracle.c", "ms_oracle.c", "nlk_oracle.h")]
     if (not os.path.exists(so)
             or os.path.getmtime(so) < max(os.path.getmtime(s) for s in src)):
         subprocess.check_call(["make", "-C", _HERE, "libnlk_oracle.so"],
@@ -90,6 +90,7 @@ def lib():
         L.tvl1o_auto_scales.restype = i
         L.tvl1o_flow.argtypes = [fp, fp, fp, fp, i, i, f, f, f, i, i, f, i, f]
         L.tvl1o_occlusion_mask.argtypes = [fp, fp, i, i, f]
+        L.mso_image_dct.argtypes = [fp, i, i, i, i]
         _LIB = L
     return _LIB
 
@@ -289,3 +290,38 @@ def tvl1_occlusion_mask(flow, th):
     m = np.zeros((h, w), np.float32)
     lib().tvl1o_occlusion_mask(_fp(flow), _fp(m), w, h, th)
     return m
+
+
+# ---- multiscale wrapper (ms_oracle.c; reference: lib/multiscale/)
+def ms_dct(im, inverse=False):
+    """Whole-image DCT of the multiscale tools (dct_inplace / idct_inplace)."""
+    a = np.array(_img(im), np.float32, copy=True)
+    h, w, ch = a.shape
+    lib().mso_image_dct(_fp(a), w, h, ch, int(inverse))
+    return a
+
+
+def ms_decompose(im, levels, ratio=2.0):
+    """decompose (reference: lib/multiscale/decompose.cpp:27-56): level i = inverse DCT of the
+    top-left h_i x w_i block of the image's DCT, sizes divided by `ratio` (truncated) per level."""
+    co = ms_dct(im)
+    h, w = co.shape[:2]
+    out = []
+    for _ in range(levels):
+        out.append(ms_dct(np.ascontiguousarray(co[:h, :w]), inverse=True))
+        w = int(w / np.float32(ratio))
+        h = int(h / np.float32(ratio))
+    return out
+
+
+def ms_recompose(levels, factor=0.8):
+    """recompose (reference: lib/multiscale/recompose.cpp:24-56): the low frequencies of level 0
+    are replaced by those of the coarser levels (the first rows*factor x cols*factor of each)."""
+    out = ms_dct(levels[0])
+    for im in levels[1:]:
+        co = ms_dct(im)
+        f = np.float32(factor)
+        bh = int(np.ceil(np.float32(co.shape[0]) * f))
+        bw = int(np.ceil(np.float32(co.shape[1]) * f))
+        out[:bh, :bw] = co[:bh, :bw]
+    return ms_dct(out, inverse=True)
