@@ -419,7 +419,8 @@ __global__ void __launch_bounds__(256) k_tv_dual(NlkTvLevel L, int n, int nparts
 //               and one partial sum of squared updates per iteration and workgroup;
 //   k_tv_decide adds them in a fixed order, finds the first iteration that satisfies the stop
 //               test and, if the batch ran past it, asks for that batch to be redone from `in`
-//               with fewer iterations (k_tv_block with fix = 1: a no-op otherwise).
+//               with fewer iterations (k_tv_block with fix = 1, launched once per group of
+//               batches: a no-op otherwise).
 #ifndef NLK_TV_K
 #define NLK_TV_K 4
 #endif
@@ -439,8 +440,12 @@ __global__ void __launch_bounds__(NLK_TV_BT)
 k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int fix) {
 #pragma clang fp contract(off)
   if (fix) {
-    if (L.st->redo_n0 != n0 || L.st->redo == 0) return;
+    // once per group of batches: redo the batch that ran past the stop, if any. `in` / `out` are
+    // the buffers of the warp's FIRST batch; batches alternate between them
+    if (L.st->redo == 0) return;
+    n0 = L.st->redo_n0;
     count = L.st->redo;
+    if ((n0 / NLK_TV_K) & 1) { const NlkTvBuf t = in; in = out; out = t; }
   } else if (n0 >= L.st->stop_iter) {
     return;
   }

@@ -91,17 +91,19 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
     NlkTvBuf cur = {L.u1, L.u2, L.p11, L.p12, L.p21, L.p22};
     const bool cur_is_a = cur.u1 == A.u1;
     NlkTvBuf oth = cur_is_a ? B : A;
+    const NlkTvBuf first = cur, second = oth;  // buffers of the warp's first batch
     int n0 = 0, batches = 0;
     while (n0 < NLK_TV_MAXIT) {
       for (int q = 0; q < look && n0 < NLK_TV_MAXIT; ++q) {
         const int count = NLK_TV_MAXIT - n0 < NLK_TV_K ? NLK_TV_MAXIT - n0 : NLK_TV_K;
         hipLaunchKernelGGL(k_tv_block, bgrid, dim3(NLK_TV_BT), 0, c->stream, L, cur, oth, n0, count, 0);
         hipLaunchKernelGGL(k_tv_decide, dim3(1), dim3(256), 0, c->stream, L, n0, count, nblocks);
-        hipLaunchKernelGGL(k_tv_block, bgrid, dim3(NLK_TV_BT), 0, c->stream, L, cur, oth, n0, count, 1);
         const NlkTvBuf t = cur; cur = oth; oth = t;
         n0 += count;
         ++batches;
       }
+      // the batch that ran past the stop (if any) is redone from its input, once per group
+      hipLaunchKernelGGL(k_tv_block, bgrid, dim3(NLK_TV_BT), 0, c->stream, L, first, second, 0, 0, 1);
       HIPCHK(c, hipMemcpyAsync(c->tv_host, st, sizeof(NlkTvState), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       if (c->tv_host->stop_iter < NLK_TV_MAXIT || c->tv_host->last >= NLK_TV_MAXIT) break;
