@@ -20,59 +20,81 @@ __global__ void k_ms_basis(float* __restrict__ M, int n, int inverse) {
 }
 
 // C[m*cm + n*cn] = sum_k A[m*am + k*ak] * B[k*bk + n*bn]   (general strides, f32)
-// Workgroup = 4 wavefronts computing a 64 x 64 tile, each wavefront 32 x 32 as 2 x 2 MFMA tiles
-// of v_mfma_f32_16x16x4_f32; K is walked in chunks of 16 staged through LDS.
+// Workgroup = 4 wavefronts computing a 128 x 128 tile, each wavefront 64 x 64 as 4 x 4 tiles of
+// v_mfma_f32_16x16x4_f32 (16 MFMAs per 8 LDS operand reads); K is walked in chunks of 16
+// staged through LDS, the next chunk's global loads in flight while the current one is
+// multiplied.
 typedef float nlk_ms_f4 __attribute__((ext_vector_type(4)));
+#define NLK_MS_T 128  // tile edge
+#define NLK_MS_KC 16  // K chunk
 
 __global__ void __launch_bounds__(256)
 k_ms_gemm(const float* __restrict__ A, long am, long ak, const float* __restrict__ B, long bk, long bn,
           float* __restrict__ C, long cm, long cn, int M, int N, int K) {
-  __shared__ float As[16][64 + 4], Bs[16][64 + 4];  // [k][m], [k][n]
+  __shared__ float As[NLK_MS_KC][NLK_MS_T + 4], Bs[NLK_MS_KC][NLK_MS_T + 4];  // [k][m], [k][n]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-  nlk_ms_f4 acc[2][2];
+  const int m0 = blockIdx.y * NLK_MS_T, n0 = blockIdx.x * NLK_MS_T;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  nlk_ms_f4 acc[4][4];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = nlk_ms_f4{0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    // stage: 1024 elements of each operand, 4 per thread; consecutive threads walk the
-    // operand's fastest dimension
-    for (int e = tid; e < 1024; e += 256) {
-      {  // A tile: element (m, k); consecutive threads follow the smaller stride
-        const int kk = ak <= am ? (e & 15) : (e >> 6), mm = ak <= am ? (e >> 4) : (e & 63);
+    for (int b = 0; b < 4; ++b) acc[a][b] = nlk_ms_f4{0.f, 0.f, 0.f, 0.f};
+  // staging roles: 2048 elements of each operand per chunk, 8 per thread; consecutive threads
+  // follow the operand's smaller stride
+  constexpr int PER = NLK_MS_T * NLK_MS_KC / 256;
+  const bool a_kfast = ak <= am, b_nfast = bn <= bk;
+  float ra[PER], rb[PER];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + 256 * u;
+      {
+        const int kk = a_kfast ? (e & 15) : (e >> 7), mm = a_kfast ? (e >> 4) : (e & 127);
         const int m = m0 + mm, k = k0 + kk;
-        As[kk][mm] = (m < M && k < K) ? A[m * am + k * ak] : 0.f;
+        ra[u] = (m < M && k < K) ? A[m * am + k * ak] : 0.f;
       }
-      {  // B tile: element (k, n)
-        const int kk = bn <= bk ? (e >> 6) : (e & 15), nn = bn <= bk ? (e & 63) : (e >> 4);
+      {
+        const int kk = b_nfast ? (e >> 7) : (e & 15), nn = b_nfast ? (e & 127) : (e >> 4);
         const int k = k0 + kk, n = n0 + nn;
-        Bs[kk][nn] = (k < K && n < N) ? B[k * bk + n * bn] : 0.f;
+        rb[u] = (k < K && n < N) ? B[k * bk + n * bn] : 0.f;
       }
     }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + 256 * u;
+      As[a_kfast ? (e & 15) : (e >> 7)][a_kfast ? (e >> 4) : (e & 127)] = ra[u];
+      Bs[b_nfast ? (e >> 7) : (e & 15)][b_nfast ? (e & 127) : (e >> 4)] = rb[u];
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += NLK_MS_KC) {
+    stage();
     __syncthreads();
+    if (k0 + NLK_MS_KC < K) fetch(k0 + NLK_MS_KC);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      float a[2], b[2];
+    for (int ks = 0; ks < NLK_MS_KC / 4; ++ks) {
+      float a[4], b[4];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < 4; ++t) {
         a[t] = As[ks * 4 + (lane >> 4)][wm + t * 16 + (lane & 15)];
         b[t] = Bs[ks * 4 + (lane >> 4)][wn + t * 16 + (lane & 15)];
       }
 #pragma unroll
-      for (int ta = 0; ta < 2; ++ta)
+      for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
+        for (int tb = 0; tb < 4; ++tb)
           acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
     }
     __syncthreads();
   }
   // C/D layout: lane l, register r -> row 4*(l>>4) + r, column l & 15
 #pragma unroll
-  for (int ta = 0; ta < 2; ++ta)
+  for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-    for (int tb = 0; tb < 2; ++tb)
+    for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm + ta * 16 + 4 * (lane >> 4) + r, n = n0 + wn + tb * 16 + (lane & 15);

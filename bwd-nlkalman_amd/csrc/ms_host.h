@@ -5,7 +5,7 @@ namespace {
 
 int ms_gemm(nlk_ctx* c, const float* A, long am, long ak, const float* B, long bk, long bn, float* C, long cm,
             long cn, int M, int N, int K) {
-  hipLaunchKernelGGL(k_ms_gemm, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, c->stream, A, am, ak, B, bk, bn,
+  hipLaunchKernelGGL(k_ms_gemm, dim3((N + NLK_MS_T - 1) / NLK_MS_T, (M + NLK_MS_T - 1) / NLK_MS_T), dim3(256), 0, c->stream, A, am, ak, B, bk, bn,
                      C, cm, cn, M, N, K);
   HIPCHK(c, hipGetLastError());
   return NLK_OK;
