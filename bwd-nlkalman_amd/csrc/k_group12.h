@@ -108,9 +108,11 @@ __device__ __forceinline__ void nlk_dct12x12_inv(float (&p)[12], const float (&c
 }
 
 __device__ __forceinline__ void nlk_load_row12(const float* __restrict__ p, float (&dst)[12]) {
-  const nlk_f4u a = *reinterpret_cast<const nlk_f4u*>(p);
-  const nlk_f4u b = *reinterpret_cast<const nlk_f4u*>(p + 4);
-  const nlk_f4u c = *reinterpret_cast<const nlk_f4u*>(p + 8);
+  // (explicit global address space: see k_group8m.h)
+  typedef const __attribute__((address_space(1))) nlk_f4u* gp4;
+  const nlk_f4u a = *(gp4)(p);
+  const nlk_f4u b = *(gp4)(p + 4);
+  const nlk_f4u c = *(gp4)(p + 8);
   dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
   dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
   dst[8] = c.x; dst[9] = c.y; dst[10] = c.z; dst[11] = c.w;
@@ -223,15 +225,25 @@ k_group12(const float* __restrict__ img, const float* __restrict__ cur,
 #pragma unroll
     for (int r = 0; r < 12; ++r) m1[r] = v1[r] = mb[r] = vb[r] = v01[r] = m0[r] = 0.f;
     int np0 = 0, np1 = 0;
-    float a[12], b[12];
-#pragma unroll
-    for (int r = 0; r < 12; ++r) a[r] = b[r] = 0.f;  // idle lanes stay finite (their coefficients are 0)
-    for (int i = 0; i < k; ++i) {
+    // The rows of the next candidate are requested before the current one is transformed.
+    // All loads are unconditional (idle lanes read row 0 of channel 0, a candidate without a
+    // valid previous patch reads the image instead: finite data that is never used), so the
+    // waits stay partial.
+    float a[12], b[12], na[12], nb[12];
+    const ptrdiff_t prev_off = prev_c - img_c;
+    auto rows_of = [&](int i, float (&ra)[12], float (&rb)[12]) {
       const uint32_t q = cand(i);
       const int org = nlk_y(q) * g.w + nlk_x(q);
       const bool v = (vbits[i >> 6] >> (i & 63)) & 1ull;
-      if (lane_on) nlk_load_row12(img_c + org, a);
-      if (lane_on && v) nlk_load_row12(prev_c + org, b);
+      nlk_load_row12(img_c + org, ra);
+      nlk_load_row12(img_c + (v ? prev_off : (ptrdiff_t)0) + org, rb);
+    };
+    if (k > 0) rows_of(0, na, nb);
+    for (int i = 0; i < k; ++i) {
+      const bool v = (vbits[i >> 6] >> (i & 63)) & 1ull;
+#pragma unroll
+      for (int r = 0; r < 12; ++r) { a[r] = na[r]; b[r] = nb[r]; }
+      rows_of(i + 1 < k ? i + 1 : i, na, nb);
       nlk_dct12x12_fwd(a, ck);
       if (v) nlk_dct12x12_fwd(b, ck);
       np1++;
