@@ -21,8 +21,14 @@
 
 static nlk_ctx *g_ctx = NULL;
 
+static struct { void *p; size_t cap; } g_slot[4]; /* device buffers of the frame calls */
+
 static void ctx_atexit(void) {
-  if (g_ctx) nlk_ctx_destroy(g_ctx);
+  if (g_ctx) {
+    for (int i = 0; i < 4; ++i)
+      if (g_slot[i].p) nlk_dev_free(g_ctx, g_slot[i].p);
+    nlk_ctx_destroy(g_ctx);
+  }
   g_ctx = NULL;
 }
 
@@ -124,22 +130,35 @@ void nlkalman_default_params(struct nlkalman_params *p, float sigma, enum FILTER
   }
 }
 
+/* Device buffers of the frame calls, kept between calls (a sequence calls the API once or twice
+ * per frame with the same sizes: hipMalloc / hipFree per call cost ~0.5 ms of a 3.5 ms call). The
+ * API is not re-entrant, like the reference's (its FFTW plans are global, src/nlkalman.c:570-575). */
+
+static float *slot(nlk_ctx *c, int i, size_t bytes) {
+  if (g_slot[i].cap < bytes) {
+    if (g_slot[i].p) nlk_dev_free(c, g_slot[i].p);
+    g_slot[i].p = NULL;
+    g_slot[i].cap = 0;
+    if (nlk_dev_alloc(c, &g_slot[i].p, bytes)) die("frame buffers", c);
+    g_slot[i].cap = bytes;
+  }
+  return (float *)g_slot[i].p;
+}
+
 static void frame_call(int smoother, float *out, float *cur, float *prev, float *basic, int w,
                        int h, int ch, float sigma, const struct nlkalman_params *prms) {
   nlk_ctx *c = ctx();
-  const size_t n = (size_t)w * h * ch;
-  float *d_cur = upload(c, cur, n), *d_prev = upload(c, prev, n), *d_basic = upload(c, basic, n);
-  void *d_out = NULL;
-  if (nlk_dev_alloc(c, &d_out, n * sizeof(float))) die("frame", c);
+  const size_t bytes = (size_t)w * h * ch * sizeof(float);
+  float *d_cur = slot(c, 0, bytes), *d_out = slot(c, 3, bytes);
+  float *d_prev = prev ? slot(c, 1, bytes) : NULL, *d_basic = basic ? slot(c, 2, bytes) : NULL;
+  if (nlk_h2d(c, d_cur, cur, bytes) || (prev && nlk_h2d(c, d_prev, prev, bytes)) ||
+      (basic && nlk_h2d(c, d_basic, basic, bytes)))
+    die("upload", c);
   const int rc = smoother
-                     ? nlk_dev_smooth_frame(c, (float *)d_out, d_cur, d_prev, d_basic, w, h, ch, sigma, prms)
-                     : nlk_dev_filter_frame(c, (float *)d_out, d_cur, d_prev, d_basic, w, h, ch, sigma, prms);
-  if (rc || nlk_d2h(c, out, d_out, n * sizeof(float)))
+                     ? nlk_dev_smooth_frame(c, d_out, d_cur, d_prev, d_basic, w, h, ch, sigma, prms)
+                     : nlk_dev_filter_frame(c, d_out, d_cur, d_prev, d_basic, w, h, ch, sigma, prms);
+  if (rc || nlk_d2h(c, out, d_out, bytes))
     die(smoother ? "nlkalman_smooth_frame" : "nlkalman_filter_frame", c);
-  nlk_dev_free(c, d_cur);
-  if (d_prev) nlk_dev_free(c, d_prev);
-  if (d_basic) nlk_dev_free(c, d_basic);
-  nlk_dev_free(c, d_out);
 }
 
 /* reference: src/nlkalman.c:518-951 */
