@@ -112,7 +112,10 @@ k_mask_commit(const uint64_t* __restrict__ marks, uint8_t* __restrict__ active, 
 // 32-bit registers (the forward bits of the mark words arrive pre-shifted and ordered by step from
 // k_marks_skew) instead of an LDS round trip + atomics + workgroup barrier.
 // ---------------------------------------------------------------------------
-#define NLK_CW_RING 64  // steps of edge data kept per wavefront
+#define NLK_CW_RING 128  // steps of edge data kept per wavefront
+#ifndef NLK_CW_PHASE
+#define NLK_CW_PHASE 32
+#endif
 
 // Pre-pass: the forward part of every mark word (the bits after the target itself: same row,
 // then the rows below; at most R + R*side <= 24 bits), stored by STEP of the replay:
@@ -135,7 +138,7 @@ k_mask_commit_wave(const uint32_t* __restrict__ skewed, uint8_t* __restrict__ ac
                    int ngy) {
   constexpr int side = 2 * R + 1, skew = R + 1, centre = R * side + R;
   constexpr uint32_t rowmask = (1u << side) - 1u;
-  constexpr int S = 16;  // steps per phase: progress is exchanged once per phase
+  constexpr int S = NLK_CW_PHASE;  // steps per phase: progress is exchanged once per phase
   __shared__ uint32_t edge[16][NLK_CW_RING][R];  // [wave][step % ring][lane 64-R+e]: packed row masks
   __shared__ int prog[16];                        // steps published by each wavefront
   const int lane = threadIdx.x & 63;
@@ -183,7 +186,9 @@ k_mask_commit_wave(const uint32_t* __restrict__ skewed, uint8_t* __restrict__ ac
     if (wave + 1 < nwaves)
       while (ld_prog(wave + 1) < s0 + S - NLK_CW_RING + 1) __builtin_amdgcn_s_sleep(1);
 
-    uint32_t flags[S / 4] = {0, 0, 0, 0};  // decisions of this phase, one byte each
+    uint32_t flags[S / 4];  // decisions of this phase, one byte each
+#pragma unroll
+    for (int q = 0; q < S / 4; ++q) flags[q] = 0;
 #pragma unroll
     for (int e = 0; e < S; ++e) {
       const int s = s0 + e;

@@ -599,7 +599,7 @@ static int run_commit(nlk_ctx* c, const uint64_t* marks, uint8_t* active, int ng
   } else if (ngy <= 1024 && R <= 3 && !getenv("NLK_COMMIT_LDS")) {
     const int threads = ((ngy + 63) / 64) * 64;
     const int nsteps = ngx + (R + 1) * (ngy - 1);
-    const size_t sk_bytes = sizeof(uint32_t) * (size_t)(nsteps + 2 * 16 + 16) * threads;
+    const size_t sk_bytes = sizeof(uint32_t) * (size_t)(nsteps + 3 * NLK_CW_PHASE) * threads;
     int rc = reserve(c, c->skew, sk_bytes);
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->skew.p, 0, sk_bytes, c->stream));
