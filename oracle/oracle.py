@@ -283,6 +283,16 @@ def tvl1_flow(i0, i1, **kw):
     return u, v
 
 
+def tvl1_gray(im):
+    """Luminance the reference's reader hands to the flow for a colour file: double sum, one
+    rounding (lib/iio/iio.c:1048-1056 via iio_read_image_float, :3993-3994)."""
+    im = np.asarray(im, np.float32)
+    if im.ndim == 2 or im.shape[2] == 1:
+        return np.ascontiguousarray(im.reshape(im.shape[0], im.shape[1]))
+    c = im.astype(np.float64)
+    return np.ascontiguousarray((.299 * c[..., 0] + .587 * c[..., 1] + .114 * c[..., 2]).astype(np.float32))
+
+
 def tvl1_occlusion_mask(flow, th):
     """flow (h, w, 2) -> mask (h, w) of 0 / 255 (|divergence| > th)."""
     flow = np.ascontiguousarray(flow, np.float32)
