@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "tv_hypot.h"
 
 #define NLK_TV_MAXIT 300  // reference: tvl1flow_lib.c:24
 #define NLK_TV_THREADS 1024  // workgroup of the level kernel: 16 wavefronts = 64 x 16 pixels per tile
@@ -25,6 +26,7 @@ struct NlkTvState {
   float error;     // its mean squared update
   int redo;        // blocked driver: iterations of batch redo_n0 to recompute (it over-ran the stop)
   int redo_n0;
+  int fin_stop;    // blocked driver: stop found by the group's closing launch (never read on the device)
 };
 
 // ---- sampling (reference: bicubic_interpolation.c:26-41, 100-131, 140-236)
@@ -226,13 +228,13 @@ __device__ __forceinline__ void nlk_tv_primal_core(float rho_c, float gx, float 
 // dual update from the forward differences of the new flow (reference: tvl1flow_lib.c:233-250);
 // hypot and 1 + taut*g are evaluated in double there. hypot() in double, rounded to float: the
 // squares of floats are exact in double, so sqrt(x*x + y*y) carries two roundings of 2^-53 and
-// gives the same float as the C library's hypot (no scaling is needed for flow gradients)
+// gives the same float as the C library's hypot (no scaling is needed for flow gradients);
+// nlk_tv_hypot returns that float without paying for the correctly rounded double root
 __device__ __forceinline__ void nlk_tv_dual_core(float& p11, float& p12, float& p21, float& p22, float ax,
                                                  float ay, float bx, float by, float taut) {
 #pragma clang fp contract(off)
-  const double dax = ax, day = ay, dbx = bx, dby = by;
-  const float g1 = (float)sqrt(dax * dax + day * day);
-  const float g2 = (float)sqrt(dbx * dbx + dby * dby);
+  const float g1 = nlk_tv_hypot(ax, ay);  // == (float)sqrt((double)ax * ax + (double)ay * ay), tv_hypot.h
+  const float g2 = nlk_tv_hypot(bx, by);
   const float ng1 = (float)(1.0 + (double)(taut * g1));
   const float ng2 = (float)(1.0 + (double)(taut * g2));
   p11 = (p11 + taut * ax) / ng1;
@@ -369,6 +371,7 @@ __global__ void __launch_bounds__(256) k_tv_warp(NlkTvLevel L) {
     L.st->error = INFINITY;
     L.st->redo = 0;
     L.st->redo_n0 = -1;
+    L.st->fin_stop = NLK_TV_MAXIT;
   }
 }
 
@@ -416,60 +419,140 @@ __global__ void __launch_bounds__(256) k_tv_dual(NlkTvLevel L, int n, int nparts
 // computed from stale halo data never reaches the tile. The tile's pixels get exactly the
 // values of the plain recursion.
 //   k_tv_block  reads state `in` (u, p after n0 iterations), writes `out` (after n0 + count)
-//               and one partial sum of squared updates per iteration and workgroup;
-//   k_tv_decide adds them in a fixed order, finds the first iteration that satisfies the stop
-//               test and, if the batch ran past it, asks for that batch to be redone from `in`
-//               with fewer iterations (k_tv_block with fix = 1, launched once per group of
-//               batches: a no-op otherwise).
+//               and one partial sum of squared updates per iteration and workgroup. The NEXT
+//               launch starts by adding the partial sums in a fixed order (every workgroup does,
+//               so that all take the same decision without a kernel in between): it finds the
+//               first iteration that satisfies the stop test; later batches are no-ops, and if
+//               the batch ran past the stop, that batch is redone from its input with fewer
+//               iterations by the launch that closes a group of batches (mode 1), which also
+//               judges the group's last batch. A launch never reads a state field it writes
+//               (workgroups of one launch do not run together), except `stop_iter`, where both
+//               values lead to the same action.
 #ifndef NLK_TV_K
 #define NLK_TV_K 4
 #endif
 #define NLK_TV_TW 64
-#define NLK_TV_TH 16
+#define NLK_TV_TH 16   // tile rows: 16 (region 72 x 24: 2 pixel slots per thread for 1 tile pixel) or, for levels
+#define NLK_TV_TH2 32  // with enough tiles to fill the chip, 32 (72 x 40: 3 slots for 2 tile pixels)
 #define NLK_TV_RW (NLK_TV_TW + 2 * NLK_TV_K)
-#define NLK_TV_RH (NLK_TV_TH + 2 * NLK_TV_K)
 #define NLK_TV_BT 1024  // threads of a k_tv_block workgroup: the coarse levels have few tiles, so a tile
                         // must finish fast rather than leave room for others
-#define NLK_TV_RPT ((NLK_TV_RW * NLK_TV_RH + NLK_TV_BT - 1) / NLK_TV_BT)  // region pixels per thread
 
 struct NlkTvBuf {
   float *u1, *u2, *p11, *p12, *p21, *p22;
 };
 
-__global__ void __launch_bounds__(NLK_TV_BT)
-k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int fix) {
-#pragma clang fp contract(off)
-  if (fix) {
-    // once per group of batches: redo the batch that ran past the stop, if any. `in` / `out` are
-    // the buffers of the warp's FIRST batch; batches alternate between them
-    if (L.st->redo == 0) return;
-    n0 = L.st->redo_n0;
-    count = L.st->redo;
-    if ((n0 / NLK_TV_K) & 1) { const NlkTvBuf t = in; in = out; out = t; }
-  } else if (n0 >= L.st->stop_iter) {
-    return;
+// the stop test over the partial sums of one batch, by every thread of the workgroup alike:
+// number of iterations of the batch that count (the first with error <= eps^2 is the last one)
+__device__ __forceinline__ int nlk_tv_judge(const NlkTvLevel& L, const float* __restrict__ part, int nblocks,
+                                            int count, double (*red)[4], float* errs, bool& stop, float& err) {
+  if (threadIdx.x < 256) {
+    double s[NLK_TV_K];
+#pragma unroll
+    for (int k = 0; k < NLK_TV_K; ++k) {
+      s[k] = 0.0;
+      if (k < count)
+        for (int b = threadIdx.x; b < nblocks; b += 256) s[k] += (double)part[k * nblocks + b];
+    }
+#pragma unroll
+    for (int k = 0; k < NLK_TV_K; ++k) {
+      for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off, 64);
+      if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s[k];
+    }
   }
-  __shared__ float s_u1[NLK_TV_RW * NLK_TV_RH], s_u2[NLK_TV_RW * NLK_TV_RH];
-  __shared__ float s_p11[NLK_TV_RW * NLK_TV_RH], s_p12[NLK_TV_RW * NLK_TV_RH];
-  __shared__ float s_p21[NLK_TV_RW * NLK_TV_RH], s_p22[NLK_TV_RW * NLK_TV_RH];
+  __syncthreads();
+  if (threadIdx.x < NLK_TV_K)
+    errs[threadIdx.x] = (float)((red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3])) /
+                        (float)(L.nx * L.ny);
+  __syncthreads();
+  int done = count;
+  stop = false;
+  for (int k = 0; k < count; ++k)
+    if (!(errs[k] > L.eps2)) {  // reference: tvl1flow_lib.c:166
+      done = k + 1;
+      stop = true;
+      break;
+    }
+  err = errs[done - 1];
+  return done;
+}
+
+// mode 0: a batch; 2: a batch that first judges the previous one; 1: closes a group of batches
+// (n0, count = the group's last batch, judged here; in / out = the buffers of the warp's FIRST
+// batch); 3: closes a group whose batches were all judged by k_tv_decide.
+// Judging inside the batches saves a launch per batch where the grid is small (every workgroup
+// re-adds all partial sums: cheap for a few hundred workgroups, not for thousands)
+template <int TH>
+__global__ void __launch_bounds__(NLK_TV_BT)
+k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode) {
+#pragma clang fp contract(off)
+  constexpr int RH = TH + 2 * NLK_TV_K, RPT = (NLK_TV_RW * RH + NLK_TV_BT - 1) / NLK_TV_BT;
+  __shared__ double red[NLK_TV_K][4];
+  __shared__ float errs[NLK_TV_K];
+  const int nblocks = gridDim.x * gridDim.y, block = blockIdx.y * gridDim.x + blockIdx.x;
+  if (mode == 1 || mode == 3) {
+    if (L.st->stop_iter < NLK_TV_MAXIT) {  // found by a batch of this group
+      if (L.st->redo == 0) return;
+      n0 = L.st->redo_n0;
+      count = L.st->redo;
+    } else if (mode == 3) {
+      return;
+    } else {
+      bool stop;
+      float err;
+      const int done = nlk_tv_judge(L, L.part + ((n0 / NLK_TV_K) & 1) * NLK_TV_K * nblocks, nblocks, count, red,
+                                    errs, stop, err);
+      if (block == 0 && threadIdx.x == 0) {
+        L.st->iters += done;
+        L.st->last = n0 + done;
+        L.st->error = err;
+        L.st->fin_stop = stop ? n0 + done : NLK_TV_MAXIT;
+      }
+      if (!stop || done == count) return;
+      count = done;
+    }
+    if ((n0 / NLK_TV_K) & 1) { const NlkTvBuf t = in; in = out; out = t; }
+  } else {
+    if (n0 >= L.st->stop_iter) return;
+    if (mode == 2) {
+      const int n0p = n0 - NLK_TV_K;
+      bool stop;
+      float err;
+      const int done = nlk_tv_judge(L, L.part + ((n0p / NLK_TV_K) & 1) * NLK_TV_K * nblocks, nblocks, NLK_TV_K,
+                                    red, errs, stop, err);
+      if (block == 0 && threadIdx.x == 0) {
+        L.st->iters += done;
+        L.st->last = n0p + done;
+        L.st->error = err;
+        if (stop) {
+          if (done < NLK_TV_K) { L.st->redo = done; L.st->redo_n0 = n0p; }
+          L.st->stop_iter = n0p + done;
+        }
+      }
+      if (stop) return;
+    }
+  }
+  float* const part = L.part + ((n0 / NLK_TV_K) & 1) * NLK_TV_K * nblocks;
+  __shared__ float s_u1[NLK_TV_RW * RH], s_u2[NLK_TV_RW * RH];
+  __shared__ float s_p11[NLK_TV_RW * RH], s_p12[NLK_TV_RW * RH];
+  __shared__ float s_p21[NLK_TV_RW * RH], s_p22[NLK_TV_RW * RH];
   __shared__ float redf[NLK_TV_BT / 64];
   const int nx = L.nx, ny = L.ny;
-  const int rx0 = blockIdx.x * NLK_TV_TW - NLK_TV_K, ry0 = blockIdx.y * NLK_TV_TH - NLK_TV_K;
-  const int nblocks = gridDim.x * gridDim.y, block = blockIdx.y * gridDim.x + blockIdx.x;
+  const int rx0 = blockIdx.x * NLK_TV_TW - NLK_TV_K, ry0 = blockIdx.y * TH - NLK_TV_K;
   // the region pixels of this thread: index in the region, in the image, constants of the warp
-  int gidx[NLK_TV_RPT];
-  bool on[NLK_TV_RPT], mine[NLK_TV_RPT];
-  float rc[NLK_TV_RPT], gx[NLK_TV_RPT], gy[NLK_TV_RPT], gr[NLK_TV_RPT];
+  int gidx[RPT];
+  bool on[RPT], mine[RPT];
+  float rc[RPT], gx[RPT], gy[RPT], gr[RPT];
 #pragma unroll
-  for (int m = 0; m < NLK_TV_RPT; ++m) {
+  for (int m = 0; m < RPT; ++m) {
     const int r = threadIdx.x + NLK_TV_BT * m;
     const int ly = r / NLK_TV_RW, lx = r - ly * NLK_TV_RW;
     const int j = rx0 + lx, i = ry0 + ly;
-    on[m] = r < NLK_TV_RW * NLK_TV_RH && j >= 0 && j < nx && i >= 0 && i < ny;
-    mine[m] = on[m] && lx >= NLK_TV_K && lx < NLK_TV_K + NLK_TV_TW && ly >= NLK_TV_K && ly < NLK_TV_K + NLK_TV_TH;
+    on[m] = r < NLK_TV_RW * RH && j >= 0 && j < nx && i >= 0 && i < ny;
+    mine[m] = on[m] && lx >= NLK_TV_K && lx < NLK_TV_K + NLK_TV_TW && ly >= NLK_TV_K && ly < NLK_TV_K + TH;
     gidx[m] = on[m] ? i * nx + j : 0;
     rc[m] = L.rho_c[gidx[m]]; gx[m] = L.I1wx[gidx[m]]; gy[m] = L.I1wy[gidx[m]]; gr[m] = L.grad[gidx[m]];
-    if (r < NLK_TV_RW * NLK_TV_RH) {
+    if (r < NLK_TV_RW * RH) {
       s_u1[r] = on[m] ? in.u1[gidx[m]] : 0.f;
       s_u2[r] = on[m] ? in.u2[gidx[m]] : 0.f;
       s_p11[r] = on[m] ? in.p11[gidx[m]] : 0.f;
@@ -482,7 +565,7 @@ k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int fix) 
   for (int k = 0; k < count; ++k) {
     float e = 0.f;
 #pragma unroll
-    for (int m = 0; m < NLK_TV_RPT; ++m) {
+    for (int m = 0; m < RPT; ++m) {
       if (!on[m]) continue;
       const int r = threadIdx.x + NLK_TV_BT * m;
       const int ly = r / NLK_TV_RW, lx = r - ly * NLK_TV_RW;
@@ -500,14 +583,14 @@ k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int fix) 
       if (mine[m]) e += (na - a) * (na - a) + (nb - b) * (nb - b);
     }
     e = nlk_tv_block_sum(e, redf);  // (its barriers also publish the new u)
-    if (threadIdx.x == 0) L.part[k * nblocks + block] = e;
+    if (threadIdx.x == 0) part[k * nblocks + block] = e;
 #pragma unroll
-    for (int m = 0; m < NLK_TV_RPT; ++m) {
+    for (int m = 0; m < RPT; ++m) {
       if (!on[m]) continue;
       const int r = threadIdx.x + NLK_TV_BT * m;
       const int ly = r / NLK_TV_RW, lx = r - ly * NLK_TV_RW;
       const int j = rx0 + lx, i = ry0 + ly;
-      const int rr = lx < NLK_TV_RW - 1 ? r + 1 : r, rd = ly < NLK_TV_RH - 1 ? r + NLK_TV_RW : r;
+      const int rr = lx < NLK_TV_RW - 1 ? r + 1 : r, rd = ly < RH - 1 ? r + NLK_TV_RW : r;
       const float a = s_u1[r], b = s_u2[r];
       const float ax = j < nx - 1 ? s_u1[rr] - a : 0.f, ay = i < ny - 1 ? s_u1[rd] - a : 0.f;
       const float bx = j < nx - 1 ? s_u2[rr] - b : 0.f, by = i < ny - 1 ? s_u2[rd] - b : 0.f;
@@ -521,7 +604,7 @@ k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int fix) 
     __syncthreads();
   }
 #pragma unroll
-  for (int m = 0; m < NLK_TV_RPT; ++m) {
+  for (int m = 0; m < RPT; ++m) {
     if (!mine[m]) continue;
     const int r = threadIdx.x + NLK_TV_BT * m;
     out.u1[gidx[m]] = s_u1[r];
@@ -533,35 +616,23 @@ k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int fix) 
   }
 }
 
+// large grids: one workgroup judges batch (n0, count) between two batches
 __global__ void __launch_bounds__(256) k_tv_decide(NlkTvLevel L, int n0, int count, int nblocks) {
   if (n0 >= L.st->stop_iter) return;
-  __shared__ double red[4];
+  __shared__ double red[NLK_TV_K][4];
   __shared__ float errs[NLK_TV_K];
-  for (int k = 0; k < count; ++k) {
-    double s = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 256) s += (double)L.part[k * nblocks + b];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float err = (float)((red[0] + red[1]) + (red[2] + red[3]));
-      errs[k] = err / (float)(L.nx * L.ny);
-    }
-  }
-  __syncthreads();
+  bool stop;
+  float err;
+  const int done = nlk_tv_judge(L, L.part + ((n0 / NLK_TV_K) & 1) * NLK_TV_K * nblocks, nblocks, count, red, errs,
+                                stop, err);
   if (threadIdx.x == 0) {
-    int done = count;
-    for (int k = 0; k < count; ++k)
-      if (!(errs[k] > L.eps2)) {  // reference: tvl1flow_lib.c:166
-        done = k + 1;
-        L.st->stop_iter = n0 + done;
-        if (done < count) { L.st->redo = done; L.st->redo_n0 = n0; }
-        break;
-      }
     L.st->iters += done;
     L.st->last = n0 + done;
-    L.st->error = errs[done - 1];
+    L.st->error = err;
+    if (stop) {
+      if (done < count) { L.st->redo = done; L.st->redo_n0 = n0; }
+      L.st->stop_iter = n0 + done;
+    }
   }
 }
 

@@ -79,12 +79,19 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
   }
   // blocked driver: NLK_TV_K iterations per launch between two state buffers. A = the level's
   // own arrays, B = a second set; the host launches batches ahead and reads the state every
-  // few batches; batches after the converged one are no-ops, so the final state sits in the
+  // few batches (each batch judges its predecessor's convergence when it starts, the launch that
+  // closes a group judges the last one); batches after the converged one are no-ops, so the final state sits in the
   // buffer written by batch ceil(stop / K).
   NlkTvBuf A = {u1, u2, L.p11, L.p12, L.p21, L.p22};
   NlkTvBuf B = {alt, alt + n, alt + 2 * n, alt + 3 * n, alt + 4 * n, alt + 5 * n};
-  const dim3 bgrid((nx + NLK_TV_TW - 1) / NLK_TV_TW, (ny + NLK_TV_TH - 1) / NLK_TV_TH);
+  // tall tiles do a quarter less halo work; they need enough tiles to keep every CU busy
+  const int nb16 = ((nx + NLK_TV_TW - 1) / NLK_TV_TW) * ((ny + NLK_TV_TH - 1) / NLK_TV_TH);
+  const bool tall = nb16 >= (getenv("NLK_TV_TALL") ? atoi(getenv("NLK_TV_TALL")) : 400);
+  const int th = tall ? NLK_TV_TH2 : NLK_TV_TH;
+  const auto block_kernel = tall ? k_tv_block<NLK_TV_TH2> : k_tv_block<NLK_TV_TH>;
+  const dim3 bgrid((nx + NLK_TV_TW - 1) / NLK_TV_TW, (ny + th - 1) / th);
   const int nblocks = bgrid.x * bgrid.y;
+  const bool inline_judge = nblocks <= (getenv("NLK_TV_INLINE") ? atoi(getenv("NLK_TV_INLINE")) : 600);
   const int look = getenv("NLK_TV_LOOK") ? atoi(getenv("NLK_TV_LOOK")) : 4;  // batches between two looks at the state
   for (int wi = 0; wi < P.nwarps; ++wi) {
     hipLaunchKernelGGL(k_tv_warp, grid, dim3(256), 0, c->stream, L);
@@ -92,28 +99,36 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
     const bool cur_is_a = cur.u1 == A.u1;
     NlkTvBuf oth = cur_is_a ? B : A;
     const NlkTvBuf first = cur, second = oth;  // buffers of the warp's first batch
-    int n0 = 0, batches = 0;
+    int n0 = 0, batches = 0, last_n0 = 0, last_count = 0;
     while (n0 < NLK_TV_MAXIT) {
       for (int q = 0; q < look && n0 < NLK_TV_MAXIT; ++q) {
         const int count = NLK_TV_MAXIT - n0 < NLK_TV_K ? NLK_TV_MAXIT - n0 : NLK_TV_K;
-        hipLaunchKernelGGL(k_tv_block, bgrid, dim3(NLK_TV_BT), 0, c->stream, L, cur, oth, n0, count, 0);
-        hipLaunchKernelGGL(k_tv_decide, dim3(1), dim3(256), 0, c->stream, L, n0, count, nblocks);
+        hipLaunchKernelGGL(block_kernel, bgrid, dim3(NLK_TV_BT), 0, c->stream, L, cur, oth, n0, count,
+                           inline_judge && q ? 2 : 0);
+        if (!inline_judge) hipLaunchKernelGGL(k_tv_decide, dim3(1), dim3(256), 0, c->stream, L, n0, count, nblocks);
+        last_n0 = n0;
+        last_count = count;
         const NlkTvBuf t = cur; cur = oth; oth = t;
         n0 += count;
         ++batches;
       }
       // the batch that ran past the stop (if any) is redone from its input, once per group
-      hipLaunchKernelGGL(k_tv_block, bgrid, dim3(NLK_TV_BT), 0, c->stream, L, first, second, 0, 0, 1);
+      // (it also judges the group's last batch)
+      hipLaunchKernelGGL(block_kernel, bgrid, dim3(NLK_TV_BT), 0, c->stream, L, first, second, last_n0, last_count,
+                         inline_judge ? 1 : 3);
       HIPCHK(c, hipMemcpyAsync(c->tv_host, st, sizeof(NlkTvState), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
-      if (c->tv_host->stop_iter < NLK_TV_MAXIT || c->tv_host->last >= NLK_TV_MAXIT) break;
+      if (c->tv_host->stop_iter < NLK_TV_MAXIT || c->tv_host->fin_stop < NLK_TV_MAXIT ||
+          c->tv_host->last >= NLK_TV_MAXIT)
+        break;
     }
     // where the state of iteration `last` lives: written by batch ceil(last / K), batches alternate
     const int used = (c->tv_host->last + NLK_TV_K - 1) / NLK_TV_K;
     const bool final_is_start = (used % 2) == 0;
     const NlkTvBuf fin = final_is_start ? (cur_is_a ? A : B) : (cur_is_a ? B : A);
     L.u1 = fin.u1; L.u2 = fin.u2; L.p11 = fin.p11; L.p12 = fin.p12; L.p21 = fin.p21; L.p22 = fin.p22;
-    (void)batches;
+    if (getenv("NLK_TV_TRACE"))
+      fprintf(stderr, "tvl1 %dx%d warp %d: %d iterations, %d batches launched\n", nx, ny, wi, c->tv_host->last, batches);
   }
   if (L.u1 != u1) {  // the level's flow belongs in the pyramid arrays
     HIPCHK(c, hipMemcpyAsync(u1, L.u1, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
@@ -176,7 +191,7 @@ int nlk_dev_tvl1_flow(nlk_ctx* c, float* flow, const float* I0, const float* I1,
   const size_t n0 = (size_t)w * h;
   // scratch: 4 pyramids (I0, I1, u1, u2) + 10 work images + 2 temporaries at full size + partial sums
   const size_t nparts0 = (size_t)((w + 63) / 64) * ((h + 3) / 4);  // workgroups of an iteration kernel at full size
-  const size_t floats = 4 * pyr + 18 * n0 + NLK_TV_K * nparts0 + 64;
+  const size_t floats = 4 * pyr + 18 * n0 + 2 * NLK_TV_K * nparts0 + 64;
   int rc = reserve(c, c->tv, sizeof(float) * floats);
   if (rc) return rc;
   if (!c->tv_host) HIPCHK(c, hipHostMalloc((void**)&c->tv_host, sizeof(NlkTvState)));
@@ -191,7 +206,7 @@ int nlk_dev_tvl1_flow(nlk_ctx* c, float* flow, const float* I0, const float* I1,
   float* tmp = q; q += n0;
   float* tmp2 = q; q += n0;
   float* alt = q; q += 6 * n0;  // second state buffer of the blocked driver
-  float* part = q; q += NLK_TV_K * nparts0;
+  float* part = q; q += 2 * NLK_TV_K * nparts0;  // two batches' partial sums
   NlkTvState* st = (NlkTvState*)q;  // 64 floats reserved
   int* mm = (int*)(q + 8);
 
