@@ -206,20 +206,19 @@ __device__ __forceinline__ void nlk_tv_primal_core(float rho_c, float gx, float 
                                                    float& na, float& nb) {
 #pragma clang fp contract(off)
   const float rho = rho_c + (gx * a + gy * b);
-  float d1, d2;
-  if (rho < -l_t * g) {
-    d1 = l_t * gx;
-    d2 = l_t * gy;
-  } else if (rho > l_t * g) {
-    d1 = -l_t * gx;
-    d2 = -l_t * gy;
-  } else if (g < 1E-10) {
-    d1 = d2 = 0;
-  } else {
-    const float fi = -rho / g;
-    d1 = fi * gx;
-    d2 = fi * gy;
-  }
+  // the four cases of the thresholding as selects (all four occur inside most wavefronts, so
+  // branches only serialise them): same values as the reference's if / else chain
+  const float lg = l_t * g;
+  const float fi = -rho / g;                       // (unused where g < 1e-10: may be inf / nan there)
+  const float t1 = l_t * gx, t2 = l_t * gy;
+  float d1 = fi * gx, d2 = fi * gy;
+  const bool flat = g < 1E-10, hi = rho > lg, lo = rho < -lg;
+  d1 = flat ? 0.f : d1;
+  d2 = flat ? 0.f : d2;
+  d1 = hi ? -t1 : d1;
+  d2 = hi ? -t2 : d2;
+  d1 = lo ? t1 : d1;
+  d2 = lo ? t2 : d2;
   const float v1 = a + d1, v2 = b + d2;
   na = v1 + theta * dv1;
   nb = v2 + theta * dv2;
@@ -324,35 +323,97 @@ __device__ __forceinline__ float nlk_tv_block_sum(float e, float* redf) {
 }
 
 __global__ void __launch_bounds__(NLK_TV_THREADS) k_tv_level_wg(NlkTvLevel L) {
+#pragma clang fp contract(off)
+  // the flow and the dual variables of the whole level live in LDS, the per-warp constants of a
+  // thread's pixels in registers: an iteration costs two LDS round trips instead of two trips to L2
+  constexpr int SL = (NLK_TV_WG_PIXELS + NLK_TV_THREADS - 1) / NLK_TV_THREADS;
   __shared__ float redf[NLK_TV_WAVES];
-  const int npix = L.nx * L.ny;
-#define NLK_TV_ALL(body)                                         \
-  for (int p_ = threadIdx.x; p_ < npix; p_ += NLK_TV_THREADS) { \
-    const int i = p_ / L.nx, j = p_ - i * L.nx;                  \
-    body;                                                        \
+  __shared__ float s_u1[NLK_TV_WG_PIXELS], s_u2[NLK_TV_WG_PIXELS];
+  __shared__ float s_p11[NLK_TV_WG_PIXELS], s_p12[NLK_TV_WG_PIXELS], s_p21[NLK_TV_WG_PIXELS], s_p22[NLK_TV_WG_PIXELS];
+  const int nx = L.nx, ny = L.ny, npix = nx * ny;
+  int pi[SL], pj[SL];
+  bool on[SL];
+#pragma unroll
+  for (int m = 0; m < SL; ++m) {
+    const int p = threadIdx.x + NLK_TV_THREADS * m;
+    on[m] = p < npix;
+    pi[m] = p / nx;
+    pj[m] = p - pi[m] * nx;
+    if (on[m]) {
+      nlk_tv_px_init(L, pi[m], pj[m]);  // (centred gradient of I1 for the sampling; p = 0)
+      s_u1[p] = L.u1[p];
+      s_u2[p] = L.u2[p];
+      s_p11[p] = s_p12[p] = s_p21[p] = s_p22[p] = 0.f;
+    }
   }
-  NLK_TV_ALL(nlk_tv_px_init(L, i, j))
   __syncthreads();
   int total = 0;
   for (int wi = 0; wi < L.nwarps; ++wi) {
-    NLK_TV_ALL(nlk_tv_px_warp(L, i, j))
-    __syncthreads();
+    float rc[SL], gx[SL], gy[SL], gr[SL];
+#pragma unroll
+    for (int m = 0; m < SL; ++m) {
+      const int p = threadIdx.x + NLK_TV_THREADS * m;
+      rc[m] = gx[m] = gy[m] = gr[m] = 0.f;
+      if (!on[m]) continue;
+      if (wi > 0) {  // the warp samples at x + u: own pixel only
+        L.u1[p] = s_u1[p];
+        L.u2[p] = s_u2[p];
+      }
+      nlk_tv_px_warp(L, pi[m], pj[m]);
+      rc[m] = L.rho_c[p]; gx[m] = L.I1wx[p]; gy[m] = L.I1wy[p]; gr[m] = L.grad[p];
+    }
     float err = INFINITY;
     int n = 0;
     while (err > L.eps2 && n < NLK_TV_MAXIT) {  // reference: tvl1flow_lib.c:166
       ++n;
       float e = 0.f;
-      NLK_TV_ALL(e += nlk_tv_px_primal(L, i, j))
+#pragma unroll
+      for (int m = 0; m < SL; ++m) {
+        if (!on[m]) continue;
+        const int p = threadIdx.x + NLK_TV_THREADS * m, i = pi[m], j = pj[m];
+        const bool top = i == 0, bot = i == ny - 1, lef = j == 0, rig = j == nx - 1;
+        const int pl = lef ? p : p - 1, pu = top ? p : p - nx;
+        const float a = s_u1[p], b = s_u2[p];
+        float na, nb;
+        nlk_tv_primal_core(rc[m], gx[m], gy[m], gr[m], a, b,
+                           nlk_tv_div_core(s_p11[p], s_p11[pl], s_p12[p], s_p12[pu], top, bot, lef, rig),
+                           nlk_tv_div_core(s_p21[p], s_p21[pl], s_p22[p], s_p22[pu], top, bot, lef, rig),
+                           L.l_t, L.theta, na, nb);
+        s_u1[p] = na;
+        s_u2[p] = nb;
+        e += (na - a) * (na - a) + (nb - b) * (nb - b);
+      }
       // fixed-order sum (the reference adds the pixels one by one in float, which rounds
       // differently in the last bits); its barriers also separate the two halves
       err = nlk_tv_block_sum(e, redf);
       err /= (float)npix;
-      NLK_TV_ALL(nlk_tv_px_dual(L, i, j))
+#pragma unroll
+      for (int m = 0; m < SL; ++m) {
+        if (!on[m]) continue;
+        const int p = threadIdx.x + NLK_TV_THREADS * m, i = pi[m], j = pj[m];
+        const int pr = j < nx - 1 ? p + 1 : p, pd = i < ny - 1 ? p + nx : p;
+        const float a = s_u1[p], b = s_u2[p];
+        const float ax = j < nx - 1 ? s_u1[pr] - a : 0.f, ay = i < ny - 1 ? s_u1[pd] - a : 0.f;
+        const float bx = j < nx - 1 ? s_u2[pr] - b : 0.f, by = i < ny - 1 ? s_u2[pd] - b : 0.f;
+        float p11 = s_p11[p], p12 = s_p12[p], p21 = s_p21[p], p22 = s_p22[p];
+        nlk_tv_dual_core(p11, p12, p21, p22, ax, ay, bx, by, L.taut);
+        s_p11[p] = p11;
+        s_p12[p] = p12;
+        s_p21[p] = p21;
+        s_p22[p] = p22;
+      }
       __syncthreads();
     }
     total += n;
   }
-#undef NLK_TV_ALL
+#pragma unroll
+  for (int m = 0; m < SL; ++m) {
+    const int p = threadIdx.x + NLK_TV_THREADS * m;
+    if (on[m]) {
+      L.u1[p] = s_u1[p];
+      L.u2[p] = s_u2[p];
+    }
+  }
   if (threadIdx.x == 0) L.st->iters += total;
 }
 
@@ -436,7 +497,10 @@ __global__ void __launch_bounds__(256) k_tv_dual(NlkTvLevel L, int n, int nparts
 #define NLK_TV_TH2 32  // with enough tiles to fill the chip, 32 (72 x 40: 3 slots for 2 tile pixels)
 #define NLK_TV_RW (NLK_TV_TW + 2 * NLK_TV_K)
 #define NLK_TV_BT 1024  // threads of a k_tv_block workgroup: the coarse levels have few tiles, so a tile
-                        // must finish fast rather than leave room for others
+                        // must finish fast rather than leave room for others;
+#ifndef NLK_TV_BT2
+#define NLK_TV_BT2 512  // large grids: two workgroups per CU overlap one's loads / stores with the other's arithmetic
+#endif
 
 struct NlkTvBuf {
   float *u1, *u2, *p11, *p12, *p21, *p22;
@@ -482,11 +546,11 @@ __device__ __forceinline__ int nlk_tv_judge(const NlkTvLevel& L, const float* __
 // batch); 3: closes a group whose batches were all judged by k_tv_decide.
 // Judging inside the batches saves a launch per batch where the grid is small (every workgroup
 // re-adds all partial sums: cheap for a few hundred workgroups, not for thousands)
-template <int TH>
-__global__ void __launch_bounds__(NLK_TV_BT)
+template <int TH, int BT>
+__global__ void __launch_bounds__(BT, 4)  // (>= 4 wavefronts per SIMD: 16 per CU either way)
 k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode) {
 #pragma clang fp contract(off)
-  constexpr int RH = TH + 2 * NLK_TV_K, RPT = (NLK_TV_RW * RH + NLK_TV_BT - 1) / NLK_TV_BT;
+  constexpr int RH = TH + 2 * NLK_TV_K, RPT = (NLK_TV_RW * RH + BT - 1) / BT;
   __shared__ double red[NLK_TV_K][4];
   __shared__ float errs[NLK_TV_K];
   const int nblocks = gridDim.x * gridDim.y, block = blockIdx.y * gridDim.x + blockIdx.x;
@@ -536,7 +600,7 @@ k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode)
   __shared__ float s_u1[NLK_TV_RW * RH], s_u2[NLK_TV_RW * RH];
   __shared__ float s_p11[NLK_TV_RW * RH], s_p12[NLK_TV_RW * RH];
   __shared__ float s_p21[NLK_TV_RW * RH], s_p22[NLK_TV_RW * RH];
-  __shared__ float redf[NLK_TV_BT / 64];
+  __shared__ float redf[BT / 64];
   const int nx = L.nx, ny = L.ny;
   const int rx0 = blockIdx.x * NLK_TV_TW - NLK_TV_K, ry0 = blockIdx.y * TH - NLK_TV_K;
   // the region pixels of this thread: index in the region, in the image, constants of the warp
@@ -545,7 +609,7 @@ k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode)
   float rc[RPT], gx[RPT], gy[RPT], gr[RPT];
 #pragma unroll
   for (int m = 0; m < RPT; ++m) {
-    const int r = threadIdx.x + NLK_TV_BT * m;
+    const int r = threadIdx.x + BT * m;
     const int ly = r / NLK_TV_RW, lx = r - ly * NLK_TV_RW;
     const int j = rx0 + lx, i = ry0 + ly;
     on[m] = r < NLK_TV_RW * RH && j >= 0 && j < nx && i >= 0 && i < ny;
@@ -567,17 +631,22 @@ k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode)
 #pragma unroll
     for (int m = 0; m < RPT; ++m) {
       if (!on[m]) continue;
-      const int r = threadIdx.x + NLK_TV_BT * m;
+      const int r = threadIdx.x + BT * m;
       const int ly = r / NLK_TV_RW, lx = r - ly * NLK_TV_RW;
       const int j = rx0 + lx, i = ry0 + ly;
-      const bool top = i == 0, bot = i == ny - 1, lef = j == 0, rig = j == nx - 1;
       const int rl = lx > 0 ? r - 1 : r, ru = ly > 0 ? r - NLK_TV_RW : r;  // (region edge: value unused or stale halo)
       const float a = s_u1[r], b = s_u2[r];
+      const float p11c = s_p11[r], p11l = s_p11[rl], p12c = s_p12[r], p12u = s_p12[ru];
+      const float p21c = s_p21[r], p21l = s_p21[rl], p22c = s_p22[r], p22u = s_p22[ru];
+      float dv1 = (p11c - p11l) + (p12c - p12u), dv2 = (p21c - p21l) + (p22c - p22u);  // interior pixel
+      if (__builtin_expect(i == 0 || i == ny - 1 || j == 0 || j == nx - 1, 0)) {
+        const bool top = i == 0, bot = i == ny - 1, lef = j == 0, rig = j == nx - 1;
+        dv1 = nlk_tv_div_core(p11c, p11l, p12c, p12u, top, bot, lef, rig);
+        dv2 = nlk_tv_div_core(p21c, p21l, p22c, p22u, top, bot, lef, rig);
+      }
       float na, nb;
       nlk_tv_primal_core(rc[m], gx[m], gy[m], gr[m], a, b,
-                         nlk_tv_div_core(s_p11[r], s_p11[rl], s_p12[r], s_p12[ru], top, bot, lef, rig),
-                         nlk_tv_div_core(s_p21[r], s_p21[rl], s_p22[r], s_p22[ru], top, bot, lef, rig),
-                         L.l_t, L.theta, na, nb);
+                         dv1, dv2, L.l_t, L.theta, na, nb);
       s_u1[r] = na;  // (u is read at the own pixel only in this half)
       s_u2[r] = nb;
       if (mine[m]) e += (na - a) * (na - a) + (nb - b) * (nb - b);
@@ -587,7 +656,7 @@ k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode)
 #pragma unroll
     for (int m = 0; m < RPT; ++m) {
       if (!on[m]) continue;
-      const int r = threadIdx.x + NLK_TV_BT * m;
+      const int r = threadIdx.x + BT * m;
       const int ly = r / NLK_TV_RW, lx = r - ly * NLK_TV_RW;
       const int j = rx0 + lx, i = ry0 + ly;
       const int rr = lx < NLK_TV_RW - 1 ? r + 1 : r, rd = ly < RH - 1 ? r + NLK_TV_RW : r;
@@ -606,7 +675,7 @@ k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode)
 #pragma unroll
   for (int m = 0; m < RPT; ++m) {
     if (!mine[m]) continue;
-    const int r = threadIdx.x + NLK_TV_BT * m;
+    const int r = threadIdx.x + BT * m;
     out.u1[gidx[m]] = s_u1[r];
     out.u2[gidx[m]] = s_u2[r];
     out.p11[gidx[m]] = s_p11[r];

@@ -48,7 +48,8 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
   L.part = part; L.st = st;
   L.nx = nx; L.ny = ny; L.nwarps = P.nwarps;
   L.l_t = P.lambda * P.theta; L.theta = P.theta; L.taut = P.tau / P.theta; L.eps2 = P.epsilon * P.epsilon;
-  const size_t wg_max = getenv("NLK_TV_WG_PIXELS") ? (size_t)atoi(getenv("NLK_TV_WG_PIXELS")) : NLK_TV_WG_PIXELS;
+  size_t wg_max = getenv("NLK_TV_WG_PIXELS") ? (size_t)atoi(getenv("NLK_TV_WG_PIXELS")) : NLK_TV_WG_PIXELS;
+  if (wg_max > NLK_TV_WG_PIXELS) wg_max = NLK_TV_WG_PIXELS;  // (the kernel's LDS arrays)
   if (n <= wg_max) {  // the whole level inside one workgroup
     hipLaunchKernelGGL(k_tv_level_wg, dim3(1), dim3(NLK_TV_THREADS), 0, c->stream, L);
     HIPCHK(c, hipGetLastError());
@@ -84,11 +85,19 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
   // buffer written by batch ceil(stop / K).
   NlkTvBuf A = {u1, u2, L.p11, L.p12, L.p21, L.p22};
   NlkTvBuf B = {alt, alt + n, alt + 2 * n, alt + 3 * n, alt + 4 * n, alt + 5 * n};
-  // tall tiles do a quarter less halo work; they need enough tiles to keep every CU busy
-  const int nb16 = ((nx + NLK_TV_TW - 1) / NLK_TV_TW) * ((ny + NLK_TV_TH - 1) / NLK_TV_TH);
-  const bool tall = nb16 >= (getenv("NLK_TV_TALL") ? atoi(getenv("NLK_TV_TALL")) : 400);
-  const int th = tall ? NLK_TV_TH2 : NLK_TV_TH;
-  const auto block_kernel = tall ? k_tv_block<NLK_TV_TH2> : k_tv_block<NLK_TV_TH>;
+  // tile shape by the number of tiles: tall tiles do a quarter less halo work but need enough tiles to
+  // keep every CU busy; with at least two tall tiles per CU, workgroups of 512 (two per CU) let one
+  // tile load or store while the other computes
+  const int tx = (nx + NLK_TV_TW - 1) / NLK_TV_TW;
+  const int nb16 = tx * ((ny + NLK_TV_TH - 1) / NLK_TV_TH), nb32 = tx * ((ny + NLK_TV_TH2 - 1) / NLK_TV_TH2);
+  int shape = nb32 >= 512 ? 2 : nb16 >= 400 ? (getenv("NLK_TV_MID") ? atoi(getenv("NLK_TV_MID")) : 1) : 0;
+  if (getenv("NLK_TV_SHAPE")) shape = atoi(getenv("NLK_TV_SHAPE"));
+  const int th = shape >= 1 && shape <= 2 ? NLK_TV_TH2 : NLK_TV_TH;
+  const int bt = shape >= 2 ? NLK_TV_BT2 : NLK_TV_BT;
+  const auto block_kernel = shape == 0 ? k_tv_block<NLK_TV_TH, NLK_TV_BT>
+                          : shape == 1 ? k_tv_block<NLK_TV_TH2, NLK_TV_BT>
+                          : shape == 2 ? k_tv_block<NLK_TV_TH2, NLK_TV_BT2>
+                                       : k_tv_block<NLK_TV_TH, NLK_TV_BT2>;
   const dim3 bgrid((nx + NLK_TV_TW - 1) / NLK_TV_TW, (ny + th - 1) / th);
   const int nblocks = bgrid.x * bgrid.y;
   const bool inline_judge = nblocks <= (getenv("NLK_TV_INLINE") ? atoi(getenv("NLK_TV_INLINE")) : 600);
@@ -103,7 +112,7 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
     while (n0 < NLK_TV_MAXIT) {
       for (int q = 0; q < look && n0 < NLK_TV_MAXIT; ++q) {
         const int count = NLK_TV_MAXIT - n0 < NLK_TV_K ? NLK_TV_MAXIT - n0 : NLK_TV_K;
-        hipLaunchKernelGGL(block_kernel, bgrid, dim3(NLK_TV_BT), 0, c->stream, L, cur, oth, n0, count,
+        hipLaunchKernelGGL(block_kernel, bgrid, dim3(bt), 0, c->stream, L, cur, oth, n0, count,
                            inline_judge && q ? 2 : 0);
         if (!inline_judge) hipLaunchKernelGGL(k_tv_decide, dim3(1), dim3(256), 0, c->stream, L, n0, count, nblocks);
         last_n0 = n0;
@@ -114,7 +123,7 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
       }
       // the batch that ran past the stop (if any) is redone from its input, once per group
       // (it also judges the group's last batch)
-      hipLaunchKernelGGL(block_kernel, bgrid, dim3(NLK_TV_BT), 0, c->stream, L, first, second, last_n0, last_count,
+      hipLaunchKernelGGL(block_kernel, bgrid, dim3(bt), 0, c->stream, L, first, second, last_n0, last_count,
                          inline_judge ? 1 : 3);
       HIPCHK(c, hipMemcpyAsync(c->tv_host, st, sizeof(NlkTvState), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
