@@ -99,7 +99,12 @@ __global__ void k_tv_minmax(const float* __restrict__ a, const float* __restrict
     lo = fminf(lo, __shfl_xor(lo, off, 64));
     hi = fmaxf(hi, __shfl_xor(hi, off, 64));
   }
-  if ((threadIdx.x & 63) == 0) {
+  // one pair of atomics per workgroup (thousands of them on two addresses cost 0.1 ms)
+  __shared__ float s_lo[16], s_hi[16];
+  if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < (int)(blockDim.x >> 6); ++k) { lo = fminf(lo, s_lo[k]); hi = fmaxf(hi, s_hi[k]); }
     atomicMin(&mm[0], nlk_tv_ord(lo));
     atomicMax(&mm[1], nlk_tv_ord(hi));
   }
@@ -125,11 +130,15 @@ struct NlkTvGauss {
   int rad;
 };
 
-__global__ void k_tv_gauss(const float* __restrict__ in, float* __restrict__ out, int nx, int ny,
+// (blockIdx.z picks one of two images: both frames / both flow components go through in one launch)
+__global__ void k_tv_gauss(const float* __restrict__ in_a, float* __restrict__ out_a,
+                           const float* __restrict__ in_b, float* __restrict__ out_b, int nx, int ny,
                            NlkTvGauss g, int vertical) {
 #pragma clang fp contract(off)
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= nx || y >= ny) return;
+  const float* __restrict__ in = blockIdx.z ? in_b : in_a;
+  float* __restrict__ out = blockIdx.z ? out_b : out_a;
   const int n = vertical ? ny : nx, c = vertical ? y : x;
   const int stride = vertical ? nx : 1;
   const float* line = in + (vertical ? x : y * nx);
@@ -148,11 +157,14 @@ __global__ void k_tv_init_minmax(int* mm) {
 }
 
 // ---- resampling (reference: zoom.c:44-108): out[i1][j1] = in(j1 / fx, i1 / fy) * gain
-__global__ void k_tv_zoom(const float* __restrict__ in, float* __restrict__ out, int nx, int ny,
+__global__ void k_tv_zoom(const float* __restrict__ in_a, float* __restrict__ out_a,
+                          const float* __restrict__ in_b, float* __restrict__ out_b, int nx, int ny,
                           int nxx, int nyy, float fx, float fy, float gain, int use_gain) {
 #pragma clang fp contract(off)
   const int j1 = blockIdx.x * blockDim.x + threadIdx.x, i1 = blockIdx.y * blockDim.y + threadIdx.y;
   if (j1 >= nxx || i1 >= nyy) return;
+  const float* __restrict__ in = blockIdx.z ? in_b : in_a;
+  float* __restrict__ out = blockIdx.z ? out_b : out_a;
   const NlkTvTaps t = nlk_tv_taps((float)j1 / fx, (float)i1 / fy, nx, ny);
   const float g = nlk_tv_sample(in, t, nx);  // border_out = false
   out[i1 * nxx + j1] = use_gain ? g * gain : g;
@@ -489,13 +501,11 @@ __global__ void __launch_bounds__(256) k_tv_dual(NlkTvLevel L, int n, int nparts
 //               judges the group's last batch. A launch never reads a state field it writes
 //               (workgroups of one launch do not run together), except `stop_iter`, where both
 //               values lead to the same action.
-#ifndef NLK_TV_K
-#define NLK_TV_K 4
-#endif
+#define NLK_TV_K 4   // iterations per launch where the grid fills the chip (halo work grows with K),
+#define NLK_TV_K2 8  // and on the small levels, whose launches are latency-bound
 #define NLK_TV_TW 64
 #define NLK_TV_TH 16   // tile rows: 16 (region 72 x 24: 2 pixel slots per thread for 1 tile pixel) or, for levels
 #define NLK_TV_TH2 32  // with enough tiles to fill the chip, 32 (72 x 40: 3 slots for 2 tile pixels)
-#define NLK_TV_RW (NLK_TV_TW + 2 * NLK_TV_K)
 #define NLK_TV_BT 1024  // threads of a k_tv_block workgroup: the coarse levels have few tiles, so a tile
                         // must finish fast rather than leave room for others;
 #ifndef NLK_TV_BT2
@@ -508,24 +518,25 @@ struct NlkTvBuf {
 
 // the stop test over the partial sums of one batch, by every thread of the workgroup alike:
 // number of iterations of the batch that count (the first with error <= eps^2 is the last one)
+template <int KI>
 __device__ __forceinline__ int nlk_tv_judge(const NlkTvLevel& L, const float* __restrict__ part, int nblocks,
                                             int count, double (*red)[4], float* errs, bool& stop, float& err) {
   if (threadIdx.x < 256) {
-    double s[NLK_TV_K];
+    double s[KI];
 #pragma unroll
-    for (int k = 0; k < NLK_TV_K; ++k) {
+    for (int k = 0; k < KI; ++k) {
       s[k] = 0.0;
       if (k < count)
         for (int b = threadIdx.x; b < nblocks; b += 256) s[k] += (double)part[k * nblocks + b];
     }
 #pragma unroll
-    for (int k = 0; k < NLK_TV_K; ++k) {
+    for (int k = 0; k < KI; ++k) {
       for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off, 64);
       if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s[k];
     }
   }
   __syncthreads();
-  if (threadIdx.x < NLK_TV_K)
+  if (threadIdx.x < KI)
     errs[threadIdx.x] = (float)((red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3])) /
                         (float)(L.nx * L.ny);
   __syncthreads();
@@ -546,13 +557,13 @@ __device__ __forceinline__ int nlk_tv_judge(const NlkTvLevel& L, const float* __
 // batch); 3: closes a group whose batches were all judged by k_tv_decide.
 // Judging inside the batches saves a launch per batch where the grid is small (every workgroup
 // re-adds all partial sums: cheap for a few hundred workgroups, not for thousands)
-template <int TH, int BT>
+template <int TH, int BT, int KI>
 __global__ void __launch_bounds__(BT, 4)  // (>= 4 wavefronts per SIMD: 16 per CU either way)
 k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode) {
 #pragma clang fp contract(off)
-  constexpr int RH = TH + 2 * NLK_TV_K, RPT = (NLK_TV_RW * RH + BT - 1) / BT;
-  __shared__ double red[NLK_TV_K][4];
-  __shared__ float errs[NLK_TV_K];
+  constexpr int RW = NLK_TV_TW + 2 * KI, RH = TH + 2 * KI, RPT = (RW * RH + BT - 1) / BT;
+  __shared__ double red[KI][4];
+  __shared__ float errs[KI];
   const int nblocks = gridDim.x * gridDim.y, block = blockIdx.y * gridDim.x + blockIdx.x;
   if (mode == 1 || mode == 3) {
     if (L.st->stop_iter < NLK_TV_MAXIT) {  // found by a batch of this group
@@ -564,7 +575,7 @@ k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode)
     } else {
       bool stop;
       float err;
-      const int done = nlk_tv_judge(L, L.part + ((n0 / NLK_TV_K) & 1) * NLK_TV_K * nblocks, nblocks, count, red,
+      const int done = nlk_tv_judge<KI>(L, L.part + ((n0 / KI) & 1) * KI * nblocks, nblocks, count, red,
                                     errs, stop, err);
       if (block == 0 && threadIdx.x == 0) {
         L.st->iters += done;
@@ -575,34 +586,34 @@ k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode)
       if (!stop || done == count) return;
       count = done;
     }
-    if ((n0 / NLK_TV_K) & 1) { const NlkTvBuf t = in; in = out; out = t; }
+    if ((n0 / KI) & 1) { const NlkTvBuf t = in; in = out; out = t; }
   } else {
     if (n0 >= L.st->stop_iter) return;
     if (mode == 2) {
-      const int n0p = n0 - NLK_TV_K;
+      const int n0p = n0 - KI;
       bool stop;
       float err;
-      const int done = nlk_tv_judge(L, L.part + ((n0p / NLK_TV_K) & 1) * NLK_TV_K * nblocks, nblocks, NLK_TV_K,
+      const int done = nlk_tv_judge<KI>(L, L.part + ((n0p / KI) & 1) * KI * nblocks, nblocks, KI,
                                     red, errs, stop, err);
       if (block == 0 && threadIdx.x == 0) {
         L.st->iters += done;
         L.st->last = n0p + done;
         L.st->error = err;
         if (stop) {
-          if (done < NLK_TV_K) { L.st->redo = done; L.st->redo_n0 = n0p; }
+          if (done < KI) { L.st->redo = done; L.st->redo_n0 = n0p; }
           L.st->stop_iter = n0p + done;
         }
       }
       if (stop) return;
     }
   }
-  float* const part = L.part + ((n0 / NLK_TV_K) & 1) * NLK_TV_K * nblocks;
-  __shared__ float s_u1[NLK_TV_RW * RH], s_u2[NLK_TV_RW * RH];
-  __shared__ float s_p11[NLK_TV_RW * RH], s_p12[NLK_TV_RW * RH];
-  __shared__ float s_p21[NLK_TV_RW * RH], s_p22[NLK_TV_RW * RH];
+  float* const part = L.part + ((n0 / KI) & 1) * KI * nblocks;
+  __shared__ float s_u1[RW * RH], s_u2[RW * RH];
+  __shared__ float s_p11[RW * RH], s_p12[RW * RH];
+  __shared__ float s_p21[RW * RH], s_p22[RW * RH];
   __shared__ float redf[BT / 64];
   const int nx = L.nx, ny = L.ny;
-  const int rx0 = blockIdx.x * NLK_TV_TW - NLK_TV_K, ry0 = blockIdx.y * TH - NLK_TV_K;
+  const int rx0 = blockIdx.x * NLK_TV_TW - KI, ry0 = blockIdx.y * TH - KI;
   // the region pixels of this thread: index in the region, in the image, constants of the warp
   int gidx[RPT];
   bool on[RPT], mine[RPT];
@@ -610,13 +621,13 @@ k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode)
 #pragma unroll
   for (int m = 0; m < RPT; ++m) {
     const int r = threadIdx.x + BT * m;
-    const int ly = r / NLK_TV_RW, lx = r - ly * NLK_TV_RW;
+    const int ly = r / RW, lx = r - ly * RW;
     const int j = rx0 + lx, i = ry0 + ly;
-    on[m] = r < NLK_TV_RW * RH && j >= 0 && j < nx && i >= 0 && i < ny;
-    mine[m] = on[m] && lx >= NLK_TV_K && lx < NLK_TV_K + NLK_TV_TW && ly >= NLK_TV_K && ly < NLK_TV_K + TH;
+    on[m] = r < RW * RH && j >= 0 && j < nx && i >= 0 && i < ny;
+    mine[m] = on[m] && lx >= KI && lx < KI + NLK_TV_TW && ly >= KI && ly < KI + TH;
     gidx[m] = on[m] ? i * nx + j : 0;
     rc[m] = L.rho_c[gidx[m]]; gx[m] = L.I1wx[gidx[m]]; gy[m] = L.I1wy[gidx[m]]; gr[m] = L.grad[gidx[m]];
-    if (r < NLK_TV_RW * RH) {
+    if (r < RW * RH) {
       s_u1[r] = on[m] ? in.u1[gidx[m]] : 0.f;
       s_u2[r] = on[m] ? in.u2[gidx[m]] : 0.f;
       s_p11[r] = on[m] ? in.p11[gidx[m]] : 0.f;
@@ -632,9 +643,9 @@ k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode)
     for (int m = 0; m < RPT; ++m) {
       if (!on[m]) continue;
       const int r = threadIdx.x + BT * m;
-      const int ly = r / NLK_TV_RW, lx = r - ly * NLK_TV_RW;
+      const int ly = r / RW, lx = r - ly * RW;
       const int j = rx0 + lx, i = ry0 + ly;
-      const int rl = lx > 0 ? r - 1 : r, ru = ly > 0 ? r - NLK_TV_RW : r;  // (region edge: value unused or stale halo)
+      const int rl = lx > 0 ? r - 1 : r, ru = ly > 0 ? r - RW : r;  // (region edge: value unused or stale halo)
       const float a = s_u1[r], b = s_u2[r];
       const float p11c = s_p11[r], p11l = s_p11[rl], p12c = s_p12[r], p12u = s_p12[ru];
       const float p21c = s_p21[r], p21l = s_p21[rl], p22c = s_p22[r], p22u = s_p22[ru];
@@ -657,9 +668,9 @@ k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode)
     for (int m = 0; m < RPT; ++m) {
       if (!on[m]) continue;
       const int r = threadIdx.x + BT * m;
-      const int ly = r / NLK_TV_RW, lx = r - ly * NLK_TV_RW;
+      const int ly = r / RW, lx = r - ly * RW;
       const int j = rx0 + lx, i = ry0 + ly;
-      const int rr = lx < NLK_TV_RW - 1 ? r + 1 : r, rd = ly < RH - 1 ? r + NLK_TV_RW : r;
+      const int rr = lx < RW - 1 ? r + 1 : r, rd = ly < RH - 1 ? r + RW : r;
       const float a = s_u1[r], b = s_u2[r];
       const float ax = j < nx - 1 ? s_u1[rr] - a : 0.f, ay = i < ny - 1 ? s_u1[rd] - a : 0.f;
       const float bx = j < nx - 1 ? s_u2[rr] - b : 0.f, by = i < ny - 1 ? s_u2[rd] - b : 0.f;
@@ -686,13 +697,14 @@ k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode)
 }
 
 // large grids: one workgroup judges batch (n0, count) between two batches
+template <int KI>
 __global__ void __launch_bounds__(256) k_tv_decide(NlkTvLevel L, int n0, int count, int nblocks) {
   if (n0 >= L.st->stop_iter) return;
-  __shared__ double red[NLK_TV_K][4];
-  __shared__ float errs[NLK_TV_K];
+  __shared__ double red[KI][4];
+  __shared__ float errs[KI];
   bool stop;
   float err;
-  const int done = nlk_tv_judge(L, L.part + ((n0 / NLK_TV_K) & 1) * NLK_TV_K * nblocks, nblocks, count, red, errs,
+  const int done = nlk_tv_judge<KI>(L, L.part + ((n0 / KI) & 1) * KI * nblocks, nblocks, count, red, errs,
                                 stop, err);
   if (threadIdx.x == 0) {
     L.st->iters += done;

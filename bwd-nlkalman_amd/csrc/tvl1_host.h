@@ -22,17 +22,18 @@ int tv_gauss_kernel(nlk_ctx* c, double sigma, int nx, int ny, NlkTvGauss* g) {
   return NLK_OK;
 }
 
-inline dim3 tv_grid(int nx, int ny) { return dim3((nx + 31) / 32, (ny + 7) / 8); }
+inline dim3 tv_grid(int nx, int ny, int images = 1) { return dim3((nx + 31) / 32, (ny + 7) / 8, images); }
 const dim3 tv_block(32, 8);
 
-// in -> out (may alias), tmp = scratch of the same size
-int tv_gaussian(nlk_ctx* c, const float* in, float* out, float* tmp, int nx, int ny, double sigma) {
+// two images at once: in -> out (may alias), tmp = scratch of the same size
+int tv_gaussian2(nlk_ctx* c, const float* in_a, float* out_a, float* tmp_a, const float* in_b, float* out_b,
+                 float* tmp_b, int nx, int ny, double sigma) {
   NlkTvGauss g;
   int rc = tv_gauss_kernel(c, sigma, nx, ny, &g);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_tv_gauss, tv_grid(nx, ny), tv_block, 0, c->stream, in, tmp, nx, ny, g, 0);
-  hipLaunchKernelGGL(k_tv_gauss, tv_grid(nx, ny), tv_block, 0, c->stream, (const float*)tmp, out, nx,
-                     ny, g, 1);
+  hipLaunchKernelGGL(k_tv_gauss, tv_grid(nx, ny, 2), tv_block, 0, c->stream, in_a, tmp_a, in_b, tmp_b, nx, ny, g, 0);
+  hipLaunchKernelGGL(k_tv_gauss, tv_grid(nx, ny, 2), tv_block, 0, c->stream, (const float*)tmp_a, out_a,
+                     (const float*)tmp_b, out_b, nx, ny, g, 1);
   HIPCHK(c, hipGetLastError());
   return NLK_OK;
 }
@@ -94,14 +95,19 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
   if (getenv("NLK_TV_SHAPE")) shape = atoi(getenv("NLK_TV_SHAPE"));
   const int th = shape >= 1 && shape <= 2 ? NLK_TV_TH2 : NLK_TV_TH;
   const int bt = shape >= 2 ? NLK_TV_BT2 : NLK_TV_BT;
-  const auto block_kernel = shape == 0 ? k_tv_block<NLK_TV_TH, NLK_TV_BT>
-                          : shape == 1 ? k_tv_block<NLK_TV_TH2, NLK_TV_BT>
-                          : shape == 2 ? k_tv_block<NLK_TV_TH2, NLK_TV_BT2>
-                                       : k_tv_block<NLK_TV_TH, NLK_TV_BT2>;
+  const bool deep = shape == 0 && getenv("NLK_TV_DEEP");  // (8 iterations per launch: measured slower, kept for experiments)
+  const int K = deep ? NLK_TV_K2 : NLK_TV_K;
+  const auto block_kernel = shape == 0 ? (deep ? k_tv_block<NLK_TV_TH, NLK_TV_BT, NLK_TV_K2> : k_tv_block<NLK_TV_TH, NLK_TV_BT, NLK_TV_K>)
+                          : shape == 1 ? k_tv_block<NLK_TV_TH2, NLK_TV_BT, NLK_TV_K>
+                          : shape == 2 ? k_tv_block<NLK_TV_TH2, NLK_TV_BT2, NLK_TV_K>
+                                       : k_tv_block<NLK_TV_TH, NLK_TV_BT2, NLK_TV_K>;
+  const auto decide_kernel = deep ? k_tv_decide<NLK_TV_K2> : k_tv_decide<NLK_TV_K>;
   const dim3 bgrid((nx + NLK_TV_TW - 1) / NLK_TV_TW, (ny + th - 1) / th);
   const int nblocks = bgrid.x * bgrid.y;
   const bool inline_judge = nblocks <= (getenv("NLK_TV_INLINE") ? atoi(getenv("NLK_TV_INLINE")) : 600);
-  const int look = getenv("NLK_TV_LOOK") ? atoi(getenv("NLK_TV_LOOK")) : 4;  // batches between two looks at the state
+  // batches between two looks at the state (a warp needs 5 to 50 iterations, mostly under 16)
+  const int look = deep ? (getenv("NLK_TV_LOOK2") ? atoi(getenv("NLK_TV_LOOK2")) : 2)
+                        : (getenv("NLK_TV_LOOK") ? atoi(getenv("NLK_TV_LOOK")) : 4);
   for (int wi = 0; wi < P.nwarps; ++wi) {
     hipLaunchKernelGGL(k_tv_warp, grid, dim3(256), 0, c->stream, L);
     NlkTvBuf cur = {L.u1, L.u2, L.p11, L.p12, L.p21, L.p22};
@@ -111,10 +117,10 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
     int n0 = 0, batches = 0, last_n0 = 0, last_count = 0;
     while (n0 < NLK_TV_MAXIT) {
       for (int q = 0; q < look && n0 < NLK_TV_MAXIT; ++q) {
-        const int count = NLK_TV_MAXIT - n0 < NLK_TV_K ? NLK_TV_MAXIT - n0 : NLK_TV_K;
+        const int count = NLK_TV_MAXIT - n0 < K ? NLK_TV_MAXIT - n0 : K;
         hipLaunchKernelGGL(block_kernel, bgrid, dim3(bt), 0, c->stream, L, cur, oth, n0, count,
                            inline_judge && q ? 2 : 0);
-        if (!inline_judge) hipLaunchKernelGGL(k_tv_decide, dim3(1), dim3(256), 0, c->stream, L, n0, count, nblocks);
+        if (!inline_judge) hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(256), 0, c->stream, L, n0, count, nblocks);
         last_n0 = n0;
         last_count = count;
         const NlkTvBuf t = cur; cur = oth; oth = t;
@@ -132,7 +138,7 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
         break;
     }
     // where the state of iteration `last` lives: written by batch ceil(last / K), batches alternate
-    const int used = (c->tv_host->last + NLK_TV_K - 1) / NLK_TV_K;
+    const int used = (c->tv_host->last + K - 1) / K;
     const bool final_is_start = (used % 2) == 0;
     const NlkTvBuf fin = final_is_start ? (cur_is_a ? A : B) : (cur_is_a ? B : A);
     L.u1 = fin.u1; L.u2 = fin.u2; L.p11 = fin.p11; L.p12 = fin.p12; L.p21 = fin.p21; L.p22 = fin.p22;
@@ -200,7 +206,7 @@ int nlk_dev_tvl1_flow(nlk_ctx* c, float* flow, const float* I0, const float* I1,
   const size_t n0 = (size_t)w * h;
   // scratch: 4 pyramids (I0, I1, u1, u2) + 10 work images + 2 temporaries at full size + partial sums
   const size_t nparts0 = (size_t)((w + 63) / 64) * ((h + 3) / 4);  // workgroups of an iteration kernel at full size
-  const size_t floats = 4 * pyr + 18 * n0 + 2 * NLK_TV_K * nparts0 + 64;
+  const size_t floats = 4 * pyr + 18 * n0 + 2 * NLK_TV_K2 * nparts0 + 64;
   int rc = reserve(c, c->tv, sizeof(float) * floats);
   if (rc) return rc;
   if (!c->tv_host) HIPCHK(c, hipHostMalloc((void**)&c->tv_host, sizeof(NlkTvState)));
@@ -215,28 +221,25 @@ int nlk_dev_tvl1_flow(nlk_ctx* c, float* flow, const float* I0, const float* I1,
   float* tmp = q; q += n0;
   float* tmp2 = q; q += n0;
   float* alt = q; q += 6 * n0;  // second state buffer of the blocked driver
-  float* part = q; q += 2 * NLK_TV_K * nparts0;  // two batches' partial sums
+  float* part = q; q += 2 * NLK_TV_K2 * nparts0;  // two batches' partial sums
   NlkTvState* st = (NlkTvState*)q;  // 64 floats reserved
   int* mm = (int*)(q + 8);
 
   // normalise both images to 0..255 with one common range, pre-smooth (reference: :376-381)
   HIPCHK(c, hipMemsetAsync(st, 0, sizeof(NlkTvState), c->stream));
   hipLaunchKernelGGL(k_tv_init_minmax, dim3(1), dim3(1), 0, c->stream, mm);
-  hipLaunchKernelGGL(k_tv_minmax, dim3(1024), dim3(256), 0, c->stream, I0, I1, (int)n0, mm);
+  hipLaunchKernelGGL(k_tv_minmax, dim3(512), dim3(1024), 0, c->stream, I0, I1, (int)n0, mm);
   hipLaunchKernelGGL(k_tv_normalize, dim3((n0 + 255) / 256), dim3(256), 0, c->stream, I0, I1, I0s[0],
                      I1s[0], (int)n0, (const int*)mm);
-  if ((rc = tv_gaussian(c, I0s[0], I0s[0], tmp, w, h, 0.8))) return rc;
-  if ((rc = tv_gaussian(c, I1s[0], I1s[0], tmp, w, h, 0.8))) return rc;
+  float *tmp_b = work, *tmp2_b = work + n0;  // (the level arrays are idle while the pyramid is built)
+  if ((rc = tv_gaussian2(c, I0s[0], I0s[0], tmp, I1s[0], I1s[0], tmp_b, w, h, 0.8))) return rc;
   // pyramid (reference: :384-398, zoom.c:44-79)
   const float zsigma = 0.6 * sqrt(1.0 / (P->zfactor * P->zfactor) - 1.0);
-  for (int s = 1; s < ns; ++s)
-    for (int k = 0; k < 2; ++k) {
-      const float* src = k ? I1s[s - 1] : I0s[s - 1];
-      float* dst = k ? I1s[s] : I0s[s];
-      if ((rc = tv_gaussian(c, src, tmp2, tmp, W[s - 1], H[s - 1], zsigma))) return rc;
-      hipLaunchKernelGGL(k_tv_zoom, tv_grid(W[s], H[s]), tv_block, 0, c->stream, (const float*)tmp2, dst,
-                         W[s - 1], H[s - 1], W[s], H[s], P->zfactor, P->zfactor, 1.f, 0);
-    }
+  for (int s = 1; s < ns; ++s) {
+    if ((rc = tv_gaussian2(c, I0s[s - 1], tmp2, tmp, I1s[s - 1], tmp2_b, tmp_b, W[s - 1], H[s - 1], zsigma))) return rc;
+    hipLaunchKernelGGL(k_tv_zoom, tv_grid(W[s], H[s], 2), tv_block, 0, c->stream, (const float*)tmp2, I0s[s],
+                       (const float*)tmp2_b, I1s[s], W[s - 1], H[s - 1], W[s], H[s], P->zfactor, P->zfactor, 1.f, 0);
+  }
   const size_t nc = (size_t)W[ns - 1] * H[ns - 1];
   HIPCHK(c, hipMemsetAsync(U1[ns - 1], 0, sizeof(float) * nc, c->stream));
   HIPCHK(c, hipMemsetAsync(U2[ns - 1], 0, sizeof(float) * nc, c->stream));
@@ -247,10 +250,8 @@ int nlk_dev_tvl1_flow(nlk_ctx* c, float* flow, const float* I0, const float* I1,
       if ((rc = tv_scale(c, I0s[s], I1s[s], U1[s], U2[s], W[s], H[s], *P, work, alt, part, st))) return rc;
     if (s == 0) break;
     const float fx = (float)W[s - 1] / W[s], fy = (float)H[s - 1] / H[s];  // zoom.c:94-95
-    for (int k = 0; k < 2; ++k)
-      hipLaunchKernelGGL(k_tv_zoom, tv_grid(W[s - 1], H[s - 1]), tv_block, 0, c->stream,
-                         (const float*)(k ? U2[s] : U1[s]), k ? U2[s - 1] : U1[s - 1], W[s], H[s], W[s - 1],
-                         H[s - 1], fx, fy, inv, 1);
+    hipLaunchKernelGGL(k_tv_zoom, tv_grid(W[s - 1], H[s - 1], 2), tv_block, 0, c->stream, (const float*)U1[s],
+                       U1[s - 1], (const float*)U2[s], U2[s - 1], W[s], H[s], W[s - 1], H[s - 1], fx, fy, inv, 1);
   }
   hipLaunchKernelGGL(k_tv_interleave, dim3((n0 + 255) / 256), dim3(256), 0, c->stream, (const float*)U1[0],
                      (const float*)U2[0], flow, (int)n0);
