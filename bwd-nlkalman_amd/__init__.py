@@ -24,7 +24,7 @@ HIP_SYMBOLS = [
     "nlk_device_count", "nlk_ctx_create", "nlk_ctx_destroy", "nlk_last_error",
     "nlk_ctx_set_profiling", "nlk_ctx_get_timings", "nlk_ctx_set_stream",
     "nlk_ctx_get_stream", "nlk_ctx_use_own_stream", "nlk_dev_alloc", "nlk_dev_free", "nlk_h2d", "nlk_d2h",
-    "nlk_d2d", "nlk_sync", "nlk_dev_rgb2opp", "nlk_dev_opp2rgb",
+    "nlk_d2d", "nlk_sync", "nlk_host_alloc", "nlk_host_free", "nlk_dev_rgb2opp", "nlk_dev_opp2rgb",
     "nlk_dev_warp_bicubic", "nlk_dev_filter_frame", "nlk_dev_smooth_frame",
     "nlk_dev_frame_accumulate", "nlk_dev_frame_normalize", "nlk_ctx_read_records",
     "nlk_dev_strip_match", "nlk_dev_mask_commit", "nlk_dev_strip_group",

@@ -430,6 +430,17 @@ int nlk_d2d(nlk_ctx* c, void* dst, const void* src, size_t n) {
   HIPCHK(c, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, c->stream));
   return NLK_OK;
 }
+int nlk_host_alloc(nlk_ctx* c, void** h, size_t n) {
+  if (!c || !h) return NLK_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipHostMalloc(h, n, hipHostMallocDefault));
+  return NLK_OK;
+}
+int nlk_host_free(nlk_ctx* c, void* h) {
+  if (!c) return NLK_EINVAL;
+  if (h) HIPCHK(c, hipHostFree(h));
+  return NLK_OK;
+}
 int nlk_sync(nlk_ctx* c) {
   if (!c) return NLK_EINVAL;
   HIPCHK(c, hipStreamSynchronize(c->stream));

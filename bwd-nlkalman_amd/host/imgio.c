@@ -100,8 +100,8 @@ static uint64_t tif_val(const tif_t *t, size_t e, uint64_t j) {
 
 static size_t lzw_decode(const unsigned char *s, size_t n, unsigned char *d, size_t cap) {
   /* TIFF LZW: MSB-first codes, 9..12 bits, early change, 256 = clear, 257 = end */
-  static uint16_t prefix[4096];
-  static unsigned char suffix[4096], stack[4096];
+  static __thread uint16_t prefix[4096];  /* (per thread: nlkalman-seq decodes and encodes files on helper threads) */
+  static __thread unsigned char suffix[4096], stack[4096];
   size_t out = 0, bitpos = 0;
   int width = 9, next = 258, prev = -1;
   for (;;) {
@@ -346,7 +346,7 @@ static int write_tiff(const char *path, const float *d, int w, int h, int ch) {
   return fclose(f);
 }
 
-static uint32_t crc_table[256];
+static __thread uint32_t crc_table[256];
 static uint32_t crc32_upd(uint32_t c, const unsigned char *b, size_t n) {
   if (!crc_table[1]) for (uint32_t i = 0; i < 256; ++i) { uint32_t k = i; for (int j = 0; j < 8; ++j) k = k & 1 ? 0xEDB88320u ^ (k >> 1) : k >> 1; crc_table[i] = k; }
   c = ~c;

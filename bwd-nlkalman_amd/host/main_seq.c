@@ -20,8 +20,14 @@
  * backwards tvl1flow(flt2_t -> smo1_{t+1}) -> mask -> warp + SMO1. Frames stay in the
  * opponent colour space between steps (the script's processes convert to RGB files and back:
  * a 1e-5 rounding on the 0..255 scale is the only numerical difference). Unlike the script,
- * flows and masks are always recomputed (it reuses files left by a previous run). */
+ * flows and masks are always recomputed (it reuses files left by a previous run).
+ *
+ * File I/O runs beside the GPU: the output files (float TIFF / .flo / PNG encoding is most of a
+ * frame's wall time) are written by a pool of threads from copies of the downloaded arrays, and
+ * the next input frame is decoded while the current one is filtered. NLK_SEQ_IO_THREADS sets
+ * the pool size (default 6; 0 = write in line). */
 #include <errno.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -63,6 +69,136 @@ static int split(const char *prog, const char *s, const char ***argv_out) {
   return n;
 }
 
+/* ---- write-behind: a bounded queue of (path, array) jobs served by worker threads. The arrays
+ * are page-locked buffers of one frame each, recycled through a pool: downloads run at the
+ * link's rate and nothing is allocated per file */
+struct wjob { char *path; float *data; int w, h, ch; struct wjob *next; };
+#define POOL_MAX 16
+static struct { float *buf[POOL_MAX]; int n; size_t bytes; } P;  /* free buffers (under Q.mu) */
+static struct {
+  pthread_mutex_t mu;
+  pthread_cond_t more, less;
+  struct wjob *head, *tail;
+  int pending, closed, failed, nthreads;
+  pthread_t th[32];
+} Q = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, NULL, 0, 0, 0, 0, {0}};
+#define WQ_MAX_PENDING 12 /* arrays waiting or being written = pool size - 1 (25 MB each at 1080p RGB) */
+
+static void *wq_worker(void *arg) {
+  (void)arg;
+  for (;;) {
+    pthread_mutex_lock(&Q.mu);
+    while (!Q.head && !Q.closed) pthread_cond_wait(&Q.more, &Q.mu);
+    struct wjob *j = Q.head;
+    if (!j) { pthread_mutex_unlock(&Q.mu); return NULL; }
+    Q.head = j->next;
+    if (!Q.head) Q.tail = NULL;
+    pthread_mutex_unlock(&Q.mu);
+    const int bad = img_write(j->path, j->data, j->w, j->h, j->ch);
+    if (bad) fprintf(stderr, "nlkalman-seq: cannot write %s\n", j->path);
+    float *data = j->data;
+    free(j->path);
+    free(j);
+    pthread_mutex_lock(&Q.mu);
+    P.buf[P.n++] = data;  /* back to the pool */
+    Q.failed |= bad != 0;
+    --Q.pending;
+    pthread_cond_signal(&Q.less);
+    pthread_mutex_unlock(&Q.mu);
+  }
+}
+
+static void wq_start(void) {
+  const char *e = getenv("NLK_SEQ_IO_THREADS");
+  Q.nthreads = e ? atoi(e) : 6;
+  if (Q.nthreads > 32) Q.nthreads = 32;
+  for (int i = 0; i < Q.nthreads; ++i)
+    if (pthread_create(&Q.th[i], NULL, wq_worker, NULL)) { Q.nthreads = i; break; }
+}
+
+/* a free frame buffer (waits for a writer to return one) */
+static float *pool_get(size_t bytes) {
+  if (bytes > P.bytes) { fprintf(stderr, "nlkalman-seq: internal: buffer of %zu bytes asked\n", bytes); exit(1); }
+  pthread_mutex_lock(&Q.mu);
+  while (P.n == 0) pthread_cond_wait(&Q.less, &Q.mu);
+  float *b = P.buf[--P.n];
+  pthread_mutex_unlock(&Q.mu);
+  return b;
+}
+
+static void pool_init(size_t bytes) {
+  P.bytes = bytes;
+  const int want = Q.nthreads > 0 ? WQ_MAX_PENDING + 1 : 1;
+  for (P.n = 0; P.n < want && P.n < POOL_MAX; ++P.n) {
+    void *h = NULL;
+    CHK(nlk_host_alloc(C, &h, bytes));
+    P.buf[P.n] = (float *)h;
+  }
+}
+
+/* takes ownership of `path` (malloc'ed) and `data` (from the pool) */
+static void wq_write(char *path, float *data, int w, int h, int ch) {
+  if (Q.nthreads == 0) {
+    if (img_write(path, data, w, h, ch)) { fprintf(stderr, "nlkalman-seq: cannot write %s\n", path); exit(1); }
+    P.buf[P.n++] = data;
+    free(path);
+    return;
+  }
+  struct wjob *j = malloc(sizeof *j);
+  j->path = path; j->data = data; j->w = w; j->h = h; j->ch = ch; j->next = NULL;
+  pthread_mutex_lock(&Q.mu);
+  if (Q.tail) Q.tail->next = j; else Q.head = j;
+  Q.tail = j;
+  ++Q.pending;
+  pthread_cond_signal(&Q.more);
+  pthread_mutex_unlock(&Q.mu);
+}
+
+/* waits for every file; returns nonzero if one could not be written */
+static int wq_finish(void) {
+  pthread_mutex_lock(&Q.mu);
+  Q.closed = 1;
+  pthread_cond_broadcast(&Q.more);
+  pthread_mutex_unlock(&Q.mu);
+  for (int i = 0; i < Q.nthreads; ++i) pthread_join(Q.th[i], NULL);
+  return Q.failed;
+}
+
+/* ---- read-ahead: the next input frame is decoded by a helper thread */
+static struct { pthread_t th; int active; char name[1024]; float *data; int w, h, ch; float *pinned; size_t pinned_bytes; } R;
+static void *ra_worker(void *arg) {
+  (void)arg;
+  R.data = img_read(R.name, &R.w, &R.h, &R.ch);
+  const size_t bytes = (size_t)R.w * R.h * R.ch * sizeof(float);
+  if (R.data && R.pinned && bytes == R.pinned_bytes) {  /* stage it where the upload is fast */
+    memcpy(R.pinned, R.data, bytes);
+    free(R.data);
+    R.data = R.pinned;
+  }
+  return NULL;
+}
+static void ra_start(const char *name) {
+  snprintf(R.name, sizeof R.name, "%s", name);
+  R.active = pthread_create(&R.th, NULL, ra_worker, NULL) == 0;
+}
+static float *ra_get(const char *name, int *w, int *h, int *ch) {
+  if (R.active && strcmp(name, R.name) == 0) {
+    pthread_join(R.th, NULL);
+    R.active = 0;
+    *w = R.w; *h = R.h; *ch = R.ch;
+    return R.data;
+  }
+  return img_read(name, w, h, ch);
+}
+
+/* download a device array into a pool buffer and queue it for writing */
+static void write_dev(char *path, const float *d, int w, int h, int ch) {
+  const size_t bytes = (size_t)w * h * ch * sizeof(float);
+  float *host = pool_get(bytes);
+  CHK(nlk_d2h(C, host, d, bytes));
+  wq_write(path, host, w, h, ch);
+}
+
 static float *dev_frame(size_t bytes) {
   void *d = NULL;
   CHK(nlk_dev_alloc(C, &d, bytes));
@@ -76,13 +212,12 @@ static char *path_of(const char *dir, const char *pattern, int i) {
   return full;
 }
 
-/* RGB copy of an opponent-space device frame -> file */
-static void write_frame(const char *path, const float *d_opp, float *d_tmp, float *host, int w, int h, int ch) {
+/* RGB copy of an opponent-space device frame -> file (takes ownership of `path`) */
+static void write_frame(char *path, const float *d_opp, float *d_tmp, int w, int h, int ch) {
   const size_t bytes = (size_t)w * h * ch * sizeof(float);
   CHK(nlk_d2d(C, d_tmp, d_opp, bytes));
   CHK(nlk_dev_opp2rgb(C, d_tmp, w, h, ch));
-  CHK(nlk_d2h(C, host, d_tmp, bytes));
-  if (img_write(path, host, w, h, ch)) { fprintf(stderr, "nlkalman-seq: cannot write %s\n", path); exit(1); }
+  write_dev(path, d_tmp, w, h, ch);
 }
 
 int main(int argc, const char **argv) {
@@ -167,9 +302,9 @@ int main(int argc, const char **argv) {
   if (mkdir(out, 0777) && errno != EEXIST) { perror(out); return 1; }
 
   C = nlkalman_hip_context();
+  wq_start();
   int w = 0, h = 0, ch = 0;
   size_t bytes = 0;
-  float *host = NULL, *host2 = NULL;
   float *d_rgb = NULL, *d_noisy = NULL, *d_tmp = NULL, *d_warp = NULL, *d_g0 = NULL, *d_g1 = NULL;
   float *d_flow = NULL, *d_occ = NULL, *flt1 = NULL;
   float **flt2 = calloc(nframes, sizeof(float *));  /* kept for the backward pass */
@@ -181,22 +316,32 @@ int main(int argc, const char **argv) {
     char name[1024];
     snprintf(name, sizeof name, seq, i);
     int w1, h1, c1;
-    float *fr = img_read(name, &w1, &h1, &c1);
+    float *fr = ra_get(name, &w1, &h1, &c1);
     if (!fr) return 1;
     if (t == 0) {
       w = w1; h = h1; ch = c1;
       bytes = (size_t)w * h * ch * sizeof(float);
-      host = malloc(bytes);
-      host2 = malloc((size_t)w * h * 2 * sizeof(float));
       d_rgb = dev_frame(bytes); d_noisy = dev_frame(bytes); d_tmp = dev_frame(bytes); d_warp = dev_frame(bytes);
       d_g0 = dev_frame((size_t)w * h * 4); d_g1 = dev_frame((size_t)w * h * 4); d_occ = dev_frame((size_t)w * h * 4);
       d_flow = dev_frame((size_t)w * h * 8);
+      pool_init(bytes > (size_t)w * h * 8 ? bytes : (size_t)w * h * 8);
+      if (Q.nthreads > 0) {
+        void *hp = NULL;
+        CHK(nlk_host_alloc(C, &hp, bytes));
+        R.pinned = (float *)hp;
+        R.pinned_bytes = bytes;
+      }
     } else if (w1 != w || h1 != h || c1 != ch) {
       fprintf(stderr, "nlkalman-seq: %s: frame size differs from the first frame\n", name);
       return 1;
     }
-    CHK(nlk_h2d(C, d_rgb, fr, bytes));
-    free(fr);
+    CHK(nlk_h2d(C, d_rgb, fr, bytes));  /* (returns when the copy is done: the staging buffer is free again) */
+    if (fr != R.pinned) free(fr);
+    if (i + stp <= lfr && Q.nthreads > 0) {  /* decode the next frame meanwhile */
+      char next[1024];
+      snprintf(next, sizeof next, seq, i + stp);
+      ra_start(next);
+    }
     CHK(nlk_d2d(C, d_noisy, d_rgb, bytes));
     CHK(nlk_dev_rgb2opp(C, d_noisy, w, h, ch));
     float *n1 = dev_frame(bytes), *n2 = dev_frame(bytes);
@@ -219,37 +364,23 @@ int main(int argc, const char **argv) {
       CHK(nlk_dev_filter_frame(C, n1, d_noisy, d_warp, NULL, w, h, ch, sigma, &f1));
       CHK(nlk_dev_warp_bicubic(C, d_warp, flt2[t - 1], d_flow, d_occ, w, h, ch));
       CHK(nlk_dev_filter_frame(C, n2, d_noisy, d_warp, n1, w, h, ch, sigma, &f2));
-      char *p = path_of(out, "bflo1-%03d.flo", i);
-      CHK(nlk_d2h(C, host2, d_flow, (size_t)w * h * 8));
-      if (img_write(p, host2, w, h, 2)) return fprintf(stderr, "cannot write %s\n", p), 1;
-      free(p);
-      p = path_of(out, "bocc1-%03d.png", i);
-      CHK(nlk_d2h(C, host2, d_occ, (size_t)w * h * 4));
-      if (img_write(p, host2, w, h, 1)) return fprintf(stderr, "cannot write %s\n", p), 1;
-      free(p);
+      write_dev(path_of(out, "bflo1-%03d.flo", i), d_flow, w, h, 2);
+      write_dev(path_of(out, "bocc1-%03d.png", i), d_occ, w, h, 1);
     }
-    char *p = path_of(out, "flt1-%03d.tif", i);
-    write_frame(p, n1, d_tmp, host, w, h, ch);
-    free(p);
-    p = path_of(out, "flt2-%03d.tif", i);
-    write_frame(p, n2, d_tmp, host, w, h, ch);
-    free(p);
+    write_frame(path_of(out, "flt1-%03d.tif", i), n1, d_tmp, w, h, ch);
+    write_frame(path_of(out, "flt2-%03d.tif", i), n2, d_tmp, w, h, ch);
     if (flt1) nlk_dev_free(C, flt1);
     flt1 = n1;
     flt2[t] = n2;
     if (!smoothing && t > 0) { nlk_dev_free(C, flt2[t - 1]); flt2[t - 1] = NULL; }
     if (verbose) printf("frame %d filtered\n", i);
   }
-  if (!smoothing) return 0; /* script line 113 */
+  if (!smoothing) return wq_finish(); /* script line 113 */
 
   /* ---- backward pass (script lines 117-150) */
   float **smo = calloc(nframes, sizeof(float *));
   smo[nframes - 1] = flt2[nframes - 1];
-  {
-    char *p = path_of(out, "smo1-%03d.tif", ffr + (nframes - 1) * stp);
-    write_frame(p, smo[nframes - 1], d_tmp, host, w, h, ch);
-    free(p);
-  }
+  write_frame(path_of(out, "smo1-%03d.tif", ffr + (nframes - 1) * stp), smo[nframes - 1], d_tmp, w, h, ch);
   for (t = nframes - 2; t >= 0; --t) {
     const int i = ffr + t * stp;
     nlk_tvl1_default_params(&of);
@@ -267,18 +398,10 @@ int main(int argc, const char **argv) {
     CHK(nlk_dev_warp_bicubic(C, d_warp, smo[t + 1], d_flow, d_occ, w, h, ch));
     smo[t] = dev_frame(bytes);
     CHK(nlk_dev_smooth_frame(C, smo[t], flt2[t], d_warp, NULL, w, h, ch, sigma, &s1));
-    char *p = path_of(out, "fflo-%03d.flo", i);
-    CHK(nlk_d2h(C, host2, d_flow, (size_t)w * h * 8));
-    if (img_write(p, host2, w, h, 2)) return fprintf(stderr, "cannot write %s\n", p), 1;
-    free(p);
-    p = path_of(out, "focc-%03d.png", i);
-    CHK(nlk_d2h(C, host2, d_occ, (size_t)w * h * 4));
-    if (img_write(p, host2, w, h, 1)) return fprintf(stderr, "cannot write %s\n", p), 1;
-    free(p);
-    p = path_of(out, "smo1-%03d.tif", i);
-    write_frame(p, smo[t], d_tmp, host, w, h, ch);
-    free(p);
+    write_dev(path_of(out, "fflo-%03d.flo", i), d_flow, w, h, 2);
+    write_dev(path_of(out, "focc-%03d.png", i), d_occ, w, h, 1);
+    write_frame(path_of(out, "smo1-%03d.tif", i), smo[t], d_tmp, w, h, ch);
     if (verbose) printf("frame %d smoothed\n", i);
   }
-  return 0;
+  return wq_finish();
 }

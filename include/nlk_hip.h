@@ -83,6 +83,10 @@ int nlk_h2d(nlk_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int nlk_d2h(nlk_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int nlk_d2d(nlk_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);
 int nlk_sync(nlk_ctx *ctx);
+/* page-locked host memory: transfers from / to it run at the link's rate instead of through a
+ * staging copy (file-based callers that keep a pool of frame buffers: host/main_seq.c) */
+int nlk_host_alloc(nlk_ctx *ctx, void **hptr, size_t bytes);
+int nlk_host_free(nlk_ctx *ctx, void *hptr);
 
 /* image helpers on device-resident HWC images (asynchronous on the ctx stream) */
 int nlk_dev_rgb2opp(nlk_ctx *ctx, float *im, int w, int h, int ch);
