@@ -122,20 +122,27 @@ k_mask_commit(const uint64_t* __restrict__ marks, uint8_t* __restrict__ active, 
 // skewed[(i + (R+1)*j) * rows + j]. Lane j of k_mask_commit_wave then reads word s*rows + j at
 // step s: one coalesced, unconditional 256-byte load per wavefront instead of 64 cache lines
 // under a branch (entries outside the grid stay 0 and mark nothing).
+// Grids of more than 1024 rows are replayed in bands of rows: a band starts with the last R rows of
+// the previous one as context (`ctx_rows`), whose decisions are known (`ctx_active`): the marks of
+// their skipped targets are dropped here, so that whatever the replay decides for the context rows,
+// exactly the marks of the truly active ones reach the rows below (an active target can only be
+// covered by an active earlier target, and those inside the context are all judged active).
 template <int R>
 __global__ void k_marks_skew(const uint64_t* __restrict__ marks, uint32_t* __restrict__ skewed, int ngx,
-                             int ngy, int rows) {
+                             int ngy, int rows, const uint8_t* __restrict__ ctx_active, int ctx_rows) {
   constexpr int side = 2 * R + 1, centre = R * side + R;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ngx * ngy) return;
   const int j = t / ngx, i = t - j * ngx;
-  skewed[(size_t)(i + (R + 1) * j) * rows + j] = (uint32_t)(marks[t] >> (centre + 1));
+  uint32_t fwd = (uint32_t)(marks[t] >> (centre + 1));
+  if (j < ctx_rows && !ctx_active[t]) fwd = 0;
+  skewed[(size_t)(i + (R + 1) * j) * rows + j] = fwd;
 }
 
 template <int R>
 __global__ void __launch_bounds__(1024)
 k_mask_commit_wave(const uint32_t* __restrict__ skewed, uint8_t* __restrict__ active, int ngx,
-                   int ngy) {
+                   int ngy, int skip_rows /* context rows of a band: decided before, not stored */) {
   constexpr int side = 2 * R + 1, skew = R + 1, centre = R * side + R;
   constexpr uint32_t rowmask = (1u << side) - 1u;
   constexpr int S = NLK_CW_PHASE;  // steps per phase: progress is exchanged once per phase
@@ -220,7 +227,8 @@ k_mask_commit_wave(const uint32_t* __restrict__ skewed, uint8_t* __restrict__ ac
 #pragma unroll
       for (int q = 0; q < S / 4; ++q) {
         const int i = i0 + 4 * q;
-        if (j < ngy && i >= 0 && i + 3 < ngx) {
+        if (j < skip_rows) {
+        } else if (j < ngy && i >= 0 && i + 3 < ngx) {
           __builtin_memcpy(row + i, &flags[q], 4);
         } else if (j < ngy) {
 #pragma unroll

@@ -607,18 +607,28 @@ static int run_commit(nlk_ctx* c, const uint64_t* marks, uint8_t* active, int ng
   if (R == 0) {
     // a group cannot reach another grid target: nothing is ever skipped
     HIPCHK(c, hipMemsetAsync(active, 1, (size_t)ngrid, c->stream));
-  } else if (ngy <= 1024 && R <= 3 && !getenv("NLK_COMMIT_LDS")) {
-    const int threads = ((ngy + 63) / 64) * 64;
-    const int nsteps = ngx + (R + 1) * (ngy - 1);
-    const size_t sk_bytes = sizeof(uint32_t) * (size_t)(nsteps + 3 * NLK_CW_PHASE) * threads;
-    int rc = reserve(c, c->skew, sk_bytes);
-    if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->skew.p, 0, sk_bytes, c->stream));
+  } else if (R <= 3 && !getenv("NLK_COMMIT_LDS")) {
+    // one lane per grid row, up to 1024 rows per launch; taller grids in bands that start with the
+    // previous band's last R rows as context (k_commit.h)
+    int band = getenv("NLK_COMMIT_BAND") ? atoi(getenv("NLK_COMMIT_BAND")) : 1024;
+    band = band < 2 * R + 2 ? 2 * R + 2 : (band > 1024 ? 1024 : band);
     auto pre = R == 1 ? k_marks_skew<1> : (R == 2 ? k_marks_skew<2> : k_marks_skew<3>);
-    hipLaunchKernelGGL(pre, dim3((ngrid + 255) / 256), dim3(256), 0, c->stream, marks, (uint32_t*)c->skew.p,
-                       ngx, ngy, threads);
     auto kern = R == 1 ? k_mask_commit_wave<1> : (R == 2 ? k_mask_commit_wave<2> : k_mask_commit_wave<3>);
-    hipLaunchKernelGGL(kern, dim3(1), dim3(threads), 0, c->stream, (const uint32_t*)c->skew.p, active, ngx, ngy);
+    for (int first = 0; first < ngy;) {  // `first` = first row this band decides
+      const int ctx = first == 0 ? 0 : R;
+      const int r0 = first - ctx, rows = min(band, ngy - r0);
+      const int threads = ((rows + 63) / 64) * 64;
+      const int nsteps = ngx + (R + 1) * (rows - 1);
+      const size_t sk_bytes = sizeof(uint32_t) * (size_t)(nsteps + 3 * NLK_CW_PHASE) * threads;
+      int rc = reserve(c, c->skew, sk_bytes);
+      if (rc) return rc;
+      HIPCHK(c, hipMemsetAsync(c->skew.p, 0, sk_bytes, c->stream));
+      hipLaunchKernelGGL(pre, dim3((rows * ngx + 255) / 256), dim3(256), 0, c->stream, marks + (size_t)r0 * ngx,
+                         (uint32_t*)c->skew.p, ngx, rows, threads, (const uint8_t*)active + (size_t)r0 * ngx, ctx);
+      hipLaunchKernelGGL(kern, dim3(1), dim3(threads), 0, c->stream, (const uint32_t*)c->skew.p,
+                         active + (size_t)r0 * ngx, ngx, rows, ctx);
+      first = r0 + rows;
+    }
     HIPCHK(c, hipGetLastError());
   } else {
     const int rpt = (ngy + 1023) / 1024;

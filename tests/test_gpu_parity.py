@@ -369,6 +369,36 @@ def test_full_size_1080p_against_oracle(ctx, built, O, synth):
     assert np.quantile(np.abs(g2[..., 1:] - g[..., 1:]), 0.9999) < 2e-2
 
 
+@pytest.mark.parametrize("band", [8, 11, 37])
+def test_banded_mask_replay_is_exact(ctx, built, O, synth, monkeypatch, band):
+    """Patch grids of more than 1024 rows (8K frames) replay the processed-mask in bands of rows
+    that start with the previous band's last rows as context (k_commit.h). With the band forced
+    small (NLK_COMMIT_BAND) the decisions must still be the oracle's, for the temporal reach (1),
+    the spatial reach (3) and the second iteration, and equal the single-band run on a larger frame."""
+    monkeypatch.setenv("NLK_COMMIT_BAND", str(band))
+    for name, mode in (("rgb96x64_s20", "x"), ("rgb96x64_s20", "t"), ("gray70x53_ragged", "x")):
+        I = cases.inputs(name)
+        s, over = I["sigma"], I["over"]
+        ref = cases.run_chain(O, name)
+        o0, o1 = O.rgb2opp(I["n0"]), O.rgb2opp(I["n1"])
+        p = built.default_params(s, built.FLT1, **over)
+        args = (o0, None, None) if mode == "x" else (o1, ref["w1"], None)
+        _, tr = O.filter_frame(*args, s, _to_o(O, p), trace=True)
+        _, rec = _dev_frame(ctx, False, *args, s, p)
+        _check_records(rec, tr, f"{name}/{mode}/band {band}")
+    w, h, ch, sigma = 400, 360, 3, 20.0
+    n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, 11)
+    o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+    p1 = built.default_params(sigma, built.FLT1)
+    f0b, r0b = _dev_frame(ctx, False, o0, None, None, sigma, p1)
+    f1b, r1b = _dev_frame(ctx, False, o1, f0b, None, sigma, p1)
+    monkeypatch.delenv("NLK_COMMIT_BAND")
+    f0, r0 = _dev_frame(ctx, False, o0, None, None, sigma, p1)
+    f1, r1 = _dev_frame(ctx, False, o1, f0b, None, sigma, p1)
+    assert np.array_equal(r0b["active"], r0["active"]) and np.array_equal(r1b["active"], r1["active"])
+    assert 0.2 < 1 - r1["active"].mean() < 0.5   # (the skip really is exercised)
+
+
 def test_group_kernels_agree_matrix_vs_dpp(ctx, built, synth, monkeypatch):
     """The 8x8 group kernel has two implementations: k_group8m (DCTs on the f32
     matrix cores, the default) and k_group8 (registers + DPP, NLK_GROUP_DPP=1).
