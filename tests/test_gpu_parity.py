@@ -461,13 +461,13 @@ def test_smoother_full_size_1080p(ctx, built, O, synth):
 
 
 def test_randomised_parameters_and_shapes(ctx, built, O):
-    """40 seeded random configurations: odd image sizes, every supported patch
+    """120 seeded random configurations: odd image sizes, every supported patch
     size, clipped windows, k larger than the window, group sizes above k, NaN
     holes, second-iteration and smoother calls. Integer records exact, pixels
     within tolerance, for each of them."""
     # (NLK_RANDOM_SEED / NLK_RANDOM_COUNT run other or longer sequences, e.g. as a soak test)
     rng = np.random.default_rng(int(os.environ.get("NLK_RANDOM_SEED", 2024)))
-    want = int(os.environ.get("NLK_RANDOM_COUNT", 40))
+    want = int(os.environ.get("NLK_RANDOM_COUNT", 120))
     done = 0
     for it in range(5 * want):
         if done == want:
@@ -509,6 +509,13 @@ def test_randomised_parameters_and_shapes(ctx, built, O):
         what = f"random #{it}: {w}x{h}x{ch} psz{psz} sx{wsz_x} st{wsz_t} nx{npx} nt{npt} na{ntagg} " \
                f"mode{mode} prev{kind} sigma{sigma}"
         _check_records(rec, tr, what)
+        # a pixel whose summed weight sits AT the reference's absolute threshold (aggr > 1e-6 ?
+        # normalise : pass the input through, src/nlkalman.c:939-942) may fall on either side with
+        # the weights summed in another order: those pixels are excused, and only those
+        # (within 1e-4 relative of it: 100x the spread of a float sum of ~100 weights)
+        edge = np.abs(tr["aggr"] - 1e-6) <= 1e-10
+        assert edge.sum() <= max(4, 0.02 * edge.size), what
+        g = np.where(edge[..., None], r, g)
         cases.assert_close(g, r, what, maxabs=5e-3, rmse=5e-4)
         done += 1
     assert done == want
