@@ -87,7 +87,12 @@ class StripFrame:
         if phases is not None:
             mx = max(self.rows) * self.ngx
             self.marks_pad = torch.zeros(mx, dtype=torch.int64, device=device)
-            self.marks_all = [torch.zeros(mx, dtype=torch.int64, device=device) for _ in range(world)]
+            # every rank's (padded) mark words land in one flat buffer; one gather compacts them to
+            # the whole grid (instead of a copy per rank)
+            self.marks_flat = torch.zeros(world * mx, dtype=torch.int64, device=device)
+            self.marks_all = list(self.marks_flat.view(world, mx).unbind(0))
+            self.compact = torch.cat([torch.arange(nr * self.ngx, dtype=torch.int64) + r * mx
+                                      for r, nr in enumerate(self.rows)]).to(device)
             self.marks_full = torch.zeros(self.ngy * self.ngx, dtype=torch.int64, device=device)
             self.active_full = torch.zeros(self.ngy * self.ngx, dtype=torch.uint8, device=device)
         self.up = rank - 1 if rank > 0 else None
@@ -118,35 +123,33 @@ class StripFrame:
             for (d, _), (hbuf, _) in zip(dev_recvs, recvs):
                 d.copy_(hbuf)
 
-    def _all_gather(self, outs, t):
+    def _all_gather(self, flat, outs, t):
+        """t of every rank -> flat (= the views `outs`, rank-major)."""
         if not self.stage_host:
-            dist.all_gather(outs, t)
+            if dist.get_backend() == "nccl":
+                dist.all_gather_into_tensor(flat, t)   # RCCL: straight into the flat buffer
+            else:
+                dist.all_gather(outs, t)
             return
         houts = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
         dist.all_gather(houts, t.cpu())
-        for o, hbuf in zip(outs, houts):
-            o.copy_(hbuf)
+        flat.copy_(torch.cat(houts))
 
     def step(self):
         p, plan, w, ch = self.p, self.plan, self.w, self.ch
         l = self._l
-        # (1) halo rows of the previous denoised frame
-        sends, recvs, rt, rb = [], [], None, None
+        # (1) halo rows of the previous denoised frame: row ranges of `prev` are contiguous, so they are
+        # sent from and received into place
+        sends, recvs = [], []
         if self.up is not None:
             n_up = plan[self.up]["Y1"] - p["own0"]          # my rows the upper rank reads
-            sends.append((self.prev[l(p["own0"]):l(p["own0"]) + n_up].contiguous(), self.up))
-            rt = torch.empty((p["own0"] - p["Y0"], w, ch), dtype=torch.float32, device=self.cur.device)
-            recvs.append((rt, self.up))
+            sends.append((self.prev[l(p["own0"]):l(p["own0"]) + n_up], self.up))
+            recvs.append((self.prev[:l(p["own0"])], self.up))
         if self.dn is not None:
             n_dn = p["own1"] - plan[self.dn]["Y0"]          # my rows the lower rank reads
-            sends.append((self.prev[l(p["own1"]) - n_dn:l(p["own1"])].contiguous(), self.dn))
-            rb = torch.empty((p["Y1"] - p["own1"], w, ch), dtype=torch.float32, device=self.cur.device)
-            recvs.append((rb, self.dn))
+            sends.append((self.prev[l(p["own1"]) - n_dn:l(p["own1"])], self.dn))
+            recvs.append((self.prev[l(p["own1"]):], self.dn))
         self._exchange(sends, recvs)
-        if rt is not None:
-            self.prev[:l(p["own0"])] = rt
-        if rb is not None:
-            self.prev[l(p["own1"]):] = rb
         # (2) kernels on the strip
         self.acc.zero_()
         oy, ngy_l = p["gy0"] * self.step_px - p["Y0"], p["gy1"] - p["gy0"]
@@ -157,11 +160,8 @@ class StripFrame:
             n_l = ngy_l * self.ngx
             reach = match(self.marks_pad[:n_l], self.cur, self.prev, oy, ngy_l)
             if self.world > 1:
-                self._all_gather(self.marks_all, self.marks_pad)
-                off = 0
-                for r, nr in enumerate(self.rows):
-                    self.marks_full[off:off + nr * self.ngx] = self.marks_all[r][:nr * self.ngx]
-                    off += nr * self.ngx
+                self._all_gather(self.marks_flat, self.marks_all, self.marks_pad)
+                torch.index_select(self.marks_flat, 0, self.compact, out=self.marks_full)
             else:
                 self.marks_full.copy_(self.marks_pad[:n_l])
             commit(self.marks_full, self.ngx, self.ngy, reach, self.active_full)
