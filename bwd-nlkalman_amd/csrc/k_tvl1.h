@@ -29,6 +29,14 @@ struct NlkTvState {
   int fin_stop;    // blocked driver: stop found by the group's closing launch (never read on the device)
 };
 
+// The host's copy of the state, in page-locked host memory the kernels write directly: the launch
+// that closes a group of batches posts the state and then the group's sequence number (system
+// scope); the host spins on the number instead of paying a copy + stream synchronisation per group.
+struct NlkTvMail {
+  NlkTvState st;
+  unsigned seq;
+};
+
 // ---- sampling (reference: bicubic_interpolation.c:26-41, 100-131, 140-236)
 __device__ __forceinline__ int nlk_tv_clamp(int x, int n, bool& out) {
   if (x < 0) { out = true; return 0; }
@@ -191,6 +199,7 @@ struct NlkTvLevel {
   float *I1x, *I1y, *I1wx, *I1wy, *grad, *rho_c, *p11, *p12, *p21, *p22;
   float* part;      // one partial sum of squared updates per workgroup
   NlkTvState* st;   // iteration count of the level (accumulated)
+  NlkTvMail* mail;  // host-resident copy (see NlkTvMail)
   int nx, ny, nwarps;
   float l_t, theta, taut, eps2;
 };
@@ -552,6 +561,13 @@ __device__ __forceinline__ int nlk_tv_judge(const NlkTvLevel& L, const float* __
   return done;
 }
 
+__device__ __forceinline__ void nlk_tv_post(const NlkTvLevel& L, unsigned seq) {
+  NlkTvMail* m = L.mail;
+  m->st = *L.st;  // (fields written by earlier launches or, just now, by this very thread)
+  __threadfence_system();
+  __hip_atomic_store(&m->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // mode 0: a batch; 2: a batch that first judges the previous one; 1: closes a group of batches
 // (n0, count = the group's last batch, judged here; in / out = the buffers of the warp's FIRST
 // batch); 3: closes a group whose batches were all judged by k_tv_decide.
@@ -559,18 +575,21 @@ __device__ __forceinline__ int nlk_tv_judge(const NlkTvLevel& L, const float* __
 // re-adds all partial sums: cheap for a few hundred workgroups, not for thousands)
 template <int TH, int BT, int KI>
 __global__ void __launch_bounds__(BT, 4)  // (>= 4 wavefronts per SIMD: 16 per CU either way)
-k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode) {
+k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode, unsigned seq) {
 #pragma clang fp contract(off)
   constexpr int RW = NLK_TV_TW + 2 * KI, RH = TH + 2 * KI, RPT = (RW * RH + BT - 1) / BT;
   __shared__ double red[KI][4];
   __shared__ float errs[KI];
   const int nblocks = gridDim.x * gridDim.y, block = blockIdx.y * gridDim.x + blockIdx.x;
   if (mode == 1 || mode == 3) {
+    const bool poster = block == 0 && threadIdx.x == 0;
     if (L.st->stop_iter < NLK_TV_MAXIT) {  // found by a batch of this group
+      if (poster) nlk_tv_post(L, seq);
       if (L.st->redo == 0) return;
       n0 = L.st->redo_n0;
       count = L.st->redo;
     } else if (mode == 3) {
+      if (poster) nlk_tv_post(L, seq);
       return;
     } else {
       bool stop;
@@ -582,6 +601,7 @@ k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode)
         L.st->last = n0 + done;
         L.st->error = err;
         L.st->fin_stop = stop ? n0 + done : NLK_TV_MAXIT;
+        nlk_tv_post(L, seq);
       }
       if (!stop || done == count) return;
       count = done;

@@ -43,7 +43,8 @@ struct nlk_ctx {
   Buf skew;                       // mark words in replay-step order (k_marks_skew)
   Buf ms;                         // whole-image DCT: temporary image + the two basis matrices
   Buf tv;                         // TV-L1 pyramids and work images
-  NlkTvState* tv_host = nullptr;  // pinned: the solver state read back between iteration batches
+  NlkTvMail* tv_host = nullptr;   // pinned: the solver state, posted by the kernels (k_tvl1.h)
+  unsigned tv_seq = 0;
   int tabs_psz = 0;
   NlkGeom last{};
   bool have_last = false;

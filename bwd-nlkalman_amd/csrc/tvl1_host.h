@@ -38,6 +38,27 @@ int tv_gaussian2(nlk_ctx* c, const float* in_a, float* out_a, float* tmp_a, cons
   return NLK_OK;
 }
 
+// waits until the launch that closes a group has posted the solver state with sequence number `seq`
+// (NlkTvMail): a spin on host memory, with a look at the stream now and then so that a failed
+// launch cannot hang the caller
+int tv_wait_mail(nlk_ctx* c, unsigned seq) {
+  volatile unsigned* flag = &c->tv_host->seq;
+  for (unsigned spins = 0;; ++spins) {
+    if (*flag == seq) break;
+    if ((spins & 0xFFF) == 0xFFF) {
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q == hipSuccess) {  // everything has run
+        if (*flag == seq) break;
+        return fail(c, NLK_EHIP, "TV-L1: the solver state was not posted");
+      }
+      if (q != hipErrorNotReady) return fail(c, NLK_EHIP, "TV-L1: %s", hipGetErrorString(q));
+    }
+    __builtin_ia32_pause();
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return NLK_OK;
+}
+
 // one scale (reference: tvl1flow_lib.c:93-275)
 int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2, int nx, int ny,
              const nlk_tvl1_params& P, float* work, float* alt, float* part, NlkTvState* st) {
@@ -46,7 +67,7 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
   L.I0 = I0; L.I1 = I1; L.u1 = u1; L.u2 = u2;
   L.I1x = work; L.I1y = L.I1x + n; L.I1wx = L.I1y + n; L.I1wy = L.I1wx + n; L.grad = L.I1wy + n;
   L.rho_c = L.grad + n; L.p11 = L.rho_c + n; L.p12 = L.p11 + n; L.p21 = L.p12 + n; L.p22 = L.p21 + n;
-  L.part = part; L.st = st;
+  L.part = part; L.st = st; L.mail = c->tv_host;
   L.nx = nx; L.ny = ny; L.nwarps = P.nwarps;
   L.l_t = P.lambda * P.theta; L.theta = P.theta; L.taut = P.tau / P.theta; L.eps2 = P.epsilon * P.epsilon;
   size_t wg_max = getenv("NLK_TV_WG_PIXELS") ? (size_t)atoi(getenv("NLK_TV_WG_PIXELS")) : NLK_TV_WG_PIXELS;
@@ -71,9 +92,9 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
           hipLaunchKernelGGL(k_tv_dual, grid, dim3(256), 0, c->stream, L, it, nparts);
         }
         launched = upto;
-        HIPCHK(c, hipMemcpyAsync(c->tv_host, st, sizeof(NlkTvState), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&c->tv_host->st, st, sizeof(NlkTvState), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->tv_host->stop_iter < NLK_TV_MAXIT || c->tv_host->last >= NLK_TV_MAXIT) break;
+        if (c->tv_host->st.stop_iter < NLK_TV_MAXIT || c->tv_host->st.last >= NLK_TV_MAXIT) break;
       }
     }
     HIPCHK(c, hipGetLastError());
@@ -119,7 +140,7 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
       for (int q = 0; q < look && n0 < NLK_TV_MAXIT; ++q) {
         const int count = NLK_TV_MAXIT - n0 < K ? NLK_TV_MAXIT - n0 : K;
         hipLaunchKernelGGL(block_kernel, bgrid, dim3(bt), 0, c->stream, L, cur, oth, n0, count,
-                           inline_judge && q ? 2 : 0);
+                           inline_judge && q ? 2 : 0, 0u);
         if (!inline_judge) hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(256), 0, c->stream, L, n0, count, nblocks);
         last_n0 = n0;
         last_count = count;
@@ -129,21 +150,22 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
       }
       // the batch that ran past the stop (if any) is redone from its input, once per group
       // (it also judges the group's last batch)
+      const unsigned seq = ++c->tv_seq;
       hipLaunchKernelGGL(block_kernel, bgrid, dim3(bt), 0, c->stream, L, first, second, last_n0, last_count,
-                         inline_judge ? 1 : 3);
-      HIPCHK(c, hipMemcpyAsync(c->tv_host, st, sizeof(NlkTvState), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      if (c->tv_host->stop_iter < NLK_TV_MAXIT || c->tv_host->fin_stop < NLK_TV_MAXIT ||
-          c->tv_host->last >= NLK_TV_MAXIT)
+                         inline_judge ? 1 : 3, seq);
+      int rc = tv_wait_mail(c, seq);
+      if (rc) return rc;
+      if (c->tv_host->st.stop_iter < NLK_TV_MAXIT || c->tv_host->st.fin_stop < NLK_TV_MAXIT ||
+          c->tv_host->st.last >= NLK_TV_MAXIT)
         break;
     }
     // where the state of iteration `last` lives: written by batch ceil(last / K), batches alternate
-    const int used = (c->tv_host->last + K - 1) / K;
+    const int used = (c->tv_host->st.last + K - 1) / K;
     const bool final_is_start = (used % 2) == 0;
     const NlkTvBuf fin = final_is_start ? (cur_is_a ? A : B) : (cur_is_a ? B : A);
     L.u1 = fin.u1; L.u2 = fin.u2; L.p11 = fin.p11; L.p12 = fin.p12; L.p21 = fin.p21; L.p22 = fin.p22;
     if (getenv("NLK_TV_TRACE"))
-      fprintf(stderr, "tvl1 %dx%d warp %d: %d iterations, %d batches launched\n", nx, ny, wi, c->tv_host->last, batches);
+      fprintf(stderr, "tvl1 %dx%d warp %d: %d iterations, %d batches launched\n", nx, ny, wi, c->tv_host->st.last, batches);
   }
   if (L.u1 != u1) {  // the level's flow belongs in the pyramid arrays
     HIPCHK(c, hipMemcpyAsync(u1, L.u1, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
@@ -209,7 +231,10 @@ int nlk_dev_tvl1_flow(nlk_ctx* c, float* flow, const float* I0, const float* I1,
   const size_t floats = 4 * pyr + 18 * n0 + 2 * NLK_TV_K2 * nparts0 + 64;
   int rc = reserve(c, c->tv, sizeof(float) * floats);
   if (rc) return rc;
-  if (!c->tv_host) HIPCHK(c, hipHostMalloc((void**)&c->tv_host, sizeof(NlkTvState)));
+  if (!c->tv_host) {
+    HIPCHK(c, hipHostMalloc((void**)&c->tv_host, sizeof(NlkTvMail)));
+    memset(c->tv_host, 0, sizeof(NlkTvMail));
+  }
   float* base = (float*)c->tv.p;
   float *I0s[64], *I1s[64], *U1[64], *U2[64];
   float* q = base;
@@ -257,9 +282,9 @@ int nlk_dev_tvl1_flow(nlk_ctx* c, float* flow, const float* I0, const float* I1,
                      (const float*)U2[0], flow, (int)n0);
   HIPCHK(c, hipGetLastError());
   if (iterations) {  // (the only read-back, and only when asked for)
-    HIPCHK(c, hipMemcpyAsync(c->tv_host, st, sizeof(NlkTvState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&c->tv_host->st, st, sizeof(NlkTvState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    *iterations = c->tv_host->iters;
+    *iterations = c->tv_host->st.iters;
   }
   return NLK_OK;
 }
