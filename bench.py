@@ -264,11 +264,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # NLK_BENCH_ONE_GPU=1 (development aid): every rank on device 0 with the gloo backend and host
+    # staging, to drive the whole N > 1 code path on a one-GPU box; its numbers mean nothing
+    one_gpu = os.environ.get("NLK_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = importlib.import_module("bwd-nlkalman_amd")
     synth = importlib.import_module("bwd-nlkalman_amd.synth")
@@ -335,7 +343,7 @@ def main():
         def group(acc, active):
             ctx.strip_group(acc.data_ptr(), active.data_ptr())
         sf = strips.StripFrame(rank, world, w, h, ch, psz, max(p.search_sz_x, p.search_sz_t), dev,
-                               accumulate, normalize, phases=(match, commit, group))
+                               accumulate, normalize, phases=(match, commit, group), stage_host=one_gpu)
         sf.load(t_n1, t_prev)
         one_step = sf.step
 
