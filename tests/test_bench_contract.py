@@ -1,0 +1,67 @@
+"""bench.py's output contract (one JSON line with the driver's fields, the roofline and the CPU
+baseline objects) and __graft_entry__.smoke(), run the way the driver runs them."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config")
+
+
+def _bench(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout           # exactly ONE line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_refuses_to_run_without_a_gpu_or_with_a_wrong_world():
+    import torch
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       cwd=ROOT, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")})
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], capture_output=True, text=True, cwd=ROOT)
+        assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_default_bench_line():
+    d = _bench("--steps", "3", "--warmup", "1")
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "Mpix/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "1080p" in d["metric"] and d["config"]["workload"].startswith("C2: 1920x1080x3")
+    assert abs(d["value"] - 1920 * 1080 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * d["value"]
+    ro = d["roofline"]
+    assert ro["bound"] in ("hbm", "mfma") and ro["unit"] in ("GB/s", "TFLOP/s") and ro["peak"] > 0
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3 and 0 < ro["frac"] < 1
+    assert ro["traffic"] is None or ro["traffic"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert abs(d["psnr_delta_db"]) <= 0.02       # BASELINE.json's quality bar, on the bench frame itself
+    assert d["value"] > 30 * cb["value"]          # north_star: >= 30x the CPU path on the same box
+
+
+@pytest.mark.gpu
+def test_flow_bench_line():
+    d = _bench("--workload", "F1", "--steps", "2", "--warmup", "1")
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.5
+    assert d["cpu_baseline"]["kind"] in ("reference", "port")
+    assert d["parity_crop_480x270"]["bit_exact"] is True
+
+
+@pytest.mark.gpu
+def test_smoke_entry_point():
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], capture_output=True, text=True,
+                       cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "smoke:" in r.stdout
