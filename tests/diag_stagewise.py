@@ -1,6 +1,6 @@
 """Stage-by-stage GPU vs oracle diagnostic (development aid; run with gpurun).
 
-  python tools/gpu_check.py [w h ch sigma]
+  python tests/diag_stagewise.py [w h ch sigma]     (lives under tests/: it uses the oracle)
 Compares top-k records, active flags and final output for FLT1 spatial,
 FLT1 temporal (with NaN holes), FLT2 and SMO1.
 """
