@@ -107,6 +107,35 @@ __device__ __forceinline__ void nlk_dct12x12_inv(float (&p)[12], const float (&c
   nlk_dct12_inv(p);
 }
 
+// Column pass through LDS (the default): the 15 dependent v_fmac_f32_dpp per register of the
+// rotation scheme above were measured at HALF of the kernel's time (13.3 -> 6.4 ms at C3 with the
+// column passes removed). Instead each lane writes its 12 row-transformed values as one row of a
+// 12x12 scratch tile of its channel, reads back one COLUMN, and runs the same register transform
+// along it: 84 VALU + 15 LDS instructions instead of 192 DPP ones. The coefficients then live
+// transposed (lane = horizontal, register = vertical frequency); statistics, gains and shrinkage
+// are elementwise and never notice, and the inverse transform undoes it: registers first, the
+// transposition, registers again, which ends in the pixel layout (lane = row) the aggregation uses.
+#ifndef NLK_G12_WAVES
+#define NLK_G12_WAVES 3  // wavefronts per SIMD the register budget is cut for (168 VGPRs): the LDS round trips of
+#endif                   // the transpositions want the third wavefront (9.2 -> 8.8 ms at C3; 4 would spill: 19 ms)
+#define NLK_T12_CS 156  // floats per channel tile (12 x 12 + 12: the channels start 12 banks apart)
+#define NLK_T12_FLOATS (4 * NLK_T12_CS)
+__device__ __forceinline__ void nlk_transpose12(float (&p)[12], float* __restrict__ tile /* of this lane's channel */,
+                                                int u, bool on) {
+  if (on) {
+    nlk_f4* row = (nlk_f4*)(tile + 12 * u);
+    row[0] = nlk_f4{p[0], p[1], p[2], p[3]};
+    row[1] = nlk_f4{p[4], p[5], p[6], p[7]};
+    row[2] = nlk_f4{p[8], p[9], p[10], p[11]};
+  }
+  nlk_wave_lds_fence();
+  if (on) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) p[j] = tile[12 * j + u];
+  }
+  nlk_wave_lds_fence();  // (the next transposition overwrites the tile)
+}
+
 __device__ __forceinline__ void nlk_load_row12(const float* __restrict__ p, float (&dst)[12]) {
   // (explicit global address space: see k_group8m.h)
   typedef const __attribute__((address_space(1))) nlk_f4u* gp4;
@@ -124,7 +153,7 @@ __device__ __forceinline__ int nlk_ror_src(int lane) {  // source lane of row_ro
 }
 
 template <int CH, bool SMO>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, NLK_G12_WAVES)
 k_group12(const float* __restrict__ img, const float* __restrict__ cur,
           const float* __restrict__ prev, const uint8_t* __restrict__ vmap, NlkGeom g,
           NlkGTile tl, const uint32_t* __restrict__ topk, const NlkTarget* __restrict__ tinfo,
@@ -171,6 +200,14 @@ k_group12(const float* __restrict__ img, const float* __restrict__ cur,
       cik[k] = ok ? basis[su * PSZ + u] : 0.f;   // inverse: x[y=u] = sum C[u'][y] Y[u']
     }
   }
+#ifndef NLK_GROUP12_DPP
+  float* const t12 = smem + (((CH + 1) * plane + 3) & ~3) + cc * NLK_T12_CS;
+#define NLK_FWD12(p) do { nlk_dct12_fwd(p); nlk_transpose12(p, t12, uu, lane_on); nlk_dct12_fwd(p); } while (0)
+#define NLK_INV12(p) do { nlk_dct12_inv(p); nlk_transpose12(p, t12, uu, lane_on); nlk_dct12_inv(p); } while (0)
+#else
+#define NLK_FWD12(p) nlk_dct12x12_fwd(p, ck)
+#define NLK_INV12(p) nlk_dct12x12_inv(p, cik)
+#endif
   float wrow[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) wrow[k] = window[uu * PSZ + k];
@@ -244,8 +281,8 @@ k_group12(const float* __restrict__ img, const float* __restrict__ cur,
 #pragma unroll
       for (int r = 0; r < 12; ++r) { a[r] = na[r]; b[r] = nb[r]; }
       rows_of(i + 1 < k ? i + 1 : i, na, nb);
-      nlk_dct12x12_fwd(a, ck);
-      if (v) nlk_dct12x12_fwd(b, ck);
+      NLK_FWD12(a);
+      if (v) NLK_FWD12(b);
       np1++;
       if (v) np0++;
       const float inp1 = __builtin_amdgcn_rcpf((float)np1);
@@ -344,15 +381,15 @@ k_group12(const float* __restrict__ img, const float* __restrict__ cur,
         const uint32_t qa = member(n0), qb = member(two ? n0 + 1 : n0);
         if (lane_on) nlk_load_row12(src_c + nlk_y(qa) * g.w + nlk_x(qa), a);
         if (lane_on && two) nlk_load_row12(src_c + nlk_y(qb) * g.w + nlk_x(qb), b);
-        nlk_dct12x12_fwd(a, ck);
-        if (two) nlk_dct12x12_fwd(b, ck);
+        NLK_FWD12(a);
+        if (two) NLK_FWD12(b);
 #pragma unroll
         for (int r = 0; r < 12; ++r) {
           a[r] = gain[r] * a[r] + (1 - gain[r]) * mu[r];
           b[r] = gain[r] * b[r] + (1 - gain[r]) * mu[r];
         }
-        nlk_dct12x12_inv(a, cik);
-        if (two) nlk_dct12x12_inv(b, cik);
+        NLK_INV12(a);
+        if (two) NLK_INV12(b);
         if (lane_on) add_patch(nlk_x(qa), nlk_y(qa), a);
         if (lane_on && two) add_patch(nlk_x(qb), nlk_y(qb), b);
       }
@@ -363,11 +400,11 @@ k_group12(const float* __restrict__ img, const float* __restrict__ cur,
         if (lane_on) nlk_load_row12(src_c + qy * g.w + qx, a);
         if (!passthrough) {
           if (lane_on) nlk_load_row12(prev_c + qy * g.w + qx, b);
-          nlk_dct12x12_fwd(a, ck);
-          nlk_dct12x12_fwd(b, ck);
+          NLK_FWD12(a);
+          NLK_FWD12(b);
 #pragma unroll
           for (int r = 0; r < 12; ++r) a[r] = (1 - gain[r]) * a[r] + gain[r] * b[r];  // reference: :1775
-          nlk_dct12x12_inv(a, cik);
+          NLK_INV12(a);
         }
         if (lane_on) add_patch(qx, qy, a);
       }
@@ -386,3 +423,6 @@ k_group12(const float* __restrict__ img, const float* __restrict__ cur,
       }
     }
 }
+
+#undef NLK_FWD12
+#undef NLK_INV12

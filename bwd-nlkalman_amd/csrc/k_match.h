@@ -40,12 +40,6 @@ __device__ inline uint64_t nlk_wave_or(uint64_t v) {
   return v;
 }
 
-__device__ inline void nlk_wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-  __builtin_amdgcn_wave_barrier();
-}
-
 // Distances + selection for one target whose window holds n <= 64*M candidates.
 // Leaves the k kept candidates, sorted, in sel[0..k).
 // (forced inline: as a real call the LDS tile pointer becomes a generic one, the candidate reads

@@ -44,3 +44,11 @@ static __device__ inline int nlk_xcd_tile(int b, int n) {
   return (b & 7) * per + (b >> 3);
 }
 static inline int nlk_xcd_grid(int n) { return ((n + 7) >> 3) << 3; }
+
+// LDS written by some lanes of a wavefront and read by others of the SAME wavefront: order the
+// accesses without a workgroup barrier
+__device__ inline void nlk_wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+}

@@ -170,9 +170,10 @@ int launch_group_fast_t(nlk_ctx* c, const NlkGeom& g, const float* img, const fl
   // groups of a temporal frame that reach further fall back to HBM atomics
   tl.wmax = (g.smoother || g.have_prev) ? g.wsz_t : g.wsz_x;
   // 4 x 1 targets per wavefront measured best for the temporal radius (profiles/README.md);
-  // with a wide halo the tile would leave LDS room for ~1 wavefront per SIMD: 2 x 1 then.
+  // with a wide halo the tile would leave LDS room for ~1 wavefront per SIMD: 2 x 1 then, and for
+  // the 12x12 kernel (8.0 ms against 8.8 with 4 x 1 at C3).
   // NLK_GTX/NLK_GTY override for experiments
-  tl.tgx = getenv("NLK_GTX") ? atoi(getenv("NLK_GTX")) : (PSZ == 8 && tl.wmax > 6 ? 2 : 4);
+  tl.tgx = getenv("NLK_GTX") ? atoi(getenv("NLK_GTX")) : ((PSZ == 8 && tl.wmax > 6) || PSZ == 12 ? 2 : 4);
   tl.tgy = getenv("NLK_GTY") ? atoi(getenv("NLK_GTY")) : 1;
   tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
   tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
@@ -191,7 +192,9 @@ int launch_group_fast_t(nlk_ctx* c, const NlkGeom& g, const float* img, const fl
     tl.rwp = rw_max | 1;
     tl.plane = tl.rwp * tl.rh_max;
   }
-  const size_t lds = sizeof(float) * ((size_t)(CH + 1) * tl.plane + (mfma ? CH * 128 : 0));
+  // (+ the 12x12 kernel's transposition scratch: k_group12.h)
+  const size_t lds = sizeof(float) * ((size_t)(CH + 1) * tl.plane + (mfma ? CH * 128 : 0) +
+                                     (PSZ == 12 ? 4 + NLK_T12_FLOATS : 0));
   if (lds > 160 * 1024) return fail(c, NLK_EUNSUP, "aggregation tile needs %zu bytes of LDS", lds);
   void (*kern)(const float*, const float*, const float*, const uint8_t*, NlkGeom, NlkGTile,
                const uint32_t*, const NlkTarget*, const uint32_t*, const uint8_t*, const float*,
