@@ -6,11 +6,11 @@
 //   channel; the image patch row lives in registers a[12], the previous-frame
 //   patch row in b[12] of the SAME lane. Hence
 //   * row pass of the DCT: register arithmetic (even/odd split, 12 + 72 ops),
-//   * column pass: lane u needs T[u'] for the 12 rows u' of its DPP row: 15
-//     rotations `row_ror:k` feed v_fmac_f32_dpp directly (inline asm); the
-//     per-lane coefficient of rotation k is looked up once per kernel by
-//     rotating the lane index itself, so no assumption on the rotation
-//     direction is baked in,
+//   * column pass: a transposition of the channel's 12x12 tile through LDS and the
+//     register transform again (nlk_transpose12 below). The first version
+//     (NLK_GROUP12_DPP) fed 15 `row_ror:k` rotations of the DPP row to
+//     v_fmac_f32_dpp, with the per-lane coefficient of rotation k looked up once
+//     per kernel by rotating the lane index itself: half of the kernel's time,
 //   * Welford statistics of both patches, the transition variance (b - a)^2,
 //     gains and shrinkage are all lane-local — no partner exchange at all,
 //   * pass B transforms two group members per step (one in a[], one in b[]).
