@@ -381,7 +381,7 @@ def main():
         # The group kernel runs its DCTs on the f32 matrix cores and everything else on the
         # f32 vector ALU, which share one FP32 datapath on gfx950 (tools/ubench/mfma_valu.hip):
         # it is priced against the dense f32 MFMA peak. Algorithmic flops per launch =
-        # 2 * 8^3 MACs per 8x8 patch transform (row-column matrix form) x the transforms the
+        # 2 * psz^3 MACs per psz x psz patch transform (row-column matrix form) x the transforms the
         # path needs: per processed target (nsel image + nsel previous-frame patches when it
         # has any + 2 * nagg for the members' forward and inverse) x channels; the counts are
         # read from the last launch's records (single GPU; strips: the 70 % of the C2 frame).
@@ -392,7 +392,7 @@ def main():
             rec = ctx.read_records()
             act = rec["active"].astype(bool) & (rec["nagg"] > 0)
             ntr = (rec["nsel"] * (1 + (rec["np0"] > 0)) + 2 * rec["nagg"])[act].sum()
-            group_flops = float(ntr) * ch * 2 * 2 * 8 ** 3
+            group_flops = float(ntr) * ch * 2 * 2 * psz ** 3
         else:
             group_flops = ngrid * 0.70 * 0.60e6
         alg_flops = {"match": ngrid * (121 * 192 * 3), "group": group_flops}
@@ -400,7 +400,7 @@ def main():
         dur = tm[dom + "_ms"] * 1e-3
         gbs = alg_bytes[dom] / world / dur / 1e9 if dur > 0 else 0.0
         tfl = alg_flops[dom] / world / dur / 1e12 if dur > 0 else 0.0
-        kname = "k_group8m" if dom == "group" else "k_bm_topk"
+        kname = ("k_group8m" if psz == 8 else "k_group12" if psz == 12 else "k_group") if dom == "group" else "k_bm_topk"
         # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE in separate runs, tools/pmc_run.sh); valid for the single-GPU C2 launch only
         traffic = None
@@ -415,7 +415,9 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes[dom] // world,
                 "hbm": {"achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 6)},
-                "note": "~550 flop per algorithmic byte: compute bound. f32 MFMA and f32 VALU share "
+                "note": ("12x12 patches: the transforms run on the f32 vector ALU (same FP32 datapath, same peak). "
+                         if psz != 8 else "") +
+                        "~550 flop per algorithmic byte: compute bound. f32 MFMA and f32 VALU share "
                         "the FP32 datapath on gfx950 (no co-issue gain measured), so the bound is "
                         "32 cycles per MFMA + 4 per VALU instruction: see DESIGN.md §5"}
         res = {"metric": "Mpix/s per frame (nlkalman-flt, 1080p sigma=20)"
