@@ -29,7 +29,7 @@ HIP_SYMBOLS = [
     "nlk_dev_frame_accumulate", "nlk_dev_frame_normalize", "nlk_ctx_read_records",
     "nlk_dev_strip_match", "nlk_dev_mask_commit", "nlk_dev_strip_group",
     "nlk_tvl1_default_params", "nlk_tvl1_scales", "nlk_dev_tvl1_flow", "nlk_dev_gray",
-    "nlk_dev_occlusion_mask", "nlk_dev_image_dct", "nlk_dev_copy_block",
+    "nlk_dev_occlusion_mask", "nlk_dev_image_dct", "nlk_dev_copy_block", "nlk_host_tables",
 ]
 API_SYMBOLS = [
     "rgb2opp", "opp2rgb", "warp_bicubic", "nlkalman_default_params",
@@ -128,6 +128,7 @@ def hip():
         L.nlk_dev_occlusion_mask.argtypes = [vp, fp, fp, i, i, f]
         L.nlk_dev_image_dct.argtypes = [vp, fp, i, i, i, i]
         L.nlk_dev_copy_block.argtypes = [vp, fp, i, fp, i, i, i, i]
+        L.nlk_host_tables.argtypes = [i, vp, vp, vp]
         _hip = L
     return _hip
 
@@ -230,6 +231,17 @@ def warp_bicubic(im, flow, occ=None):
     out = np.empty_like(im)
     api().warp_bicubic(_fp(out), _fp(im), _fp(flow), _fp(occ), w, h, ch)
     return out
+
+
+def host_tables(psz):
+    """The DCT basis and aggregation window a frame call uploads for this patch size, and the
+    compile-time 12x12 basis of the register kernel (nlk_host_tables; no device needed)."""
+    b, w, b12 = (np.zeros((psz, psz), np.float32), np.zeros((psz, psz), np.float32),
+                 np.zeros((12, 12), np.float32))
+    rc = hip().nlk_host_tables(psz, b.ctypes.data, w.ctypes.data, b12.ctypes.data)
+    if rc:
+        raise NlkError(hip().nlk_last_error(None).decode())
+    return b, w, b12
 
 
 # ------------------------------------------------------- device-resident C-ABI

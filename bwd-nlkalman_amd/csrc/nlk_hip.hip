@@ -741,6 +741,15 @@ int nlk_dev_smooth_frame(nlk_ctx* c, float* smoo1, const float* filt1, const flo
   return run_frame(c, smoo1, filt1, smoo0, bsic1, w, h, ch, sigma, P, 1);
 }
 
+// the tables upload_tables() sends to the device, for tests that pin them (tests/test_fftw_pin.py)
+int nlk_host_tables(int psz, float* basis, float* window, float* basis12_regs) {
+  if (psz < 2 || psz > 64) return fail(nullptr, NLK_EINVAL, "patch size %d", psz);
+  if (basis) host_basis(basis, psz);
+  if (window) host_window(window, psz);
+  if (basis12_regs) memcpy(basis12_regs, NLK_C12, sizeof(NLK_C12));  // compile-time table of k_group12.h
+  return NLK_OK;
+}
+
 int nlk_ctx_read_records(nlk_ctx* c, int* ngrid, int* kmax, int* gmax, unsigned char* active,
                          int* nsel, int* np0, int* nagg, unsigned int* topk,
                          unsigned int* gcoords) {

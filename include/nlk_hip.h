@@ -176,6 +176,12 @@ int nlk_ctx_read_records(nlk_ctx *ctx, int *ngrid, int *kmax, int *gmax,
                          unsigned char *active, int *nsel, int *np0, int *nagg,
                          unsigned int *topk, unsigned int *gcoords);
 
+/* the host-side tables a frame call uploads (tests only; no device needed): the orthonormal
+ * DCT-II basis [psz][psz] that stands for FFTW REDFT10/REDFT01 x the reference's scaling
+ * (src/nlkalman.c:204-220, 281-298, 335-353), the aggregation window (:365-419), and the
+ * compile-time 12x12 basis of the register kernel. Any pointer may be NULL. */
+int nlk_host_tables(int psz, float *basis, float *window, float *basis12_regs);
+
 #ifdef __cplusplus
 }
 #endif
