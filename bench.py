@@ -186,7 +186,7 @@ def bench_flow(args, pkg, synth, ctx, torch, dist, rank, world, dev):
 
 def bench_sequence(args, pkg, synth, ctx, torch, rank, world, dev):
     """Workload S1: one step = one frame of the forward recursion of scripts/nlkalman-seq.sh on
-    resident frames (tvl1flow lambda 0.40 fscale 1 -> mask 0.75 -> warp + FLT1 -> warp + FLT2)."""
+    resident frames (tvl1flow lambda 0.25 fscale 1 -> mask 0.75 -> warp + FLT1 -> warp + FLT2)."""
     import numpy as np
     seq = importlib.import_module("bwd-nlkalman_amd.sequence")
     if world != 1:
@@ -230,7 +230,7 @@ def bench_sequence(args, pkg, synth, ctx, torch, rank, world, dev):
            "value": round(w * h / (dt / args.steps) / 1e6, 3), "unit": "Mpix/s", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"S1: {w}x{h}x{ch} sigma={sigma:g}, per frame: TV-L1 flow (lambda 0.40, fscale 1) "
+           "config": {"workload": f"S1: {w}x{h}x{ch} sigma={sigma:g}, per frame: TV-L1 flow (lambda 0.25, fscale 1: the default of scripts/nlkalman-seq.sh) "
                                   "to the previous FLT2 output, occlusion mask (0.75), warp + FLT1, warp + FLT2 "
                                   "(defaults of nlkalman_default_params), nothing leaves HBM",
                       "parallelism": "single GPU" if ns == 1 else f"single GPU, {ns} concurrent sequences",

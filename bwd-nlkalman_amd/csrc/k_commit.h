@@ -158,7 +158,8 @@ k_mask_commit_wave(const uint32_t* __restrict__ skewed, uint8_t* __restrict__ ac
   // (blockDim.x = rows of the skewed array; it holds 2 phases of zero rows past the last step)
   auto fetch = [&](int s) -> uint32_t { return skewed[(size_t)s * blockDim.x + j]; };
   auto ld_prog = [&](int w) {
-    return __hip_atomic_load(&prog[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // acquire: the edge[] words read after a successful poll were written before the matching release
+    return __hip_atomic_load(&prog[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
   uint32_t A[S], B[S];
 #pragma unroll
@@ -217,9 +218,9 @@ k_mask_commit_wave(const uint32_t* __restrict__ skewed, uint8_t* __restrict__ ac
       pend = (pend >> 1) | (fwd & ((1u << R) - 1u));  // same row, columns i+1 .. i+R
       if (lane >= 64 - R) edge[wave][s % NLK_CW_RING][lane - (64 - R)] = outp;
     }
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // this phase's edge words are in LDS
+    // release: this phase's edge words (plain LDS stores above) are visible before the progress word
     if (lane == 63)
-      __hip_atomic_store(&prog[wave], s0 + S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(&prog[wave], s0 + S, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     // write the phase's decisions: whole 32-bit words where the 4 columns exist
     {
       const int i0 = s0 - skew * j;  // column of step s0 for this row

@@ -53,6 +53,7 @@ struct nlk_ctx {
   // only by nlk_ctx_get_timings, so the timed loop never synchronises
   static constexpr int NEV = 7, MAXSETS = 512;
   bool profiling = false;
+  bool recording = false;    // the current frame call has an event set (false once MAXSETS are used)
   hipEvent_t* ev = nullptr;  // [MAXSETS][NEV], created lazily
   int nsets = 0;             // completed + current
   nlk_timings tm{};
@@ -297,13 +298,15 @@ int check_images(nlk_ctx* c, const void* out, const void* cur, int w, int h, int
 }
 
 // event i of the current frame call; event 0 opens a new set
+// (once MAXSETS frame calls have been recorded, recording stops: the averages then cover the
+// first MAXSETS calls, and no set is ever overwritten or left half-recorded)
 void mark(nlk_ctx* c, int i) {
   if (!c->profiling) return;
   if (i == 0) {
-    if (c->nsets >= nlk_ctx::MAXSETS) return;
-    c->nsets++;
+    c->recording = c->nsets < nlk_ctx::MAXSETS;
+    if (c->recording) c->nsets++;
   }
-  if (c->nsets < 1 || c->nsets > nlk_ctx::MAXSETS) return;
+  if (!c->recording || c->nsets < 1) return;
   (void)hipEventRecord(c->ev[(c->nsets - 1) * nlk_ctx::NEV + i], c->stream);
 }
 
@@ -365,6 +368,7 @@ int nlk_ctx_set_profiling(nlk_ctx* c, int on) {
     for (int i = 0; i < n; ++i) HIPCHK(c, hipEventCreate(&c->ev[i]));
   }
   c->profiling = on != 0;
+  c->recording = false;
   c->nsets = 0;  // (re)start averaging
   return NLK_OK;
 }

@@ -42,20 +42,22 @@ int tv_gaussian2(nlk_ctx* c, const float* in_a, float* out_a, float* tmp_a, cons
 // (NlkTvMail): a spin on host memory, with a look at the stream now and then so that a failed
 // launch cannot hang the caller
 int tv_wait_mail(nlk_ctx* c, unsigned seq) {
-  volatile unsigned* flag = &c->tv_host->seq;
+  // system-scope acquire load pairing with the kernel's system-scope release store of `seq`
+  // (k_tvl1.h: nlk_tv_post): the solver state posted before it is visible once the number matches
+  unsigned* flag = &c->tv_host->seq;
+  auto posted = [&]() { return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq; };
   for (unsigned spins = 0;; ++spins) {
-    if (*flag == seq) break;
+    if (posted()) break;
     if ((spins & 0xFFF) == 0xFFF) {
       const hipError_t q = hipStreamQuery(c->stream);
       if (q == hipSuccess) {  // everything has run
-        if (*flag == seq) break;
+        if (posted()) break;
         return fail(c, NLK_EHIP, "TV-L1: the solver state was not posted");
       }
       if (q != hipErrorNotReady) return fail(c, NLK_EHIP, "TV-L1: %s", hipGetErrorString(q));
     }
     __builtin_ia32_pause();
   }
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);
   return NLK_OK;
 }
 

@@ -16,14 +16,21 @@ static float *fail(const char *path, const char *why) {
   return NULL;
 }
 
+/* header-supplied sizes: positive and at most 2^31 samples (8 GiB of floats) */
+static int sane_size(uint64_t w, uint64_t h, uint64_t ch) {
+  return w > 0 && h > 0 && ch > 0 && w <= 1u << 20 && h <= 1u << 20 && ch <= 1024 && w * h <= (1ull << 31) / ch;
+}
+
 static unsigned char *slurp(const char *path, size_t *n) {
   FILE *f = fopen(path, "rb");
   if (!f) return NULL;
   fseek(f, 0, SEEK_END);
   long sz = ftell(f);
   fseek(f, 0, SEEK_SET);
-  unsigned char *b = malloc(sz > 0 ? (size_t)sz : 1);
+  if (sz < 0) { fclose(f); return NULL; }
+  unsigned char *b = malloc((size_t)sz + 1); /* + a NUL: the text headers are parsed with sscanf */
   if (b && fread(b, 1, (size_t)sz, f) != (size_t)sz) { free(b); b = NULL; }
+  if (b) b[sz] = 0;
   fclose(f);
   *n = (size_t)sz;
   return b;
@@ -51,9 +58,11 @@ static float *read_pfm(const char *path, const unsigned char *b, size_t n, int *
   double scale;
   if (sscanf((const char *)b + 2, "%d %d %lf%n", w, h, &scale, &pos) != 3) return fail(path, "bad PFM header");
   size_t off = 2 + pos + 1; /* one whitespace byte after the scale */
+  if (*w <= 0 || *h <= 0 || !sane_size((uint64_t)*w, (uint64_t)*h, (uint64_t)c)) return fail(path, "bad PFM size");
   size_t cnt = (size_t)*w * *h * c;
   if (off + cnt * 4 > n) return fail(path, "truncated PFM");
   float *d = malloc(cnt * 4);
+  if (!d) return fail(path, "out of memory");
   memcpy(d, b + off, cnt * 4);
   if (scale > 0) /* big-endian samples */
     for (size_t i = 0; i < cnt; ++i) {
@@ -69,9 +78,11 @@ static float *read_flo(const char *path, const unsigned char *b, size_t n, int *
   int32_t ww, hh;
   memcpy(&ww, b + 4, 4);
   memcpy(&hh, b + 8, 4);
+  if (ww <= 0 || hh <= 0 || !sane_size((uint64_t)ww, (uint64_t)hh, 2)) return fail(path, "bad .flo");
   size_t cnt = (size_t)ww * hh * 2;
-  if (ww <= 0 || hh <= 0 || 12 + cnt * 4 > n) return fail(path, "bad .flo");
+  if (12 + cnt * 4 > n) return fail(path, "bad .flo");
   float *d = malloc(cnt * 4);
+  if (!d) return fail(path, "out of memory");
   memcpy(d, b + 12, cnt * 4);
   *w = ww; *h = hh; *ch = 2;
   return d;
@@ -98,41 +109,48 @@ static uint64_t tif_val(const tif_t *t, size_t e, uint64_t j) {
   return j < cnt ? rd(t, base + j * ts, ts) : 0;
 }
 
+/* TIFF LZW: MSB-first codes of 9..12 bits, early change, 256 = clear, 257 = end of data.
+ * Returns the number of bytes decoded, or (size_t)-1 on a corrupt stream (a code beyond the
+ * next free entry, or a code before any clear-state literal). Every table entry that can be
+ * reached was written since the last clear code, and every prefix is smaller than its entry,
+ * so the chain walks terminate within the 4096-byte stack. */
 static size_t lzw_decode(const unsigned char *s, size_t n, unsigned char *d, size_t cap) {
-  /* TIFF LZW: MSB-first codes, 9..12 bits, early change, 256 = clear, 257 = end */
-  static __thread uint16_t prefix[4096];  /* (per thread: nlkalman-seq decodes and encodes files on helper threads) */
-  static __thread unsigned char suffix[4096], stack[4096];
+  uint16_t prefix[4096];
+  unsigned char suffix[4096], stack[4096];
   size_t out = 0, bitpos = 0;
   int width = 9, next = 258, prev = -1;
   for (;;) {
-    if ((bitpos + width + 7) / 8 > n + 1) break;
+    if (bitpos + width > 8 * n) break; /* ran out of bits without an end code: tolerated (got < want is caught by the caller) */
     uint32_t code = 0;
     for (int i = 0; i < width; ++i) {
       const size_t bp = bitpos + i;
-      const int bit = bp / 8 < n ? (s[bp / 8] >> (7 - bp % 8)) & 1 : 0;
-      code = (code << 1) | bit;
+      code = (code << 1) | ((s[bp / 8] >> (7 - bp % 8)) & 1);
     }
     bitpos += width;
     if (code == 257) break;
     if (code == 256) { width = 9; next = 258; prev = -1; continue; }
-    int sp = 0, c = (int)code;
-    if (prev < 0) {
-      if (out < cap) d[out++] = (unsigned char)c;
-      prev = c;
+    if (prev < 0) { /* first code after a clear must be a literal */
+      if (code > 255) return (size_t)-1;
+      if (out < cap) d[out++] = (unsigned char)code;
+      prev = (int)code;
       continue;
     }
-    if (c >= next) { /* KwKwK */
+    if ((int)code > next || (int)code >= 4096) return (size_t)-1; /* only code == next (KwKwK) may be undefined */
+    int sp = 0, c = (int)code;
+    if (c == next) { /* KwKwK: the string of prev followed by its own first byte */
       int p = prev;
-      while (p >= 258) p = prefix[p];
+      while (p >= 258 && sp < 4095) p = prefix[p];
+      if (p >= 258) return (size_t)-1;
       stack[sp++] = (unsigned char)p;
       c = prev;
     }
-    while (c >= 258) { stack[sp++] = suffix[c]; c = prefix[c]; }
+    while (c >= 258 && sp < 4095) { stack[sp++] = suffix[c]; c = prefix[c]; }
+    if (c >= 258) return (size_t)-1;
     stack[sp++] = (unsigned char)c;
     const unsigned char first = (unsigned char)c;
     while (sp > 0 && out < cap) d[out++] = stack[--sp];
     if (next < 4096) {
-      prefix[next] = (uint16_t)prev;
+      prefix[next] = (uint16_t)prev; /* prev < next: chains strictly decrease */
       suffix[next] = first;
       next++;
       if (next == 511 || next == 1023 || next == 2047) width++;
@@ -141,6 +159,47 @@ static size_t lzw_decode(const unsigned char *s, size_t n, unsigned char *d, siz
     if (out >= cap) break;
   }
   return out;
+}
+
+/* the same code stream the other way (for the writer): greedy longest match, hash-probed table */
+static size_t lzw_encode(const unsigned char *s, size_t n, unsigned char *d, size_t cap) {
+  enum { HS = 9001 };
+  static __thread int32_t hkey[HS];
+  static __thread uint16_t hval[HS];
+  size_t o = 0;
+  uint64_t acc = 0;
+  int nbits = 0, width = 9, next = 258;
+#define LZW_PUT(code) do { acc = (acc << width) | (uint32_t)(code); nbits += width; \
+    while (nbits >= 8) { if (o < cap) d[o] = (unsigned char)(acc >> (nbits - 8)); ++o; nbits -= 8; } } while (0)
+  for (int i = 0; i < HS; ++i) hkey[i] = -1;
+  LZW_PUT(256);
+  if (n == 0) { LZW_PUT(257); if (nbits) { if (o < cap) d[o] = (unsigned char)(acc << (8 - nbits)); ++o; } return o; }
+  int cur = s[0];
+  for (size_t i = 1; i < n; ++i) {
+    const int ch = s[i];
+    const int32_t key = (cur << 8) | ch;
+    int h = (int)(((uint32_t)key * 2654435761u) % HS);
+    while (hkey[h] != -1 && hkey[h] != key) h = h + 1 == HS ? 0 : h + 1;
+    if (hkey[h] == key) { cur = hval[h]; continue; }
+    LZW_PUT(cur);
+    hkey[h] = key; hval[h] = (uint16_t)next++;
+    /* the decoder creates each entry one code later than the encoder, so its "early" widening at
+     * 511 / 1023 / 2047 entries is the encoder's at 512 / 1024 / 2048 */
+    if (next == 4094) { /* table full: clear */
+      LZW_PUT(256);
+      for (int k = 0; k < HS; ++k) hkey[k] = -1;
+      width = 9; next = 258;
+    } else if (next == 512 || next == 1024 || next == 2048) width++;
+    cur = ch;
+  }
+  LZW_PUT(cur);
+  next++; /* the decoder adds an entry for this code too, and may widen (or fill up) because of it */
+  if (next == 4094) { LZW_PUT(256); width = 9; }
+  else if (next == 512 || next == 1024 || next == 2048) width++;
+  LZW_PUT(257);
+  if (nbits) { if (o < cap) d[o] = (unsigned char)(acc << (8 - nbits)); ++o; }
+#undef LZW_PUT
+  return o;
 }
 
 static size_t packbits_decode(const unsigned char *s, size_t n, unsigned char *d, size_t cap) {
@@ -161,8 +220,9 @@ static float *read_tiff(const char *path, const unsigned char *b, size_t n, int 
   size_t ifd = (size_t)(t.big ? rd(&t, 8, 8) : rd(&t, 4, 4));
   const uint64_t nent = t.big ? rd(&t, ifd, 8) : rd(&t, ifd, 2);
   const size_t e0 = ifd + (t.big ? 8 : 2), esz = t.big ? 20 : 12;
-  uint64_t W = 0, H = 0, bps = 1, comp = 1, spp = 1, rps = 0, planar = 1, fmt = 1, pred = 1;
-  size_t e_off = 0, e_cnt = 0;
+  if (ifd >= n || nent > 4096 || e0 + nent * esz > n) return fail(path, "TIFF directory outside the file");
+  uint64_t W = 0, H = 0, bps = 1, comp = 1, spp = 1, rps = 0, planar = 1, fmt = 1, pred = 1, TW = 0, TL = 0;
+  size_t e_off = 0, e_cnt = 0, e_toff = 0, e_tcnt = 0;
   for (uint64_t i = 0; i < nent; ++i) {
     const size_t e = e0 + i * esz;
     switch ((int)rd(&t, e, 2)) {
@@ -177,59 +237,79 @@ static float *read_tiff(const char *path, const unsigned char *b, size_t n, int 
       case 284: planar = tif_val(&t, e, 0); break;
       case 317: pred = tif_val(&t, e, 0); break;
       case 339: fmt = tif_val(&t, e, 0); break;
-      case 322: case 324: return fail(path, "tiled TIFF not supported");
+      case 322: TW = tif_val(&t, e, 0); break;
+      case 323: TL = tif_val(&t, e, 0); break;
+      case 324: e_toff = e; break;
+      case 325: e_tcnt = e; break;
     }
   }
+  /* Data is organised either in strips of `rps` rows or in TW x TL tiles (TIFF 6.0 section 15;
+   * the reference's reader takes both through libtiff, lib/iio/iio.c:1463-1661). Both are handled as
+   * "chunks" of cw x cl pixels, `across` of them per row of chunks; edge tiles are stored whole. */
+  const int tiled = TW && TL && e_toff && e_tcnt;
+  if (tiled) { e_off = e_toff; e_cnt = e_tcnt; }
   if (!W || !H || !e_off || !e_cnt) return fail(path, "incomplete TIFF directory");
+  if (!sane_size(W, H, spp)) return fail(path, "unreasonable TIFF size");
   if (!rps || rps > H) rps = H;
   if (bps != 8 && bps != 16 && bps != 32 && bps != 64) return fail(path, "unsupported bits per sample");
+  if (pred == 3) return fail(path, "floating-point predictor (3) not supported");
+  if (pred != 1 && pred != 2) return fail(path, "unknown TIFF predictor");
+  if (tiled && (TW > (1u << 20) || TL > (1u << 20))) return fail(path, "unreasonable tile size");
   const int bytes = (int)bps / 8;
-  const uint64_t planes = planar == 2 ? spp : 1, cpp = planar == 2 ? 1 : spp; /* comps per pixel in a strip */
-  const uint64_t spp_strips = (H + rps - 1) / rps;
+  const uint64_t planes = planar == 2 ? spp : 1, cpp = planar == 2 ? 1 : spp; /* comps per pixel in a chunk */
+  const uint64_t cw = tiled ? TW : W, cl = tiled ? TL : rps;
+  const uint64_t across = (W + cw - 1) / cw, down = (H + cl - 1) / cl;
   float *out = malloc((size_t)W * H * spp * sizeof(float));
-  unsigned char *raw = malloc((size_t)W * rps * cpp * bytes + 16);
+  unsigned char *raw = malloc((size_t)cw * cl * cpp * bytes + 16);
+  if (!out || !raw) { free(out); free(raw); return fail(path, "out of memory"); }
   for (uint64_t pl = 0; pl < planes; ++pl)
-    for (uint64_t s = 0; s < spp_strips; ++s) {
-      const uint64_t idx = pl * spp_strips + s;
-      const size_t off = (size_t)tif_val(&t, e_off, idx), cnt = (size_t)tif_val(&t, e_cnt, idx);
-      const uint64_t rows = (s + 1) * rps <= H ? rps : H - s * rps;
-      const size_t want = (size_t)W * rows * cpp * bytes;
-      if (off + cnt > n) { free(out); free(raw); return fail(path, "strip outside the file"); }
-      size_t got = want;
-      if (comp == 1) memcpy(raw, b + off, cnt < want ? cnt : want);
-      else if (comp == 5) got = lzw_decode(b + off, cnt, raw, want);
-      else if (comp == 32773) got = packbits_decode(b + off, cnt, raw, want);
-      else if (comp == 8 || comp == 32946) { if (z_uncompress(raw, &got, b + off, cnt)) got = 0; }
-      else { free(out); free(raw); return fail(path, "unsupported TIFF compression"); }
-      if (got < want) { free(out); free(raw); return fail(path, "short strip"); }
-      if (pred == 2 && bytes <= 4 && fmt != 3) /* horizontal differencing */
-        for (uint64_t r = 0; r < rows; ++r)
-          for (uint64_t x = cpp; x < W * cpp; ++x) {
-            unsigned char *p = raw + (r * W * cpp + x) * bytes, *q = p - cpp * bytes;
-            if (bytes == 1) p[0] += q[0];
-            else {
-              uint32_t a = 0, c2 = 0;
-              for (int k = 0; k < bytes; ++k) { a |= (uint32_t)p[t.le ? k : bytes - 1 - k] << (8 * k); c2 |= (uint32_t)q[t.le ? k : bytes - 1 - k] << (8 * k); }
-              a += c2;
-              for (int k = 0; k < bytes; ++k) p[t.le ? k : bytes - 1 - k] = (unsigned char)(a >> (8 * k));
+    for (uint64_t cy = 0; cy < down; ++cy)
+      for (uint64_t cx = 0; cx < across; ++cx) {
+        const uint64_t idx = (pl * down + cy) * across + cx;
+        const size_t off = (size_t)tif_val(&t, e_off, idx), cnt = (size_t)tif_val(&t, e_cnt, idx);
+        /* a strip holds only the rows that exist, a tile is always whole */
+        const uint64_t rows_in = tiled ? cl : ((cy + 1) * cl <= H ? cl : H - cy * cl);
+        const uint64_t rows = (cy + 1) * cl <= H ? cl : H - cy * cl;   /* rows of it inside the image */
+        const uint64_t cols = (cx + 1) * cw <= W ? cw : W - cx * cw;
+        const size_t want = (size_t)cw * rows_in * cpp * bytes;
+        if (off > n || cnt > n - off) { free(out); free(raw); return fail(path, "strip / tile outside the file"); }
+        size_t got = want;
+        if (comp == 1) { got = cnt < want ? cnt : want; memcpy(raw, b + off, got); }
+        else if (comp == 5) got = lzw_decode(b + off, cnt, raw, want);
+        else if (comp == 32773) got = packbits_decode(b + off, cnt, raw, want);
+        else if (comp == 8 || comp == 32946) { if (z_uncompress(raw, &got, b + off, cnt)) got = 0; }
+        else { free(out); free(raw); return fail(path, "unsupported TIFF compression"); }
+        if (got == (size_t)-1) { free(out); free(raw); return fail(path, "corrupt LZW stream"); }
+        if (got < want) { free(out); free(raw); return fail(path, "short strip / tile"); }
+        if (pred == 2 && bytes <= 4 && fmt != 3) /* horizontal differencing */
+          for (uint64_t r = 0; r < rows_in; ++r)
+            for (uint64_t x = cpp; x < cw * cpp; ++x) {
+              unsigned char *p = raw + (r * cw * cpp + x) * bytes, *q = p - cpp * bytes;
+              if (bytes == 1) p[0] += q[0];
+              else {
+                uint32_t a = 0, c2 = 0;
+                for (int k = 0; k < bytes; ++k) { a |= (uint32_t)p[t.le ? k : bytes - 1 - k] << (8 * k); c2 |= (uint32_t)q[t.le ? k : bytes - 1 - k] << (8 * k); }
+                a += c2;
+                for (int k = 0; k < bytes; ++k) p[t.le ? k : bytes - 1 - k] = (unsigned char)(a >> (8 * k));
+              }
             }
-          }
-      for (uint64_t r = 0; r < rows; ++r)
-        for (uint64_t x = 0; x < W; ++x)
-          for (uint64_t c = 0; c < cpp; ++c) {
-            const unsigned char *p = raw + ((r * W + x) * cpp + c) * bytes;
-            uint64_t v = 0;
-            for (int k = 0; k < bytes; ++k) v |= (uint64_t)p[t.le ? k : bytes - 1 - k] << (8 * k);
-            float f;
-            if (fmt == 3) {
-              if (bytes == 4) { uint32_t u = (uint32_t)v; memcpy(&f, &u, 4); }
-              else { double dd; memcpy(&dd, &v, 8); f = (float)dd; }
-            } else if (fmt == 2) {
-              f = bytes == 1 ? (float)(int8_t)v : bytes == 2 ? (float)(int16_t)v : bytes == 4 ? (float)(int32_t)v : (float)(int64_t)v;
-            } else f = (float)v;
-            out[((s * rps + r) * W + x) * spp + (planar == 2 ? pl : c)] = f;
-          }
-    }
+        for (uint64_t r = 0; r < rows; ++r)
+          for (uint64_t x = 0; x < cols; ++x)
+            for (uint64_t c = 0; c < cpp; ++c) {
+              const unsigned char *p = raw + ((r * cw + x) * cpp + c) * bytes;
+              uint64_t v = 0;
+              for (int k = 0; k < bytes; ++k) v |= (uint64_t)p[t.le ? k : bytes - 1 - k] << (8 * k);
+              float f;
+              if (fmt == 3) {
+                if (bytes == 4) { uint32_t u = (uint32_t)v; memcpy(&f, &u, 4); }
+                else if (bytes == 8) { double dd; memcpy(&dd, &v, 8); f = (float)dd; }
+                else { free(out); free(raw); return fail(path, "unsupported float sample size"); }
+              } else if (fmt == 2) {
+                f = bytes == 1 ? (float)(int8_t)v : bytes == 2 ? (float)(int16_t)v : bytes == 4 ? (float)(int32_t)v : (float)(int64_t)v;
+              } else f = (float)v;
+              out[((cy * cl + r) * W + cx * cw + x) * spp + (planar == 2 ? pl : c)] = f;
+            }
+      }
   free(raw);
   *w = (int)W; *h = (int)H; *ch = (int)spp;
   return out;
@@ -241,12 +321,14 @@ static float *read_png(const char *path, const unsigned char *b, size_t n, int *
   size_t pos = 8, zlen = 0;
   uint32_t W = 0, H = 0;
   int depth = 0, ctype = 0, interlace = 0, npal = 0;
-  unsigned char *z = malloc(n), pal[256 * 3];
+  unsigned char *z = malloc(n ? n : 1), pal[256 * 3];
+  if (!z) return fail(path, "out of memory");
+  memset(pal, 0, sizeof pal);
   while (pos + 12 <= n) {
     const uint32_t len = be32(b + pos);
     const unsigned char *ty = b + pos + 4, *dat = b + pos + 8;
     if (pos + 12 + len > n) break;
-    if (!memcmp(ty, "IHDR", 4)) { W = be32(dat); H = be32(dat + 4); depth = dat[8]; ctype = dat[9]; interlace = dat[12]; }
+    if (!memcmp(ty, "IHDR", 4) && len >= 13) { W = be32(dat); H = be32(dat + 4); depth = dat[8]; ctype = dat[9]; interlace = dat[12]; }
     else if (!memcmp(ty, "PLTE", 4)) { npal = len / 3; memcpy(pal, dat, len > 768 ? 768 : len); }
     else if (!memcmp(ty, "IDAT", 4)) { memcpy(z + zlen, dat, len); zlen += len; }
     else if (!memcmp(ty, "IEND", 4)) break;
@@ -254,11 +336,16 @@ static float *read_png(const char *path, const unsigned char *b, size_t n, int *
   }
   (void)npal;
   if (!W || !H || interlace || (depth != 8 && depth != 16)) { free(z); return fail(path, "unsupported PNG (need 8/16-bit, non-interlaced)"); }
+  if (!sane_size(W, H, 4) || (ctype != 0 && ctype != 2 && ctype != 3 && ctype != 4 && ctype != 6) || (ctype == 3 && depth != 8)) {
+    free(z);
+    return fail(path, "bad PNG header");
+  }
   const int comps = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : 4;
   const int bpp = comps * depth / 8;
   const size_t stride = (size_t)W * bpp;
   size_t rawlen = (stride + 1) * H;
   unsigned char *raw = malloc(rawlen);
+  if (!raw) { free(z); return fail(path, "out of memory"); }
   if (z_uncompress(raw, &rawlen, z, zlen) || rawlen < (stride + 1) * H) { free(z); free(raw); return fail(path, "PNG inflate failed"); }
   free(z);
   for (uint32_t y = 0; y < H; ++y) { /* undo the per-row filters */
@@ -276,6 +363,7 @@ static float *read_png(const char *path, const unsigned char *b, size_t n, int *
   }
   const int och = ctype == 3 ? 3 : comps;
   float *out = malloc((size_t)W * H * och * sizeof(float));
+  if (!out) { free(raw); return fail(path, "out of memory"); }
   for (uint32_t y = 0; y < H; ++y)
     for (uint32_t x = 0; x < W; ++x)
       for (int c = 0; c < och; ++c) {
@@ -313,10 +401,32 @@ static int write_tiff(const char *path, const float *d, int w, int h, int ch) {
   int as_bytes = 1; /* the reference's writer stores 8 bits when every sample is an integer in [0,255] */
   for (size_t i = 0; i < cnt && as_bytes; ++i) as_bytes = d[i] >= 0 && d[i] <= 255 && d[i] == floorf(d[i]);
   const int bytes = as_bytes ? 1 : 4;
-  const uint64_t datalen = (uint64_t)cnt * bytes;
+  uint64_t datalen = (uint64_t)cnt * bytes;
+  /* The reference's writer (libtiff, lib/iio/iio.c:3022-3026) LZW-compresses images below 4 Mpixel. Float
+   * noise does not compress and the encoder would dominate a frame's time, so files are written
+   * uncompressed by default (every reader concerned takes both); NLK_TIFF_LZW=1 selects LZW, one strip. */
+  const char *want_lzw = getenv("NLK_TIFF_LZW");
+  const int lzw = want_lzw && atoi(want_lzw) && (uint64_t)w * h < 2000ull * 2000ull;
+  unsigned char *packed = NULL;
+  if (lzw) {
+    const size_t cap = (size_t)datalen + datalen / 2 + 64;
+    unsigned char *src = (unsigned char *)d, *tmp = NULL;
+    if (as_bytes) {
+      tmp = malloc(cnt ? cnt : 1);
+      if (!tmp) return -1;
+      for (size_t i = 0; i < cnt; ++i) tmp[i] = (unsigned char)d[i];
+      src = tmp;
+    }
+    packed = malloc(cap);
+    if (!packed) { free(tmp); return -1; }
+    const size_t plen = lzw_encode(src, (size_t)datalen, packed, cap);
+    free(tmp);
+    if (plen > cap) { free(packed); return -1; }
+    datalen = plen;
+  }
   const int big = datalen > 0xF0000000ull;
   FILE *f = fopen(path, "wb");
-  if (!f) return -1;
+  if (!f) { free(packed); return -1; }
   unsigned char hdr[512], *p = hdr;
   const int nent = 10, esz = big ? 20 : 12;
   const uint64_t ifd_off = big ? 16 : 8;
@@ -331,7 +441,7 @@ static int write_tiff(const char *path, const float *d, int w, int h, int ch) {
   ENT(257, 4, 1, (uint64_t)h);
   if (ch <= (big ? 4 : 2)) { uint64_t v = 0; for (int c = 0; c < ch; ++c) v |= (uint64_t)(8 * bytes) << (16 * c); ENT(258, 3, (uint64_t)ch, v); }
   else ENT(258, 3, (uint64_t)ch, bps_off);
-  ENT(259, 3, 1, 1);                        /* no compression */
+  ENT(259, 3, 1, lzw ? 5 : 1);              /* LZW on request, else none */
   ENT(262, 3, 1, ch >= 3 ? 2 : 1);          /* RGB / min-is-black (reference: lib/iio/iio.c:3000-3020) */
   ENT(273, ltype, 1, data_off);
   ENT(277, 3, 1, (uint64_t)ch);
@@ -341,7 +451,8 @@ static int write_tiff(const char *path, const float *d, int w, int h, int ch) {
   put(&p, 0, big ? 8 : 4);                  /* no next IFD */
   for (int c = 0; c < 8; ++c) put(&p, c < ch ? 8 * bytes : 0, 2);
   fwrite(hdr, 1, (size_t)data_off, f);
-  if (as_bytes) { for (size_t i = 0; i < cnt; ++i) fputc((int)d[i], f); }
+  if (packed) { fwrite(packed, 1, (size_t)datalen, f); free(packed); }
+  else if (as_bytes) { for (size_t i = 0; i < cnt; ++i) fputc((int)d[i], f); }
   else fwrite(d, 4, cnt, f);
   return fclose(f);
 }

@@ -33,9 +33,11 @@ def _p():
 
 class SequenceFilter:
     """`ctx` = bwd-nlkalman_amd.Context. Flow parameters `of_*` are what the scripts pass to
-    tvl1flow (lambda = "DW", finest scale, occlusion threshold: nlkalman-seq.sh:47-52)."""
+    tvl1flow (lambda = "DW", finest scale, occlusion threshold: nlkalman-seq.sh:47-52); the defaults
+    are the script's own OPM default "1 0.25 0.75 1 0.25 0.75" (nlkalman-seq.sh:12), as in host/main_seq.c
+    (nlkalman-seq-gt.sh uses DW = 0.40)."""
 
-    def __init__(self, ctx, w, h, ch, sigma, f1=None, f2=None, s1=None, of_lambda=0.40, of_fscale=1,
+    def __init__(self, ctx, w, h, ch, sigma, f1=None, f2=None, s1=None, of_lambda=0.25, of_fscale=1,
                  occ_th=0.75, keep_history=True):
         pkg = _p()
         self.ctx, self.w, self.h, self.ch, self.sigma = ctx, w, h, ch, float(sigma)

@@ -224,3 +224,65 @@ def test_two_frame_pipeline_files(tools, O, tmp_path, name):
             cases.assert_close(got[k], g[k], "survey " + k, maxabs=2e-3)
         clean = I["clean1"]
         assert abs(cases.synth.psnr(got["f2_1"], clean) - cases.synth.psnr(g["f2_1"], clean)) <= 0.02
+
+
+def test_hostile_image_files_are_rejected(tools, tmp_path):
+    """LZW codes beyond the next free entry, stale-table cycles, short
+    uncompressed strips, the floating-point predictor and absurd header sizes must end in an
+    error message, never in a crash or a hang."""
+    import struct
+    from PIL import Image
+    g = np.random.default_rng(0).uniform(0, 255, (17, 29)).astype(np.float32)
+    Image.fromarray(g).save(tmp_path / "p.tif", compression="tiff_lzw")
+    raw = bytearray(open(tmp_path / "p.tif", "rb").read())
+
+    def entries(buf):
+        off = struct.unpack("<I", buf[4:8])[0]
+        n = struct.unpack("<H", buf[off:off + 2])[0]
+        return {struct.unpack("<H", buf[off + 2 + 12 * i:off + 4 + 12 * i])[0]: off + 2 + 12 * i for i in range(n)}
+    ent = entries(raw)
+    strip_off = struct.unpack("<I", raw[ent[273] + 8:ent[273] + 12])[0]
+    # (1) a stream whose second code is far beyond the table: clear, literal 65, code 400
+    bad = bytearray(raw)
+    bits = f"{256:09b}{65:09b}{400:09b}{257:09b}"
+    bits += "0" * (-len(bits) % 8)
+    evil = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+    bad[strip_off:strip_off + len(evil)] = evil
+    open(tmp_path / "bad1.tif", "wb").write(bad)
+    r = run("nlk-imgconv", tmp_path / "bad1.tif", tmp_path / "o.pfm")
+    assert r.returncode != 0 and "LZW" in r.stderr
+    # (2) random bytes as an LZW strip: must terminate with an error (or short strip), whatever they decode to
+    for seed in range(20):
+        bad = bytearray(raw)
+        junk = np.random.default_rng(seed).integers(0, 256, len(raw) - strip_off, dtype=np.uint8).tobytes()
+        bad[strip_off:] = junk
+        open(tmp_path / "bad2.tif", "wb").write(bad)
+        r = run("nlk-imgconv", tmp_path / "bad2.tif", tmp_path / "o.pfm")
+        assert r.returncode in (0, 1), (seed, r.returncode)      # no signal, no hang
+    # (3) uncompressed strip shorter than the image
+    Image.fromarray(g).save(tmp_path / "u.tif")
+    ur = bytearray(open(tmp_path / "u.tif", "rb").read())
+    ue = entries(ur)
+    ur[ue[279] + 8:ue[279] + 12] = struct.pack("<I", 40)          # StripByteCounts = 40 bytes
+    open(tmp_path / "bad3.tif", "wb").write(ur)
+    r = run("nlk-imgconv", tmp_path / "bad3.tif", tmp_path / "o.pfm")
+    assert r.returncode != 0 and "short strip" in r.stderr
+    # (4) floating-point predictor
+    Image.fromarray(g).save(tmp_path / "f.tif", compression="tiff_lzw", tiffinfo={317: 3})
+    r = run("nlk-imgconv", tmp_path / "f.tif", tmp_path / "o.pfm")
+    fr = open(tmp_path / "f.tif", "rb").read()
+    if 317 in entries(fr) and struct.unpack("<H", fr[entries(fr)[317] + 8:entries(fr)[317] + 10])[0] == 3:
+        assert r.returncode != 0 and "predictor" in r.stderr
+    # (5) absurd sizes in the header
+    ur = bytearray(open(tmp_path / "u.tif", "rb").read())
+    ur[ue[256] + 8:ue[256] + 12] = struct.pack("<I", 0x7fffffff)
+    ur[ue[257] + 8:ue[257] + 12] = struct.pack("<I", 0x7fffffff)
+    open(tmp_path / "bad5.tif", "wb").write(ur)
+    r = run("nlk-imgconv", tmp_path / "bad5.tif", tmp_path / "o.pfm")
+    assert r.returncode != 0 and "unreasonable" in r.stderr
+    open(tmp_path / "bad6.pfm", "wb").write(b"Pf\n2000000000 2000000000\n-1\n" + b"\0" * 64)
+    r = run("nlk-imgconv", tmp_path / "bad6.pfm", tmp_path / "o.pfm")
+    assert r.returncode != 0
+    open(tmp_path / "bad7.pfm", "wb").write(b"Pf")                 # header runs into the end of the buffer
+    r = run("nlk-imgconv", tmp_path / "bad7.pfm", tmp_path / "o.pfm")
+    assert r.returncode != 0

@@ -276,3 +276,105 @@ def test_gpu_filter_tool_reads_and_writes_reference_files(iio, built, tmp_path):
     # two runs of the filter agree to the float atomics' ordering noise only
     assert np.abs(outs["tif"] - outs["pfm"]).max() < 2e-3
     assert synth.psnr(outs["tif"], synth.clean_frame(w, h, 3, 1)) > synth.psnr(n1, synth.clean_frame(w, h, 3, 1)) + 4
+
+
+# ------------------------------------------------------------ round 2: tiles, LZW writer, hostile files
+
+def _tiled_tiff(path, a, tw, tl, comp="raw", planar=False, big=False):
+    """A tiled TIFF assembled by hand from the TIFF 6.0 specification (section 15): tiles of
+    tw x tl pixels, edge tiles padded, float32 samples; `comp` raw or deflate."""
+    import struct
+    import zlib
+    h, w, ch = a.shape
+    ax, ay = (w + tw - 1) // tw, (h + tl - 1) // tl
+    tiles = []
+    for pl in range(ch if planar else 1):
+        for ty in range(ay):
+            for tx in range(ax):
+                t = np.zeros((tl, tw, 1 if planar else ch), np.float32)
+                blk = a[ty * tl:(ty + 1) * tl, tx * tw:(tx + 1) * tw]
+                blk = blk[..., pl:pl + 1] if planar else blk
+                t[:blk.shape[0], :blk.shape[1]] = blk
+                raw = t.tobytes()
+                tiles.append(zlib.compress(raw) if comp == "deflate" else raw)
+    ents = [(256, 4, [w]), (257, 4, [h]), (258, 3, [32] * ch), (259, 3, [8 if comp == "deflate" else 1]),
+            (262, 3, [2 if ch >= 3 else 1]), (277, 3, [ch]), (284, 3, [2 if planar else 1]),
+            (322, 4, [tw]), (323, 4, [tl]), (324, 16 if big else 4, None), (325, 16 if big else 4, [len(t) for t in tiles]),
+            (339, 3, [3] * ch)]
+    tsz = {3: 2, 4: 4, 16: 8}
+    fsz, esz, hdr = (8, 20, 16) if big else (4, 12, 8)
+    ifd_len = (8 if big else 2) + len(ents) * esz + fsz
+    extra_off = hdr + ifd_len
+    extra = b""
+    # first pass: sizes of the out-of-line value arrays, then the tile offsets
+    sizes = [tsz[ty] * (len(tiles) if v is None else len(v)) for _, ty, v in ents]
+    data_off = extra_off + sum(s for s in sizes if s > fsz)
+    offs, o = [], data_off
+    for t in tiles:
+        offs.append(o)
+        o += len(t)
+    body = b""
+    for (tag, ty, v), s in zip(ents, sizes):
+        v = offs if v is None else v
+        fmt = {3: "H", 4: "I", 16: "Q"}[ty]
+        packed = struct.pack("<" + fmt * len(v), *v)
+        body += struct.pack("<HH", tag, ty) + struct.pack("<Q" if big else "<I", len(v))
+        if s <= fsz:
+            body += packed.ljust(fsz, b"\0")
+        else:
+            body += struct.pack("<Q" if big else "<I", extra_off + len(extra))
+            extra += packed
+    head = (struct.pack("<2sHHHQQ", b"II", 43, 8, 0, hdr, len(ents)) if big
+            else struct.pack("<2sHIH", b"II", 42, hdr, len(ents)))
+    with open(path, "wb") as f:
+        f.write(head + body + b"\0" * fsz + extra + b"".join(tiles))
+
+
+@pytest.mark.parametrize("comp,planar,big", [("raw", False, False), ("deflate", False, False), ("raw", True, False),
+                                             ("deflate", False, True)])
+def test_tiled_tiff_is_read_like_the_reference_library_reads_it(iio, conv, tmp_path, comp, planar, big):
+    """lib/iio/iio.c:1463-1661 reads tiled files through libtiff; host/imgio.c decodes the tiles itself."""
+    a = np.random.default_rng(8).normal(100, 50, (45, 70, 3)).astype(np.float32)
+    _tiled_tiff(tmp_path / "t.tif", a, 32, 16, comp, planar, big)
+    ref = iio.read(tmp_path / "t.tif")
+    assert np.array_equal(ref, a)                      # the hand-made file is a valid tiled TIFF
+    conv(tmp_path / "t.tif", tmp_path / "t.pfm")
+    assert np.array_equal(iio.read(tmp_path / "t.pfm"), a)
+
+
+@pytest.mark.parametrize("name", ["float_big_rgb", "bytes_rgb", "nan_holes", "float_gray"])
+def test_lzw_tiff_we_write_is_read_by_the_reference_library(iio, tmp_path, name):
+    """NLK_TIFF_LZW=1: the compression the reference's writer picks below 4 Mpixel (lib/iio/iio.c:3022-3026)."""
+    a = IMAGES[name](np.random.default_rng(6))
+    iio.write(tmp_path / "in.pfm", a)
+    r = subprocess.run([os.path.join(BIN, "nlk-imgconv"), str(tmp_path / "in.pfm"), str(tmp_path / "o.tif")],
+                       env=dict(os.environ, NLK_TIFF_LZW="1"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    import struct
+    raw = open(tmp_path / "o.tif", "rb").read()
+    n = struct.unpack("<H", raw[8:10])[0]
+    tags = {struct.unpack("<H", raw[10 + 12 * i:12 + 12 * i])[0]: struct.unpack("<H", raw[18 + 12 * i:20 + 12 * i])[0]
+            for i in range(n)}
+    assert tags[259] == 5                              # really LZW
+    assert np.array_equal(iio.read(tmp_path / "o.tif"), a, equal_nan=True)
+    # ... and by our own reader
+    r = subprocess.run([os.path.join(BIN, "nlk-imgconv"), str(tmp_path / "o.tif"), str(tmp_path / "back.pfm")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(iio.read(tmp_path / "back.pfm"), a, equal_nan=True)
+
+
+def test_lzw_long_runs_and_table_resets_round_trip(iio, tmp_path):
+    """An image large and repetitive enough to fill the 12-bit table several times and to hit
+    the KwKwK case, through our encoder -> the reference's decoder and our decoder."""
+    rng = np.random.default_rng(7)
+    a = np.repeat(rng.integers(0, 4, (64, 48, 3)), 8, axis=1).astype(np.float32)   # 64 x 384 x 3, long runs
+    a[::7] = rng.integers(0, 256, a[::7].shape)
+    iio.write(tmp_path / "in.pfm", a)
+    env = dict(os.environ, NLK_TIFF_LZW="1")
+    assert subprocess.run([os.path.join(BIN, "nlk-imgconv"), str(tmp_path / "in.pfm"), str(tmp_path / "o.tif")],
+                          env=env).returncode == 0
+    assert os.path.getsize(tmp_path / "o.tif") < a.size            # 8-bit samples, compressed
+    assert np.array_equal(iio.read(tmp_path / "o.tif"), a)
+    assert subprocess.run([os.path.join(BIN, "nlk-imgconv"), str(tmp_path / "o.tif"), str(tmp_path / "b.pfm")]).returncode == 0
+    assert np.array_equal(iio.read(tmp_path / "b.pfm"), a)
