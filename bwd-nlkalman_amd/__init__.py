@@ -64,7 +64,7 @@ class Timings(C.Structure):
 
 def build(force=False):
     """Compile the in-tree libraries with hipcc/gcc (gfx950). No GPU needed."""
-    args = ["make", "-C", _HERE, "all"]
+    args = ["make", "-j8", "-C", _HERE, "all"]
     if force:
         args.insert(1, "-B")
     subprocess.check_call(args)

@@ -18,6 +18,7 @@
 // with coalesced global float atomics (see k_group8.h).
 #pragma once
 #include "k_group8.h"
+#include "k_group8m.h"  // nlk_f4
 #include "nlk_common.h"
 
 constexpr float NLK_C12[12][12] = {

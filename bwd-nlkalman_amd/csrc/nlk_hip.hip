@@ -4,93 +4,18 @@
 // stream; scratch buffers are grown on demand and kept, so a steady-state frame
 // call performs no allocation (context/alloc time is on the
 // CLI critical path).
-#include <hip/hip_runtime.h>
 #include <math.h>
-#include <stdarg.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
 
-#include "../../include/nlk_hip.h"
 #include "k_commit.h"
 #include "k_frame.h"
-#include "k_group.h"
-#include "k_group8.h"
-#include "k_group8m.h"
-#include "k_group12.h"
-#include "k_match.h"
-#include "k_tvl1.h"
-#include "k_ms.h"
-#include "nlk_common.h"
+#include "k_match.h"   // NlkTile (the kernels themselves are compiled in tu_match.hip)
+#include "nlk_internal.h"
+
+char nlk_g_err[512] = "";
 
 namespace {
 
-struct Buf {
-  void* p = nullptr;
-  size_t cap = 0;
-};
-
-char g_err[512] = "";
-
-}  // namespace
-
-struct nlk_ctx {
-  int device = 0;
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream = nullptr;
-  char err[512] = "";
-  Buf pl_cur, pl_prev, pl_basic, rowok, vmap, topk, tinfo, gcoords, marks, active, acc, tabs, wide;
-  Buf skew;                       // mark words in replay-step order (k_marks_skew)
-  Buf ms;                         // whole-image DCT: temporary image + the two basis matrices
-  Buf tv;                         // TV-L1 pyramids and work images
-  NlkTvMail* tv_host = nullptr;   // pinned: the solver state, posted by the kernels (k_tvl1.h)
-  unsigned tv_seq = 0;
-  int tabs_psz = 0;
-  NlkGeom last{};
-  bool have_last = false;
-  const float *p_match = nullptr, *p_cur = nullptr, *p_prev = nullptr;  // planar images of the last match phase
-  // profiling: one set of NEV events per frame call, read back (and averaged)
-  // only by nlk_ctx_get_timings, so the timed loop never synchronises
-  static constexpr int NEV = 7, MAXSETS = 512;
-  bool profiling = false;
-  bool recording = false;    // the current frame call has an event set (false once MAXSETS are used)
-  hipEvent_t* ev = nullptr;  // [MAXSETS][NEV], created lazily
-  int nsets = 0;             // completed + current
-  nlk_timings tm{};
-};
-
-namespace {
-
-int fail(nlk_ctx* c, int code, const char* fmt, ...) {
-  char msg[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(msg, sizeof msg, fmt, ap);
-  va_end(ap);
-  snprintf(g_err, sizeof g_err, "%s", msg);
-  if (c) snprintf(c->err, sizeof c->err, "%s", msg);
-  return code;
-}
-
-#define HIPCHK(ctx, call)                                                         \
-  do {                                                                            \
-    hipError_t e_ = (call);                                                       \
-    if (e_ != hipSuccess)                                                         \
-      return fail(ctx, NLK_EHIP, "%s failed: %s (%s:%d)", #call,                  \
-                  hipGetErrorString(e_), __FILE__, __LINE__);                     \
-  } while (0)
-
-int reserve(nlk_ctx* c, Buf& b, size_t bytes) {
-  if (bytes <= b.cap) return NLK_OK;
-  if (b.p) HIPCHK(c, hipFree(b.p));
-  b.p = nullptr;
-  b.cap = 0;
-  const size_t want = bytes + bytes / 8 + 256;
-  if (hipMalloc(&b.p, want) != hipSuccess)
-    return fail(c, NLK_ENOMEM, "hipMalloc of %zu bytes failed", want);
-  b.cap = want;
-  return NLK_OK;
-}
+typedef NlkBuf Buf;
 
 // reference: src/nlkalman.c:365-419 ("gaussian"), float/double mix as written there
 void host_window(float* W, int psz) {
@@ -129,150 +54,14 @@ int upload_tables(nlk_ctx* c, int psz) {
   return NLK_OK;
 }
 
-template <int PSZ, int CH>
-int launch_group_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
-                   const float* prev, float* acc, const uint8_t* active) {
-  const int ngrid = g.ngx * g.ngy;
-  const float* basis = (const float*)c->tabs.p;
-  const float* window = basis + PSZ * PSZ;
-  if (g.smoother)
-    hipLaunchKernelGGL((k_group<PSZ, CH, true>), dim3(ngrid), dim3(64), 0, c->stream, img,
-                       cur, prev, (const uint8_t*)c->vmap.p, g, (const uint32_t*)c->topk.p,
-                       (const NlkTarget*)c->tinfo.p, (const uint32_t*)c->gcoords.p,
-                       active, basis, window, acc);
-  else
-    hipLaunchKernelGGL((k_group<PSZ, CH, false>), dim3(ngrid), dim3(64), 0, c->stream, img,
-                       cur, prev, (const uint8_t*)c->vmap.p, g, (const uint32_t*)c->topk.p,
-                       (const NlkTarget*)c->tinfo.p, (const uint32_t*)c->gcoords.p,
-                       active, basis, window, acc);
-  HIPCHK(c, hipGetLastError());
-  return NLK_OK;
-}
-
-template <int CH>
-int launch_group_ch(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
-                    const float* prev, float* acc, const uint8_t* active) {
-  switch (g.psz) {
-    case 4: return launch_group_t<4, CH>(c, g, img, cur, prev, acc, active);
-    case 6: return launch_group_t<6, CH>(c, g, img, cur, prev, acc, active);
-    case 8: return launch_group_t<8, CH>(c, g, img, cur, prev, acc, active);
-    case 10: return launch_group_t<10, CH>(c, g, img, cur, prev, acc, active);
-    case 12: return launch_group_t<12, CH>(c, g, img, cur, prev, acc, active);
-    case 16: return launch_group_t<16, CH>(c, g, img, cur, prev, acc, active);
-  }
-  return fail(c, NLK_EUNSUP, "patch size %d not supported (4, 6, 8, 10, 12, 16)", g.psz);
-}
-
-template <int PSZ, int CH, bool SMO>
-int launch_group_fast_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
-                        const float* prev, float* acc, const uint8_t* active) {
-  NlkGTile tl{};
-  // LDS tile halo = reach of the dominant kind of group; the rare spatial-branch
-  // groups of a temporal frame that reach further fall back to HBM atomics
-  tl.wmax = (g.smoother || g.have_prev) ? g.wsz_t : g.wsz_x;
-  // 4 x 1 targets per wavefront measured best for the temporal radius (profiles/README.md);
-  // with a wide halo the tile would leave LDS room for ~1 wavefront per SIMD: 2 x 1 then, and for
-  // the 12x12 kernel (8.0 ms against 8.8 with 4 x 1 at C3).
-  // NLK_GTX/NLK_GTY override for experiments
-  tl.tgx = getenv("NLK_GTX") ? atoi(getenv("NLK_GTX")) : ((PSZ == 8 && tl.wmax > 6) || PSZ == 12 ? 2 : 4);
-  tl.tgy = getenv("NLK_GTY") ? atoi(getenv("NLK_GTY")) : 1;
-  tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
-  tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
-  // psz 8 runs its DCTs on the matrix cores (k_group8m.h); NLK_GROUP_DPP selects the
-  // register/DPP kernel (k_group8.h) for comparison
-  const bool mfma = PSZ == 8 && !getenv("NLK_GROUP_DPP");
-  const int rw_max = (tl.tgx - 1) * g.step + 2 * tl.wmax + g.psz;
-  tl.rh_max = (tl.tgy - 1) * g.step + 2 * tl.wmax + g.psz;
-  if (mfma) {
-    // one aggregation access = 4x4 pixels of each plane: row stride = 4 and plane
-    // stride = 16 (mod 32 banks) make the 64 lanes hit every bank twice
-    tl.rwp = rw_max + ((4 - rw_max) % 32 + 32) % 32;
-    tl.plane = tl.rwp * tl.rh_max;
-    tl.plane += ((16 - tl.plane) % 32 + 32) % 32;
-  } else {
-    tl.rwp = rw_max | 1;
-    tl.plane = tl.rwp * tl.rh_max;
-  }
-  // (+ the 12x12 kernel's transposition scratch: k_group12.h)
-  const size_t lds = sizeof(float) * ((size_t)(CH + 1) * tl.plane + (mfma ? CH * 128 : 0) +
-                                     (PSZ == 12 ? 4 + NLK_T12_FLOATS : 0));
-  if (lds > 160 * 1024) return fail(c, NLK_EUNSUP, "aggregation tile needs %zu bytes of LDS", lds);
-  void (*kern)(const float*, const float*, const float*, const uint8_t*, NlkGeom, NlkGTile,
-               const uint32_t*, const NlkTarget*, const uint32_t*, const uint8_t*, const float*,
-               const float*, float*);
-  if (PSZ == 8) kern = mfma ? k_group8m<CH, SMO> : k_group8<CH, SMO>;
-  else kern = k_group12<CH, SMO>;
-  HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
-  const float* basis = (const float*)c->tabs.p;
-  hipLaunchKernelGGL(kern, dim3(nlk_xcd_grid(tl.ntx * tl.nty)), dim3(64), lds, c->stream, img, cur, prev,
-                     (const uint8_t*)c->vmap.p, g, tl, (const uint32_t*)c->topk.p,
-                     (const NlkTarget*)c->tinfo.p, (const uint32_t*)c->gcoords.p,
-                     active, basis, basis + PSZ * PSZ, acc);
-  HIPCHK(c, hipGetLastError());
-  return NLK_OK;
-}
-
 int launch_group(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
                  const float* prev, float* acc, const uint8_t* active) {
-  // register/DPP fast path (its per-lane candidate lists hold up to 128 entries)
-  if ((g.psz == 8 || g.psz == 12) && g.kmax <= 128 && g.gstride <= 128 &&
-      !getenv("NLK_GENERIC_GROUP")) {
-#define NLK_FAST(P, C)                                                                    \
-  if (g.psz == P && g.ch == C)                                                            \
-    return g.smoother ? launch_group_fast_t<P, C, true>(c, g, img, cur, prev, acc, active) \
-                      : launch_group_fast_t<P, C, false>(c, g, img, cur, prev, acc, active);
-    NLK_FAST(8, 1) NLK_FAST(8, 3) NLK_FAST(12, 1) NLK_FAST(12, 3)
-#undef NLK_FAST
-  }
-  if (g.ch == 1) return launch_group_ch<1>(c, g, img, cur, prev, acc, active);
-  if (g.ch == 3) return launch_group_ch<3>(c, g, img, cur, prev, acc, active);
-  return fail(c, NLK_EUNSUP, "%d channels not supported (1 or 3)", g.ch);
-}
-
-template <int PSZ, int CH, int MAXM>
-int launch_match_t(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds,
-                   const float* img, bool wide) {
-  auto kern = wide ? k_bm_wide<PSZ, CH, MAXM> : k_bm_topk<PSZ, CH, MAXM>;
-  HIPCHK(c, hipFuncSetAttribute((const void*)kern,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  // k_bm_wide: the queue length is only known on the device, so a fixed grid strides over it
-  const int grid = wide ? 512 : nlk_xcd_grid(tl.ntx * tl.nty);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NLK_BM_THREADS), lds, c->stream, img,
-                     (const uint8_t*)c->vmap.p, g, tl, (uint32_t*)c->topk.p,
-                     (NlkTarget*)c->tinfo.p, (uint32_t*)c->gcoords.p, (uint64_t*)c->marks.p,
-                     (uint32_t*)c->wide.p + 1, (uint32_t*)c->wide.p);
-  HIPCHK(c, hipGetLastError());
-  return NLK_OK;
-}
-
-template <int PSZ, int CH>
-int launch_match_m(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds,
-                   const float* img, int maxm, bool wide) {
-  if (maxm <= 2) return launch_match_t<PSZ, CH, 2>(c, g, tl, lds, img, wide);
-  if (maxm <= 7) return launch_match_t<PSZ, CH, 7>(c, g, tl, lds, img, wide);
-  return launch_match_t<PSZ, CH, 16>(c, g, tl, lds, img, wide);
-}
-
-template <int CH>
-int launch_match_ch(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds,
-                    const float* img, int maxm, bool wide) {
-  switch (g.psz) {
-    case 4: return launch_match_m<4, CH>(c, g, tl, lds, img, maxm, wide);
-    case 6: return launch_match_m<6, CH>(c, g, tl, lds, img, maxm, wide);
-    case 8: return launch_match_m<8, CH>(c, g, tl, lds, img, maxm, wide);
-    case 10: return launch_match_m<10, CH>(c, g, tl, lds, img, maxm, wide);
-    case 12: return launch_match_m<12, CH>(c, g, tl, lds, img, maxm, wide);
-    case 16: return launch_match_m<16, CH>(c, g, tl, lds, img, maxm, wide);
-  }
-  return fail(c, NLK_EUNSUP, "patch size %d not supported (4, 6, 8, 10, 12, 16)", g.psz);
-}
-
-int launch_match(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds, const float* img,
-                 int maxm, bool wide) {
-  if (g.ch == 1) return launch_match_ch<1>(c, g, tl, lds, img, maxm, wide);
-  if (g.ch == 3) return launch_match_ch<3>(c, g, tl, lds, img, maxm, wide);
-  return fail(c, NLK_EUNSUP, "%d channels not supported (1 or 3)", g.ch);
+  // register / matrix-core fast paths (their per-lane candidate lists hold up to 128 entries)
+  if ((g.psz == 8 || g.psz == 12) && (g.ch == 1 || g.ch == 3) && g.kmax <= 128 && g.gstride <= 128 &&
+      !getenv("NLK_GENERIC_GROUP"))
+    return g.psz == 8 ? nlk_launch_group8(c, g, img, cur, prev, acc, active)
+                      : nlk_launch_group12(c, g, img, cur, prev, acc, active);
+  return nlk_launch_group_generic(c, g, img, cur, prev, acc, active);
 }
 
 int to_planar(nlk_ctx* c, Buf& dst, const float* src, int npix, int ch, const float** out) {
@@ -320,7 +109,7 @@ int nlk_device_count(void) {
   return n;
 }
 
-const char* nlk_last_error(const nlk_ctx* ctx) { return ctx ? ctx->err : g_err; }
+const char* nlk_last_error(const nlk_ctx* ctx) { return ctx ? ctx->err : nlk_g_err; }
 
 int nlk_ctx_create(nlk_ctx** out, int device) {
   if (!out) return fail(nullptr, NLK_EINVAL, "null ctx pointer");
@@ -585,7 +374,7 @@ static int run_match(nlk_ctx* c, const float* cur, const float* prev, const floa
   const bool wide = g.have_prev && !g.smoother && g.wsz_x > g.wsz_t;
   if (wide) HIPCHK(c, hipMemsetAsync(c->wide.p, 0, sizeof(uint32_t), c->stream));
   const int wdom = 2 * tl.halo + 1;
-  rc = launch_match(c, g, tl, lds, img_match, (wdom * wdom + 63) / 64, false);
+  rc = nlk_launch_match(c, g, tl, lds, img_match, (wdom * wdom + 63) / 64, false);
   if (rc) return rc;
   if (wide) {
     NlkTile tw = tl;
@@ -598,7 +387,7 @@ static int run_match(nlk_ctx* c, const float* cur, const float* prev, const floa
     const size_t lds_w = sizeof(float) * NLK_BM_WAVES * per_wave;
     if (lds_w > 160 * 1024)
       return fail(c, NLK_EUNSUP, "spatial window of a temporal frame needs %zu bytes of LDS (> 160 KiB)", lds_w);
-    rc = launch_match(c, g, tw, lds_w, img_match, (ncand + 63) / 64, true);
+    rc = nlk_launch_match(c, g, tw, lds_w, img_match, (ncand + 63) / 64, true);
     if (rc) return rc;
   }
   mark(c, 2);
@@ -750,7 +539,7 @@ int nlk_host_tables(int psz, float* basis, float* window, float* basis12_regs) {
   if (psz < 2 || psz > 64) return fail(nullptr, NLK_EINVAL, "patch size %d", psz);
   if (basis) host_basis(basis, psz);
   if (window) host_window(window, psz);
-  if (basis12_regs) memcpy(basis12_regs, NLK_C12, sizeof(NLK_C12));  // compile-time table of k_group12.h
+  if (basis12_regs) memcpy(basis12_regs, nlk_basis12_table(), sizeof(float) * 144);  // compile-time table of k_group12.h
   return NLK_OK;
 }
 
@@ -789,5 +578,3 @@ int nlk_ctx_read_records(nlk_ctx* c, int* ngrid, int* kmax, int* gmax, unsigned 
 
 }  // extern "C"
 
-#include "tvl1_host.h"
-#include "ms_host.h"

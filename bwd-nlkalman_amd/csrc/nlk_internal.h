@@ -1,0 +1,95 @@
+// nlk_internal.h — what the translation units of libnlk_hip.so share: the context, error helpers,
+// scratch-buffer growth and the launchers each unit exports to nlk_hip.hip. (The library is built
+// from several .hip files so that `make -j` compiles the big kernels in parallel.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/nlk_hip.h"
+#include "nlk_common.h"
+
+struct NlkTvMail;   // k_tvl1.h
+struct NlkTile;     // k_match.h
+struct NlkGTile;    // k_group8.h
+
+struct NlkBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct nlk_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  char err[512] = "";
+  NlkBuf pl_cur, pl_prev, pl_basic, rowok, vmap, topk, tinfo, gcoords, marks, active, acc, tabs, wide;
+  NlkBuf skew;                    // mark words in replay-step order (k_marks_skew)
+  NlkBuf ms;                      // whole-image DCT: temporary image + the two basis matrices
+  NlkBuf tv;                      // TV-L1 pyramids and work images
+  NlkTvMail* tv_host = nullptr;   // pinned: the solver state, posted by the kernels (k_tvl1.h)
+  unsigned tv_seq = 0;
+  int tabs_psz = 0;
+  NlkGeom last{};
+  bool have_last = false;
+  const float *p_match = nullptr, *p_cur = nullptr, *p_prev = nullptr;  // planar images of the last match phase
+  // profiling: one set of NEV events per frame call, read back (and averaged)
+  // only by nlk_ctx_get_timings, so the timed loop never synchronises
+  static constexpr int NEV = 7, MAXSETS = 512;
+  bool profiling = false;
+  bool recording = false;    // the current frame call has an event set (false once MAXSETS are used)
+  hipEvent_t* ev = nullptr;  // [MAXSETS][NEV], created lazily
+  int nsets = 0;             // completed + current
+  nlk_timings tm{};
+};
+
+extern char nlk_g_err[512];  // last error without a context (nlk_hip.hip)
+
+static inline int fail(nlk_ctx* c, int code, const char* fmt, ...) {
+  char msg[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(msg, sizeof msg, fmt, ap);
+  va_end(ap);
+  snprintf(nlk_g_err, sizeof nlk_g_err, "%s", msg);
+  if (c) snprintf(c->err, sizeof c->err, "%s", msg);
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                         \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess)                                                         \
+      return fail(ctx, NLK_EHIP, "%s failed: %s (%s:%d)", #call,                  \
+                  hipGetErrorString(e_), __FILE__, __LINE__);                     \
+  } while (0)
+
+static inline int reserve(nlk_ctx* c, NlkBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return NLK_OK;
+  if (b.p) HIPCHK(c, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  const size_t want = bytes + bytes / 8 + 256;
+  if (hipMalloc(&b.p, want) != hipSuccess)
+    return fail(c, NLK_ENOMEM, "hipMalloc of %zu bytes failed", want);
+  b.cap = want;
+  return NLK_OK;
+}
+
+// ---- launchers (one translation unit each; all enqueue on c->stream)
+// tu_group8.hip / tu_group12.hip: the register / matrix-core group kernels for 8x8 and 12x12 patches
+int nlk_launch_group8(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur, const float* prev,
+                      float* acc, const uint8_t* active);
+int nlk_launch_group12(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur, const float* prev,
+                       float* acc, const uint8_t* active);
+// tu_group_generic.hip: the LDS-DCT kernel for every other patch size
+int nlk_launch_group_generic(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
+                             const float* prev, float* acc, const uint8_t* active);
+// tu_match.hip: block matching + selection (wide = the queued targets of a temporal frame)
+int nlk_launch_match(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds, const float* img,
+                     int maxm, bool wide);
+// the 12x12 table of k_group12.h (nlk_host_tables)
+const float* nlk_basis12_table(void);
