@@ -26,6 +26,11 @@ int launch_group_fast_t(nlk_ctx* c, const NlkGeom& g, const float* img, const fl
   // (k_group12p.h); NLK_GROUP12_ROWS selects the lane = (channel, row) kernel (k_group12.h)
   const bool mfma = false;
   const bool packed = PSZ == 12 && !getenv("NLK_GROUP12_ROWS");
+  if (packed) {  // one target per workgroup (k_group12p.h)
+    tl.tgx = tl.tgy = 1;
+    tl.ntx = g.ngx;
+    tl.nty = g.ngy;
+  }
   const int rw_max = (tl.tgx - 1) * g.step + 2 * tl.wmax + g.psz;
   tl.rh_max = (tl.tgy - 1) * g.step + 2 * tl.wmax + g.psz;
   if (mfma) {
@@ -55,7 +60,7 @@ int launch_group_fast_t(nlk_ctx* c, const NlkGeom& g, const float* img, const fl
     tl.plane = tl.rwp * tl.rh_max;
   }
   // (+ the 12x12 kernels' transposition scratch: k_group12.h, k_group12p.h)
-  const size_t lds = sizeof(float) * ((size_t)(CH + 1) * tl.plane + (mfma ? CH * 128 : 0) +
+  const size_t lds = sizeof(float) * ((size_t)(packed ? 2 : CH + 1) * tl.plane + (mfma ? CH * 128 : 0) +
                                      (packed ? NLK_P12_SCRATCH + NLK_P12_GAINS(CH) : PSZ == 12 ? 4 + NLK_T12_FLOATS : 0));
   if (lds > 160 * 1024) return fail(c, NLK_EUNSUP, "aggregation tile needs %zu bytes of LDS", lds);
   void (*kern)(const float*, const float*, const float*, const uint8_t*, NlkGeom, NlkGTile,
