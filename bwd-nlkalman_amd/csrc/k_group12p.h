@@ -37,6 +37,13 @@
 #ifndef NLK_G12P_WAVES
 #define NLK_G12P_WAVES 3  // wavefronts per SIMD the register budget is cut for (168)
 #endif
+// ordering of this wavefront's LDS writes and reads: compiler-only (nlk_common.h); NLK_P12_WAITS
+// builds the variant that also waits for the LDS counter (5.22 ms against 5.07 at C3)
+#ifdef NLK_P12_WAITS
+#define NLK_P12_SYNC nlk_wave_lds_fence
+#else
+#define NLK_P12_SYNC nlk_wave_lds_order
+#endif
 #define NLK_P12_TS 172                    // floats per slot of the transposition scratch (= 12 mod 32: the 5 slots' columns sit on disjoint banks)
 #define NLK_P12_SCRATCH (5 * NLK_P12_TS)  // also holds [5][12][12] reduction partials / staged pixel rows
 #define NLK_P12_GAINS(CH) ((CH) * 2 * 144)
@@ -49,12 +56,12 @@ __device__ __forceinline__ void nlk_p12_transpose(float (&p)[12], float* __restr
     row[1] = nlk_f4{p[4], p[5], p[6], p[7]};
     row[2] = nlk_f4{p[8], p[9], p[10], p[11]};
   }
-  nlk_wave_lds_fence();
+  NLK_P12_SYNC();
   if (on) {
 #pragma unroll
     for (int j = 0; j < 12; ++j) p[j] = tile[12 * j + u];
   }
-  nlk_wave_lds_fence();
+  NLK_P12_SYNC();
 }
 
 __device__ __forceinline__ void nlk_p12_load_row(const float* __restrict__ p, float (&dst)[12]) {
@@ -181,7 +188,7 @@ k_group12p(const float* __restrict__ img, const float* __restrict__ cur,
         ((nlk_f4*)red)[1] = nlk_f4{v[4], v[5], v[6], v[7]};
         ((nlk_f4*)red)[2] = nlk_f4{v[8], v[9], v[10], v[11]};
       }
-      nlk_wave_lds_fence();
+      NLK_P12_SYNC();
     };
     auto sum5 = [&]() -> nlk_f4 {  // sum over the 5 slots of the owned coefficients
       nlk_f4 tsum = nlk_f4{0.f, 0.f, 0.f, 0.f};
@@ -189,7 +196,7 @@ k_group12p(const float* __restrict__ img, const float* __restrict__ cur,
 #pragma unroll
         for (int s5 = 0; s5 < 5; ++s5) tsum += *(const nlk_f4*)(rd + s5 * 144);
       }
-      nlk_wave_lds_fence();
+      NLK_P12_SYNC();
       return tsum;
     };
     // two copies of the channel loop (with / without previous-frame statistics): with `hp` a
@@ -246,7 +253,7 @@ k_group12p(const float* __restrict__ img, const float* __restrict__ cur,
                                          fmaf(gm, b[4 * j + 2] - x0[4 * j + 2], S[2][4 * j + 2]),
                                          fmaf(gm, b[4 * j + 3] - x0[4 * j + 3], S[2][4 * j + 3])};
           }
-          nlk_wave_lds_fence();
+          NLK_P12_SYNC();
           tot5 = sum5();
         }
         if constexpr (HP) {
@@ -286,7 +293,7 @@ k_group12p(const float* __restrict__ img, const float* __restrict__ cur,
       nlk_f4 tot[5], x04;
       put12(x0);
       x04 = owner ? *(const nlk_f4*)rd : nlk_f4{0.f, 0.f, 0.f, 0.f};  // (every slot holds the same x0)
-      nlk_wave_lds_fence();
+      NLK_P12_SYNC();
 #pragma unroll
       for (int st = 0; st < 5; ++st) {
         tot[st] = nlk_f4{0.f, 0.f, 0.f, 0.f};
@@ -330,7 +337,7 @@ k_group12p(const float* __restrict__ img, const float* __restrict__ cur,
         *(nlk_f4*)(gbuf + ((c * 2 + 0) * 12 + u) * 12 + 4 * slot) = ga4;
         *(nlk_f4*)(gbuf + ((c * 2 + 1) * 12 + u) * 12 + 4 * slot) = mu4;
       }
-      nlk_wave_lds_fence();
+      NLK_P12_SYNC();
      }
     };
     if (hp) pass_a(std::true_type{});
@@ -353,7 +360,7 @@ k_group12p(const float* __restrict__ img, const float* __restrict__ cur,
       row[1] = nlk_f4{px[4], px[5], px[6], px[7]};
       row[2] = nlk_f4{px[8], px[9], px[10], px[11]};
     }
-    nlk_wave_lds_fence();
+    NLK_P12_SYNC();
 #pragma unroll 1
     for (int s = 0; s < 5; ++s) {
       const int mi = n0 + s;
@@ -384,7 +391,7 @@ k_group12p(const float* __restrict__ img, const float* __restrict__ cur,
         }
       }
     }
-    nlk_wave_lds_fence();
+    NLK_P12_SYNC();
   };
   // a tile plane -> HBM (coalesced rows, untouched entries skipped), cleared for the next channel
   const bool two_rows = rw <= 32;  // a narrow tile puts two rows on the 64 lanes
@@ -401,7 +408,7 @@ k_group12p(const float* __restrict__ img, const float* __restrict__ cur,
           if (clear) sp[y * rwp + xx] = 0.f;
         }
       }
-    nlk_wave_lds_fence();
+    NLK_P12_SYNC();
   };
   for (int c = 0; c < CH; ++c) {
     const float* img_c = img + c * npix;

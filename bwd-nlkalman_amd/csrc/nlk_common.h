@@ -52,3 +52,11 @@ __device__ inline void nlk_wave_lds_fence() {
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
   __builtin_amdgcn_wave_barrier();
 }
+// The same without the wait: the LDS executes the DS instructions of one wavefront in the order
+// they were issued, so a read issued after a write of the same wavefront returns the written
+// data; only the COMPILER must be kept from moving the read above the write (the wait for the
+// data itself is the ordinary lgkmcnt wait in front of its first use).
+__device__ inline void nlk_wave_lds_order() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
