@@ -16,7 +16,8 @@
 // costs 24 x 67 lane-operations = 27 wavefront instructions per plane at 60 active lanes, ~90 cycles.
 #pragma once
 
-#ifndef NLK_HD
+#ifndef NLK_HD  // (a host test defines it as `static inline` and compiles this header with g++)
+#include <hip/hip_runtime.h>
 #define NLK_HD __device__ __forceinline__
 #endif
 

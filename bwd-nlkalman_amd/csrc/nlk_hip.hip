@@ -56,12 +56,20 @@ int upload_tables(nlk_ctx* c, int psz) {
 
 int launch_group(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
                  const float* prev, float* acc, const uint8_t* active) {
-  // register / matrix-core fast paths (their per-lane candidate lists hold up to 128 entries)
-  if ((g.psz == 8 || g.psz == 12) && (g.ch == 1 || g.ch == 3) && g.kmax <= 128 && g.gstride <= 128 &&
-      !getenv("NLK_GENERIC_GROUP"))
-    return g.psz == 8 ? nlk_launch_group8(c, g, img, cur, prev, acc, active)
-                      : nlk_launch_group12(c, g, img, cur, prev, acc, active);
-  return nlk_launch_group_generic(c, g, img, cur, prev, acc, active);
+  // Default: 8x8 patches with 1 or 3 channels on the matrix cores (k_group8m.h: 1.04 ms at C2 against
+  // 1.34 ms for the packed-lane kernel), everything else on the packed-lane kernel (k_groupp.h; its
+  // per-lane candidate lists hold up to 128 entries). Comparison variants: NLK_GROUP_PACKED=1 (8x8 on
+  // k_groupp), NLK_GROUP_DPP=1 (8x8: registers + DPP), NLK_GROUP12_ROWS=1 (12x12: lane = (channel,
+  // row)), NLK_GENERIC_GROUP=1 (LDS-DCT kernel, which also takes the lists of more than 128 entries)
+  const bool ch13 = g.ch == 1 || g.ch == 3;
+  const bool lists_fit = g.kmax <= 128 && g.gstride <= 128;
+  if (getenv("NLK_GENERIC_GROUP") || !lists_fit) return nlk_launch_group_generic(c, g, img, cur, prev, acc, active);
+  if (g.psz == 8 && ch13 && !getenv("NLK_GROUP_PACKED"))
+    return nlk_launch_group8(c, g, img, cur, prev, acc, active);
+  if (g.psz == 12 && ch13 && getenv("NLK_GROUP12_ROWS")) return nlk_launch_group12(c, g, img, cur, prev, acc, active);
+  if (g.psz <= 8) return nlk_launch_groupp_a(c, g, img, cur, prev, acc, active);
+  if (g.psz <= 12) return nlk_launch_groupp_b(c, g, img, cur, prev, acc, active);
+  return nlk_launch_groupp_c(c, g, img, cur, prev, acc, active);
 }
 
 int to_planar(nlk_ctx* c, Buf& dst, const float* src, int npix, int ch, const float** out) {

@@ -85,7 +85,14 @@ int nlk_launch_group8(nlk_ctx* c, const NlkGeom& g, const float* img, const floa
                       float* acc, const uint8_t* active);
 int nlk_launch_group12(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur, const float* prev,
                        float* acc, const uint8_t* active);
-// tu_group_generic.hip: the LDS-DCT kernel for every other patch size
+// tu_groupp_{a,b,c}.hip: the packed-lane kernel (k_groupp.h), patch sizes 2..8 / 9..12 / 13..16, any channel count
+int nlk_launch_groupp_a(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur, const float* prev,
+                        float* acc, const uint8_t* active);
+int nlk_launch_groupp_b(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur, const float* prev,
+                        float* acc, const uint8_t* active);
+int nlk_launch_groupp_c(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur, const float* prev,
+                        float* acc, const uint8_t* active);
+// tu_group_generic.hip: the LDS-DCT kernel (even patch sizes, candidate lists of any length)
 int nlk_launch_group_generic(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
                              const float* prev, float* acc, const uint8_t* active);
 // tu_match.hip: block matching + selection (wide = the queued targets of a temporal frame)

@@ -1,7 +1,6 @@
-// tu_group12.hip — launcher of the 12x12 group kernels: k_group12p (packed lanes, default) and
-// k_group12 (lane = (channel, row), NLK_GROUP12_ROWS=1)
+// tu_group12.hip — launcher of k_group12 (12x12, lane = (channel, row)): the comparison variant
+// NLK_GROUP12_ROWS=1 of the packed-lane kernel (k_groupp.h)
 #include "k_group12.h"
-#include "k_group12p.h"
 #include "nlk_internal.h"
 
 namespace {
@@ -25,12 +24,7 @@ int launch_group_fast_t(nlk_ctx* c, const NlkGeom& g, const float* img, const fl
   // register/DPP kernel (k_group8.h) for comparison. psz 12 runs the packed-lane kernel
   // (k_group12p.h); NLK_GROUP12_ROWS selects the lane = (channel, row) kernel (k_group12.h)
   const bool mfma = false;
-  const bool packed = PSZ == 12 && !getenv("NLK_GROUP12_ROWS");
-  if (packed) {  // one target per workgroup (k_group12p.h)
-    tl.tgx = tl.tgy = 1;
-    tl.ntx = g.ngx;
-    tl.nty = g.ngy;
-  }
+  const bool packed = false;
   const int rw_max = (tl.tgx - 1) * g.step + 2 * tl.wmax + g.psz;
   tl.rh_max = (tl.tgy - 1) * g.step + 2 * tl.wmax + g.psz;
   if (mfma) {
@@ -39,34 +33,17 @@ int launch_group_fast_t(nlk_ctx* c, const NlkGeom& g, const float* img, const fl
     tl.rwp = rw_max + ((4 - rw_max) % 32 + 32) % 32;
     tl.plane = tl.rwp * tl.rh_max;
     tl.plane += ((16 - tl.plane) % 32 + 32) % 32;
-  } else if (packed) {
-    // one aggregation access = 12 rows x 4 blocks of 3 pixels (lane = 12 * block + row): the row
-    // stride with the fewest bank collisions among those 48 addresses (two halves of 32 lanes)
-    int best = 1 << 30;
-    tl.rwp = rw_max;
-    for (int r = rw_max; r < rw_max + 32; ++r) {
-      int cost = 0;
-      for (int half = 0; half < 2; ++half) {
-        int cnt[32] = {0}, mx = 0;
-        for (int l = 32 * half; l < 32 * half + 32 && l < 48; ++l) mx = max(mx, ++cnt[((l % 12) * r + 3 * (l / 12)) & 31]);
-        cost += mx;
-      }
-      cost = cost * 64 + (r - rw_max);  // (ties: the narrowest)
-      if (cost < best) { best = cost; tl.rwp = r; }
-    }
-    tl.plane = (tl.rwp * tl.rh_max + 3) & ~3;
   } else {
     tl.rwp = rw_max | 1;
     tl.plane = tl.rwp * tl.rh_max;
   }
   // (+ the 12x12 kernels' transposition scratch: k_group12.h, k_group12p.h)
-  const size_t lds = sizeof(float) * ((size_t)(packed ? 2 : CH + 1) * tl.plane + (mfma ? CH * 128 : 0) +
-                                     (packed ? NLK_P12_SCRATCH + NLK_P12_GAINS(CH) : PSZ == 12 ? 4 + NLK_T12_FLOATS : 0));
+  const size_t lds = sizeof(float) * ((size_t)(CH + 1) * tl.plane + 4 + NLK_T12_FLOATS);
   if (lds > 160 * 1024) return fail(c, NLK_EUNSUP, "aggregation tile needs %zu bytes of LDS", lds);
   void (*kern)(const float*, const float*, const float*, const uint8_t*, NlkGeom, NlkGTile,
                const uint32_t*, const NlkTarget*, const uint32_t*, const uint8_t*, const float*,
                const float*, float*);
-  kern = packed ? k_group12p<CH, SMO> : k_group12<CH, SMO>;
+  kern = k_group12<CH, SMO>;
   HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
   const float* basis = (const float*)c->tabs.p;
