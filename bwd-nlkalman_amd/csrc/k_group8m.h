@@ -110,7 +110,11 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   const int rwp = tl.rwp, plane = tl.plane;
   for (int i = lane; i < (CH + 1) * plane / 4; i += 64)  // (plane is a multiple of 16)
     reinterpret_cast<nlk_f4*>(smem)[i] = nlk_f4{0.f, 0.f, 0.f, 0.f};
-  float* stash = smem + (CH + 1) * plane;  // [CH][2][4][16]: gains / means between the passes
+  // [CH+2][2][4][16]: gains / means between the passes. Pass B treats the weight plane as one more
+  // channel (gain 0, mean = DCT of a constant-1 patch: 8 at the DC coefficient) and the unused slots
+  // of a 1-channel frame as another (all zero), so that its shrinkage is one fma without selects
+  float* stash = smem + (CH + 1) * plane;
+  for (int i = lane; i < 2 * 128; i += 64) stash[CH * 128 + i] = (i == 64) ? 8.f : 0.f;
   __syncthreads();
 
   const int lo = lane & 15, g4 = lane >> 4;
@@ -297,23 +301,32 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
           }
         }
         if (b == nb - 1) {
-          // the channel is complete: candidates are spread over the four lane groups
+          // The channel is complete: candidates are spread over the four lane groups. Each of the
+          // sums is reduced over them with the row-swap instructions: two registers per
+          // v_permlane32_swap + add, two of those per v_permlane16_swap + add, which leaves the total
+          // of S[a][q] in lane group q (tools/ubench/permlane_swap.hip) - 6 operations per 4 registers
+          // instead of 16, and the gains below are computed once per (quadrant, coefficient): lane
+          // (lo, g4) owns coefficient lo of quadrant g4.
+          float T[6];
 #pragma unroll
-          for (int a = 0; a < (HP ? 6 : 2); ++a)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              float v = S[a][q];
-              v += nlk_bperm(v, lane ^ 16);
-              v += nlk_bperm(v, lane ^ 32);
-              S[a][q] = v;
+          for (int a = 0; a < 6; ++a) {
+            T[a] = 0.f;
+            if (a < (HP ? (SMO ? 5 : 6) : 2)) {
+              const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(S[a][0]), __float_as_uint(S[a][2]), false, false);
+              const auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(S[a][1]), __float_as_uint(S[a][3]), false, false);
+              const float X = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+              const float Y = __uint_as_float(y[0]) + __uint_as_float(y[1]);
+              const auto z = __builtin_amdgcn_permlane16_swap(__float_as_uint(X), __float_as_uint(Y), false, false);
+              T[a] = __uint_as_float(z[0]) + __uint_as_float(z[1]);
             }
-          // ---- gains of coefficient lo of each quadrant (reference: :799-811, :859-904; smoother :1683-1776)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float mean1 = x0[q] + S[0][q] * in1;
-            const float v1 = (S[1][q] - S[0][q] * S[0][q] * in1) * in1;  // image variance
-            const float v0 = (S[3][q] - S[2][q] * S[2][q] * in0) * in0;  // previous-frame variance
-            const float v01n = S[4][q] * in0;
+          }
+          // ---- gain of coefficient lo of quadrant g4 (reference: :799-811, :859-904; smoother :1683-1776)
+          {
+            const float x0q = g4 == 0 ? x0[0] : (g4 == 1 ? x0[1] : (g4 == 2 ? x0[2] : x0[3]));
+            const float mean1 = x0q + T[0] * in1;
+            const float v1 = (T[1] - T[0] * T[0] * in1) * in1;  // image variance
+            const float v0 = (T[3] - T[2] * T[2] * in0) * in0;  // previous-frame variance
+            const float v01n = T[4] * in0;
             float a, term, m;
             if (SMO) {
               a = v1 * __builtin_amdgcn_rcpf(v1 + g.beta_t * v01n);
@@ -325,7 +338,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
               const float v = v0 + (0.f > d ? 0.f : d);
               a = v * __builtin_amdgcn_rcpf(v + g.beta_t * s2);
               term = (1 - a * a) * v + a * a * s2;
-              m = x0[q] + S[5][q] * ing;
+              m = x0q + T[5] * ing;
             } else {
               const float d = v1 - (g.have_basic ? 0.f : s2);
               const float v = 0.f > d ? 0.f : d;
@@ -333,13 +346,11 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
               term = a * v;
               m = mean1;
             }
-            if (g4 == 0) {
-              part_sum += term;
-              // parked in LDS for pass B: [channel][gain | (1-a)*mean][quadrant][coefficient]
-              // (filter: a*PG + (1-a)*M, reference: :879, :902)
-              stash[((ch * 2 + 0) * 4 + q) * 16 + lo] = a;
-              stash[((ch * 2 + 1) * 4 + q) * 16 + lo] = (1 - a) * m;
-            }
+            part_sum += term;
+            // parked in LDS for pass B: [channel][gain | (1-a)*mean][quadrant][coefficient]
+            // (filter: a*PG + (1-a)*M, reference: :879, :902)
+            stash[((ch * 2 + 0) * 4 + g4) * 16 + lo] = a;
+            stash[((ch * 2 + 1) * 4 + g4) * 16 + lo] = (1 - a) * m;
           }
 #pragma unroll
           for (int a = 0; a < 6; ++a)
@@ -378,8 +389,9 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     float ww[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) ww[kk] = wgt * win[kk];
-    const float* st_g = stash + (bchc * 2 + 0) * 64 + 4 * g4;  // + 16*q: gains of coefficients 4*g4 .. 4*g4+3
-    const float* st_m = stash + (bchc * 2 + 1) * 64 + 4 * g4;
+    const int bst = min(bch, CH + 1);  // stash channel of slot lo: image channel, weights, or nothing
+    const float* st_g = stash + (bst * 2 + 0) * 64 + 4 * g4;  // + 16*q: gains of coefficients 4*g4 .. 4*g4+3
+    const float* st_m = stash + (bst * 2 + 1) * 64 + 4 * g4;
     for (int n0 = 0; n0 < nagg; n0 += 4) {
       nlk_f4 Y[4], Z[4];
       nlk_fold(R, F);
@@ -401,12 +413,14 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const nlk_f4 gq = *reinterpret_cast<const nlk_f4*>(st_g + 16 * q);
+          const nlk_f4 mq = *reinterpret_cast<const nlk_f4*>(st_m + 16 * q);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float a = passthrough ? 0.f : gq[j];
-            const float wv = (q == 0 && g4 == 0 && j == 0) ? 8.f : 0.f;  // weight plane: DCT of a constant-1 patch
+            // (weight / unused slots: gain 1 in the stash's first half would need Yp = the constant;
+            // they carry gain 0 and their value in the mean half instead)
+            const float a = (passthrough && bch < CH) ? 0.f : gq[j];
             Y[q][j] = bch < CH ? (1 - a) * Y[q][j] + a * Yp[q][j]  // reference: :1775
-                               : (bch == CH ? wv : 0.f);
+                               : mq[j];
           }
         }
       } else {
@@ -418,10 +432,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
           const nlk_f4 gq = *reinterpret_cast<const nlk_f4*>(st_g + 16 * q);
           const nlk_f4 mq = *reinterpret_cast<const nlk_f4*>(st_m + 16 * q);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float wv = (q == 0 && g4 == 0 && j == 0) ? 8.f : 0.f;  // weight plane: gain 0, DCT of a constant-1 patch
-            Y[q][j] = bch < CH ? fmaf(gq[j], Y[q][j], mq[j]) : (bch == CH ? wv : 0.f);
-          }
+          for (int j = 0; j < 4; ++j) Y[q][j] = fmaf(gq[j], Y[q][j], mq[j]);
         }
       }
 #pragma unroll

@@ -55,7 +55,7 @@ int launch_group_fast_t(nlk_ctx* c, const NlkGeom& g, const float* img, const fl
     tl.plane = tl.rwp * tl.rh_max;
   }
   // (+ the 12x12 kernels' transposition scratch: k_group12.h, k_group12p.h)
-  const size_t lds = sizeof(float) * ((size_t)(CH + 1) * tl.plane + (mfma ? CH * 128 : 0) +
+  const size_t lds = sizeof(float) * ((size_t)(CH + 1) * tl.plane + (mfma ? (CH + 2) * 128 : 0) +
                                      0);
   if (lds > 160 * 1024) return fail(c, NLK_EUNSUP, "aggregation tile needs %zu bytes of LDS", lds);
   void (*kern)(const float*, const float*, const float*, const uint8_t*, NlkGeom, NlkGTile,
