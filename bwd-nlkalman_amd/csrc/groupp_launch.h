@@ -40,8 +40,8 @@ static int nlk_groupp_launch_t(nlk_ctx* c, const NlkGeom& g, const float* img, c
   auto kern = g.smoother ? k_groupp<PSZ, true> : k_groupp<PSZ, false>;
   HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const float* basis = (const float*)c->tabs.p;
-  hipLaunchKernelGGL(kern, dim3(nlk_xcd_grid(g.ngx * g.ngy)), dim3(64), lds, c->stream, img, cur, prev, g, tl,
-                     (const uint32_t*)c->topk.p, (const NlkTarget*)c->tinfo.p, (const uint32_t*)c->gcoords.p,
+  hipLaunchKernelGGL(kern, dim3(nlk_xcd_grid(g.ngx * g.ngy)), dim3(64), lds, c->rv.stream, img, cur, prev, g, tl,
+                     (const uint32_t*)c->rv.topk, (const NlkTarget*)c->rv.tinfo, (const uint32_t*)c->rv.gcoords,
                      active, basis, basis + PSZ * PSZ, acc);
   HIPCHK(c, hipGetLastError());
   return NLK_OK;

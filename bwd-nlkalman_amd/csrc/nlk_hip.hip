@@ -135,6 +135,12 @@ int nlk_ctx_create(nlk_ctx** out, int device) {
     return fail(nullptr, NLK_EHIP, "cannot create a stream on device %d", device);
   }
   c->stream = c->own_stream;
+  bool ok = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) == hipSuccess;
+  for (hipEvent_t& e : c->sync_ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    nlk_ctx_destroy(c);
+    return fail(nullptr, NLK_EHIP, "cannot create the second stream / events on device %d", device);
+  }
   *out = c;
   return NLK_OK;
 }
@@ -143,6 +149,7 @@ void nlk_ctx_destroy(nlk_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
+  if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
   Buf* bufs[] = {&c->pl_cur, &c->pl_prev, &c->pl_basic, &c->rowok, &c->vmap, &c->topk,
                  &c->tinfo, &c->gcoords, &c->marks, &c->active, &c->acc, &c->tabs, &c->wide, &c->tv, &c->skew, &c->ms};
   for (Buf* b : bufs)
@@ -152,6 +159,9 @@ void nlk_ctx_destroy(nlk_ctx* c) {
     for (int i = 0; i < nlk_ctx::MAXSETS * nlk_ctx::NEV; ++i) (void)hipEventDestroy(c->ev[i]);
     free(c->ev);
   }
+  for (hipEvent_t e : c->sync_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
   (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -281,16 +291,46 @@ int nlk_dev_warp_bicubic(nlk_ctx* c, float* imw, const float* im, const float* o
   return NLK_OK;
 }
 
-// phase 1: layout + block matching; leaves topk / gcoords / tinfo / marks of the strip in the
-// context (c->last = its geometry)
-static int run_match(nlk_ctx* c, const float* cur, const float* prev, const float* basic, int w,
-                     int h, int ch, float sigma, const struct nlkalman_params* P, int oy, int ngy,
-                     int smoother) {
+// ---- frame plan: geometry, planar images, scratch and the launch shapes of one frame or strip call
+struct NlkPlan {
+  NlkGeom g{};                   // the whole call: target rows [0, g.ngy) from image row g.oy
+  const float *img_cur = nullptr, *img_prev = nullptr, *img_basic = nullptr, *img_match = nullptr;
+  NlkTile tl{}, tw{};            // match tiles: dominant window / wide window
+  size_t lds = 0, lds_w = 0;
+  int maxm = 0, maxm_w = 0;
+  bool wide = false;
+};
+
+// records of the target rows from `r0` on (a view into the call's buffers)
+static NlkRecView view_rows(nlk_ctx* c, const NlkGeom& g, hipStream_t stream, int r0, int band) {
+  const size_t t0 = (size_t)r0 * g.ngx;
+  NlkRecView v;
+  v.stream = stream;
+  v.topk = (uint32_t*)c->topk.p + t0 * g.kmax;
+  v.tinfo = (NlkTarget*)c->tinfo.p + t0;
+  v.gcoords = (uint32_t*)c->gcoords.p + t0 * g.gstride;
+  v.marks = (uint64_t*)c->marks.p + t0;
+  v.wide = (uint32_t*)c->wide.p + t0 + band;  // (every band: its own counter in front of its own list)
+  return v;
+}
+
+// the geometry of target rows [r0, r0 + rows) of the plan
+static NlkGeom band_geom(const NlkGeom& g, int r0, int rows) {
+  NlkGeom b = g;
+  b.oy = g.oy + r0 * g.step;
+  b.ngy = rows;
+  return b;
+}
+
+// phase 0: checks, geometry, layout (planar copies + validity map), scratch. Runs on c->stream.
+static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* prev, const float* basic, int w,
+                      int h, int ch, float sigma, const struct nlkalman_params* P, int oy, int ngy,
+                      int smoother, int nbands) {
   int rc = check_images(c, cur, cur, w, h, ch);
   if (rc) return rc;
   if (!P) return fail(c, NLK_EINVAL, "null parameters");
   HIPCHK(c, hipSetDevice(c->device));
-  NlkGeom g{};
+  NlkGeom& g = pl.g;
   g.w = w; g.h = h; g.ch = ch;
   g.psz = P->patch_sz;
   if (g.psz < 2 || g.psz > 16) return fail(c, NLK_EUNSUP, "patch size %d not supported", g.psz);
@@ -332,14 +372,13 @@ static int run_match(nlk_ctx* c, const float* cur, const float* prev, const floa
 
   mark(c, 0);
   // ---- layout: planar copies, validity map
-  const float *img_cur, *img_prev = nullptr, *img_basic = nullptr;
-  if ((rc = to_planar(c, c->pl_cur, cur, npix, ch, &img_cur))) return rc;
-  if (prev && (rc = to_planar(c, c->pl_prev, prev, npix, ch, &img_prev))) return rc;
-  if (basic && (rc = to_planar(c, c->pl_basic, basic, npix, ch, &img_basic))) return rc;
+  if ((rc = to_planar(c, c->pl_cur, cur, npix, ch, &pl.img_cur))) return rc;
+  if (prev && (rc = to_planar(c, c->pl_prev, prev, npix, ch, &pl.img_prev))) return rc;
+  if (basic && (rc = to_planar(c, c->pl_basic, basic, npix, ch, &pl.img_basic))) return rc;
   if (prev) {
     if ((rc = reserve(c, c->rowok, npix)) || (rc = reserve(c, c->vmap, npix))) return rc;
     const dim3 grd((w + 255) / 256, h);
-    hipLaunchKernelGGL(k_nan_rows, grd, dim3(256), 0, c->stream, img_prev, (uint8_t*)c->rowok.p,
+    hipLaunchKernelGGL(k_nan_rows, grd, dim3(256), 0, c->stream, pl.img_prev, (uint8_t*)c->rowok.p,
                        w, h, g.psz);
     hipLaunchKernelGGL(k_nan_cols, grd, dim3(256), 0, c->stream, (const uint8_t*)c->rowok.p,
                        (uint8_t*)c->vmap.p, w, h, g.psz);
@@ -351,17 +390,16 @@ static int run_match(nlk_ctx* c, const float* cur, const float* prev, const floa
       (rc = reserve(c, c->gcoords, sizeof(uint32_t) * (size_t)ngrid * ntagg_alloc)) ||
       (rc = reserve(c, c->marks, sizeof(uint64_t) * (size_t)ngrid)) ||
       (rc = reserve(c, c->active, (size_t)ngrid)) ||
-      (rc = reserve(c, c->wide, sizeof(uint32_t) * ((size_t)ngrid + 1))))  // [0] = queue length
+      (rc = reserve(c, c->wide, sizeof(uint32_t) * ((size_t)ngrid + nbands))))  // per band: queue length + queue
     return rc;
   mark(c, 1);
 
-  // ---- block matching + selection
-  const float* img_match = basic ? img_basic : img_cur;
-  NlkTile tl{};
+  // ---- launch shapes of the block matching
+  pl.img_match = basic ? pl.img_basic : pl.img_cur;
+  NlkTile& tl = pl.tl;
   tl.tgx = getenv("NLK_MTX") ? atoi(getenv("NLK_MTX")) : 8;
   tl.tgy = getenv("NLK_MTY") ? atoi(getenv("NLK_MTY")) : 4;
   tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
-  tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
   // LDS holds the halo of the dominant window; its row stride = window width
   // (mod 32): candidate i of a window then sits on bank i mod 32, so a
   // wavefront's 64 candidate reads are conflict free
@@ -373,96 +411,172 @@ static int run_match(nlk_ctx* c, const float* cur, const float* prev, const floa
   }
   tl.rh_max = (tl.tgy - 1) * g.step + 2 * tl.halo + g.psz;
   tl.ksel_max = g.kmax;
-  const size_t lds = sizeof(float) * ((size_t)ch * tl.rwp * tl.rh_max + 1 +
-                                      (size_t)NLK_BM_WAVES * (3 * tl.ksel_max + ntagg_alloc));
-  if (lds > 160 * 1024)
-    return fail(c, NLK_EUNSUP, "matching tile needs %zu bytes of LDS (> 160 KiB)", lds);
+  pl.lds = sizeof(float) * ((size_t)ch * tl.rwp * tl.rh_max + 1 +
+                            (size_t)NLK_BM_WAVES * (3 * tl.ksel_max + ntagg_alloc));
+  if (pl.lds > 160 * 1024)
+    return fail(c, NLK_EUNSUP, "matching tile needs %zu bytes of LDS (> 160 KiB)", pl.lds);
   // targets of a temporal frame without a valid previous patch search the spatial window
   // (reference: :637); when that one is the wider, they are queued for a second launch
-  const bool wide = g.have_prev && !g.smoother && g.wsz_x > g.wsz_t;
-  if (wide) HIPCHK(c, hipMemsetAsync(c->wide.p, 0, sizeof(uint32_t), c->stream));
+  pl.wide = g.have_prev && !g.smoother && g.wsz_x > g.wsz_t;
   const int wdom = 2 * tl.halo + 1;
-  rc = nlk_launch_match(c, g, tl, lds, img_match, (wdom * wdom + 63) / 64, false);
-  if (rc) return rc;
-  if (wide) {
-    NlkTile tw = tl;
+  pl.maxm = (wdom * wdom + 63) / 64;
+  if (pl.wide) {
+    NlkTile& tw = pl.tw;
+    tw = tl;
     const int need = 2 * g.wsz_x + g.psz, ww = 2 * g.wsz_x + 1;
     tw.halo = g.wsz_x;
     tw.rwp = need + ((ww - need) % 32 + 32) % 32;
     tw.rh_max = need;
     const size_t per_wave = (((size_t)ch * tw.rwp * tw.rh_max + 1) & ~(size_t)1) +
                             ((3 * (size_t)tw.ksel_max + ntagg_alloc + 1) & ~(size_t)1);
-    const size_t lds_w = sizeof(float) * NLK_BM_WAVES * per_wave;
-    if (lds_w > 160 * 1024)
-      return fail(c, NLK_EUNSUP, "spatial window of a temporal frame needs %zu bytes of LDS (> 160 KiB)", lds_w);
-    rc = nlk_launch_match(c, g, tw, lds_w, img_match, (ncand + 63) / 64, true);
-    if (rc) return rc;
+    pl.lds_w = sizeof(float) * NLK_BM_WAVES * per_wave;
+    if (pl.lds_w > 160 * 1024)
+      return fail(c, NLK_EUNSUP, "spatial window of a temporal frame needs %zu bytes of LDS (> 160 KiB)", pl.lds_w);
+    pl.maxm_w = (ncand + 63) / 64;
   }
-  mark(c, 2);
-
-  c->p_match = img_match; c->p_cur = img_cur; c->p_prev = img_prev;
+  c->p_match = pl.img_match; c->p_cur = pl.img_cur; c->p_prev = pl.img_prev;
   c->last = g;
   c->have_last = true;
   return NLK_OK;
 }
 
-// phase 2: replay of the raster-order processed mask over the mark words of a whole patch grid
-static int run_commit(nlk_ctx* c, const uint64_t* marks, uint8_t* active, int ngx, int ngy, int R) {
-  const int ngrid = ngx * ngy;
+// phase 1 for the target rows [r0, r0 + rows) of the plan: block matching + selection on `stream`;
+// leaves topk / gcoords / tinfo / marks of those rows in the context's buffers
+static int match_rows(nlk_ctx* c, const NlkPlan& pl, hipStream_t stream, int r0, int rows, int band) {
+  const NlkGeom gb = band_geom(pl.g, r0, rows);
+  c->rv = view_rows(c, pl.g, stream, r0, band);
+  NlkTile tl = pl.tl;
+  tl.nty = (rows + tl.tgy - 1) / tl.tgy;
+  if (pl.wide) HIPCHK(c, hipMemsetAsync(c->rv.wide, 0, sizeof(uint32_t), stream));
+  int rc = nlk_launch_match(c, gb, tl, pl.lds, pl.img_match, pl.maxm, false);
+  if (rc) return rc;
+  if (pl.wide) {
+    NlkTile tw = pl.tw;
+    tw.nty = tl.nty;
+    rc = nlk_launch_match(c, gb, tw, pl.lds_w, pl.img_match, pl.maxm_w, true);
+  }
+  return rc;
+}
+
+// phase 2: replay of the raster-order processed mask over the mark words of the grid rows
+// [first, first + rows) (`marks` / `active` = whole-grid arrays). Rows before `first` are context:
+// their decisions must be final in `active`.
+static int commit_rows(nlk_ctx* c, hipStream_t stream, const uint64_t* marks, uint8_t* active, int ngx, int first,
+                       int nrows, int R) {
   if (R == 0) {
     // a group cannot reach another grid target: nothing is ever skipped
-    HIPCHK(c, hipMemsetAsync(active, 1, (size_t)ngrid, c->stream));
-  } else if (R <= 3 && !getenv("NLK_COMMIT_LDS")) {
-    // one lane per grid row, up to 1024 rows per launch; taller grids in bands that start with the
-    // previous band's last R rows as context (k_commit.h)
+    HIPCHK(c, hipMemsetAsync(active + (size_t)first * ngx, 1, (size_t)nrows * ngx, stream));
+    return NLK_OK;
+  }
+  if (R <= 3 && !getenv("NLK_COMMIT_LDS")) {
+    // one lane per grid row, up to 1024 rows per launch; more rows in pieces that start with the
+    // previous piece's last R rows as context (k_commit.h)
     int band = getenv("NLK_COMMIT_BAND") ? atoi(getenv("NLK_COMMIT_BAND")) : 1024;
     band = band < 2 * R + 2 ? 2 * R + 2 : (band > 1024 ? 1024 : band);
     auto pre = R == 1 ? k_marks_skew<1> : (R == 2 ? k_marks_skew<2> : k_marks_skew<3>);
     auto kern = R == 1 ? k_mask_commit_wave<1> : (R == 2 ? k_mask_commit_wave<2> : k_mask_commit_wave<3>);
-    for (int first = 0; first < ngy;) {  // `first` = first row this band decides
-      const int ctx = first == 0 ? 0 : R;
-      const int r0 = first - ctx, rows = min(band, ngy - r0);
+    const int end = first + nrows;
+    for (int f = first; f < end;) {  // `f` = first row this piece decides
+      const int ctx = f == 0 ? 0 : R;
+      const int r0 = f - ctx, rows = min(band, end - r0);
       const int threads = ((rows + 63) / 64) * 64;
       const int nsteps = ngx + (R + 1) * (rows - 1);
       const size_t sk_bytes = sizeof(uint32_t) * (size_t)(nsteps + 3 * NLK_CW_PHASE) * threads;
       int rc = reserve(c, c->skew, sk_bytes);
       if (rc) return rc;
-      HIPCHK(c, hipMemsetAsync(c->skew.p, 0, sk_bytes, c->stream));
-      hipLaunchKernelGGL(pre, dim3((rows * ngx + 255) / 256), dim3(256), 0, c->stream, marks + (size_t)r0 * ngx,
+      HIPCHK(c, hipMemsetAsync(c->skew.p, 0, sk_bytes, stream));
+      hipLaunchKernelGGL(pre, dim3((rows * ngx + 255) / 256), dim3(256), 0, stream, marks + (size_t)r0 * ngx,
                          (uint32_t*)c->skew.p, ngx, rows, threads, (const uint8_t*)active + (size_t)r0 * ngx, ctx);
-      hipLaunchKernelGGL(kern, dim3(1), dim3(threads), 0, c->stream, (const uint32_t*)c->skew.p,
+      hipLaunchKernelGGL(kern, dim3(1), dim3(threads), 0, stream, (const uint32_t*)c->skew.p,
                          active + (size_t)r0 * ngx, ngx, rows, ctx);
-      first = r0 + rows;
+      f = r0 + rows;
     }
     HIPCHK(c, hipGetLastError());
-  } else {
-    const int rpt = (ngy + 1023) / 1024;
-    const int threads = min(1024, ((ngy + 63) / 64) * 64);
-    const size_t bits = sizeof(uint32_t) * ((size_t)(ngrid + (R + 1) * ngx + 63) / 32 + 1);
-    if (bits > 160 * 1024 || rpt > 4)
-      return fail(c, NLK_EUNSUP, "patch grid %dx%d too large for the mask replay", ngx, ngy);
-    auto kern = rpt == 1 ? k_mask_commit<1> : (rpt == 2 ? k_mask_commit<2> : k_mask_commit<4>);
-    HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)bits));
-    hipLaunchKernelGGL(kern, dim3(1), dim3(threads), bits, c->stream, marks, active, ngx, ngy, R);
-    HIPCHK(c, hipGetLastError());
+    return NLK_OK;
   }
+  if (first != 0) return fail(c, NLK_EINVAL, "the LDS mask replay takes whole grids only");
+  const int ngy = nrows, ngrid = ngx * ngy;
+  const int rpt = (ngy + 1023) / 1024;
+  const int threads = min(1024, ((ngy + 63) / 64) * 64);
+  const size_t bits = sizeof(uint32_t) * ((size_t)(ngrid + (R + 1) * ngx + 63) / 32 + 1);
+  if (bits > 160 * 1024 || rpt > 4)
+    return fail(c, NLK_EUNSUP, "patch grid %dx%d too large for the mask replay", ngx, ngy);
+  auto kern = rpt == 1 ? k_mask_commit<1> : (rpt == 2 ? k_mask_commit<2> : k_mask_commit<4>);
+  HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bits));
+  hipLaunchKernelGGL(kern, dim3(1), dim3(threads), bits, stream, marks, active, ngx, ngy, R);
+  HIPCHK(c, hipGetLastError());
   return NLK_OK;
+}
+
+// phase 3 for the target rows [r0, r0 + rows) of the last plan (c->last)
+static int group_rows(nlk_ctx* c, hipStream_t stream, float* acc, const uint8_t* active_rows, int r0, int rows,
+                      int band) {
+  const NlkGeom gb = band_geom(c->last, r0, rows);
+  c->rv = view_rows(c, c->last, stream, r0, band);
+  return launch_group(c, gb, c->p_match, c->p_cur, c->p_prev, acc, active_rows);
+}
+
+// Bands of a whole-frame call (NLK_BANDS=<n>, default 1 = off). The mask replay runs on ONE compute
+// unit (it is a chain of dependent steps) for ~7 % of a 1080p frame's time. With the grid rows cut in
+// bands on two streams, band b+1 is matched while band b's mask is replayed and band b is filtered
+// while band b+1's is. Measured at C2 (profiles/README.md): 1.59 ms with one band, 1.64 with two,
+// 1.77 with four - the two bands' match kernels share the chip instead of finishing one after the
+// other, and the four cross-stream dependencies and the doubled launches cost what the hidden replay
+// gains. Kept as an option (and as the exactness test of banding); profiling always runs one band.
+static int frame_bands(const nlk_ctx* c, const NlkGeom& g) {
+  if (c->profiling || g.R == 0) return 1;
+  const char* e = getenv("NLK_BANDS");
+  int nb = e ? atoi(e) : 1;
+  nb = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
+  while (nb > 1 && g.ngy / nb < 4 * (g.R + 1) + 8) --nb;  // (thin bands: nothing to gain)
+  return nb;
 }
 
 int nlk_dev_frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const float* prev,
                              const float* basic, int w, int h, int ch, float sigma,
                              const struct nlkalman_params* P, int oy, int ngy, int smoother) {
   if (!acc) return fail(c, NLK_EINVAL, "null accumulator");
-  int rc = run_match(c, cur, prev, basic, w, h, ch, sigma, P, oy, ngy, smoother);
+  NlkPlan pl;
+  int rc = plan_frame(c, pl, cur, prev, basic, w, h, ch, sigma, P, oy, ngy, smoother, 8);
   if (rc) return rc;
-  const NlkGeom& g = c->last;
-  if ((rc = run_commit(c, (const uint64_t*)c->marks.p, (uint8_t*)c->active.p, g.ngx, g.ngy, g.R)))
-    return rc;
-  mark(c, 3);
-  if ((rc = launch_group(c, g, c->p_match, c->p_cur, c->p_prev, acc, (const uint8_t*)c->active.p)))
-    return rc;
-  mark(c, 4);
+  const NlkGeom& g = pl.g;
+  const int nb = frame_bands(c, g);
+  uint8_t* active = (uint8_t*)c->active.p;
+  if (nb == 1) {
+    if ((rc = match_rows(c, pl, c->stream, 0, g.ngy, 0))) return rc;
+    mark(c, 2);
+    if ((rc = commit_rows(c, c->stream, (const uint64_t*)c->marks.p, active, g.ngx, 0, g.ngy, g.R))) return rc;
+    mark(c, 3);
+    if ((rc = group_rows(c, c->stream, acc, active, 0, g.ngy, 0))) return rc;
+    mark(c, 4);
+    return NLK_OK;
+  }
+  // ---- banded on two streams. Band b runs on stream b & 1; its mask replay waits for band b-1's.
+  // (the replay's scratch is sized for the largest piece now: growing it between two bands would
+  // synchronise the device)
+  {
+    const int rows = min(1024, (g.ngy + nb - 1) / nb + g.R + 1), threads = ((rows + 63) / 64) * 64;
+    const size_t need = sizeof(uint32_t) * (size_t)(g.ngx + (g.R + 1) * (rows - 1) + 3 * NLK_CW_PHASE) * threads;
+    if ((rc = reserve(c, c->skew, need))) return rc;
+  }
+  hipStream_t st[2] = {c->stream, c->aux_stream};
+  hipEvent_t* ev = c->sync_ev;  // [0] layout done, [1] / [2] replay of the last even / odd band done, [3] aux stream done
+  HIPCHK(c, hipEventRecord(ev[0], st[0]));
+  HIPCHK(c, hipStreamWaitEvent(st[1], ev[0], 0));
+  int r0[9];
+  for (int b = 0; b <= nb; ++b) r0[b] = (int)((long)g.ngy * b / nb);
+  for (int b = 0; b < nb; ++b)
+    if ((rc = match_rows(c, pl, st[b & 1], r0[b], r0[b + 1] - r0[b], b))) return rc;
+  for (int b = 0; b < nb; ++b) {
+    hipStream_t s = st[b & 1];
+    if (b > 0) HIPCHK(c, hipStreamWaitEvent(s, ev[1 + ((b - 1) & 1)], 0));
+    if ((rc = commit_rows(c, s, (const uint64_t*)c->marks.p, active, g.ngx, r0[b], r0[b + 1] - r0[b], g.R))) return rc;
+    HIPCHK(c, hipEventRecord(ev[1 + (b & 1)], s));
+    if ((rc = group_rows(c, s, acc, active + (size_t)r0[b] * g.ngx, r0[b], r0[b + 1] - r0[b], b))) return rc;
+  }
+  HIPCHK(c, hipEventRecord(ev[3], st[1]));
+  HIPCHK(c, hipStreamWaitEvent(st[0], ev[3], 0));
   return NLK_OK;
 }
 
@@ -470,8 +584,11 @@ int nlk_dev_frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const flo
 int nlk_dev_strip_match(nlk_ctx* c, const float* cur, const float* prev, const float* basic, int w,
                         int h, int ch, float sigma, const struct nlkalman_params* P, int oy,
                         int ngy, int smoother, void* marks_out, int* reach) {
-  int rc = run_match(c, cur, prev, basic, w, h, ch, sigma, P, oy, ngy, smoother);
+  NlkPlan pl;
+  int rc = plan_frame(c, pl, cur, prev, basic, w, h, ch, sigma, P, oy, ngy, smoother, 1);
   if (rc) return rc;
+  if ((rc = match_rows(c, pl, c->stream, 0, pl.g.ngy, 0))) return rc;
+  mark(c, 2);
   if (reach) *reach = c->last.R;
   if (marks_out)
     HIPCHK(c, hipMemcpyAsync(marks_out, c->marks.p, sizeof(uint64_t) * (size_t)c->last.ngx * c->last.ngy,
@@ -484,7 +601,7 @@ int nlk_dev_mask_commit(nlk_ctx* c, const void* marks, int ngx, int ngy, int rea
   if (!c || !marks || !active || ngx < 1 || ngy < 1 || reach < 0)
     return fail(c, NLK_EINVAL, "bad mask-commit arguments");
   HIPCHK(c, hipSetDevice(c->device));
-  int rc = run_commit(c, (const uint64_t*)marks, active, ngx, ngy, reach);
+  int rc = commit_rows(c, c->stream, (const uint64_t*)marks, active, ngx, 0, ngy, reach);
   mark(c, 3);
   return rc;
 }
@@ -492,7 +609,7 @@ int nlk_dev_mask_commit(nlk_ctx* c, const void* marks, int ngx, int ngy, int rea
 int nlk_dev_strip_group(nlk_ctx* c, float* acc, const unsigned char* active) {
   if (!c || !c->have_last) return fail(c, NLK_EINVAL, "nlk_dev_strip_match has not run");
   if (!acc || !active) return fail(c, NLK_EINVAL, "null accumulator / active flags");
-  int rc = launch_group(c, c->last, c->p_match, c->p_cur, c->p_prev, acc, active);
+  int rc = group_rows(c, c->stream, acc, active, 0, c->last.ngy, 0);
   mark(c, 4);
   return rc;
 }

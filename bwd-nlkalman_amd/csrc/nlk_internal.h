@@ -21,10 +21,24 @@ struct NlkBuf {
   size_t cap = 0;
 };
 
+// what a launcher works on: the stream and the per-target records of the patch-grid rows it is
+// given (the whole grid, a strip, or one band of a frame processed in bands on two streams)
+struct NlkRecView {
+  hipStream_t stream = nullptr;
+  uint32_t* topk = nullptr;      // [targets][kmax]
+  NlkTarget* tinfo = nullptr;    // [targets]
+  uint32_t* gcoords = nullptr;   // [targets][gstride]
+  uint64_t* marks = nullptr;     // [targets]
+  uint32_t* wide = nullptr;      // [0] = queue length, then the queued targets (k_bm_wide)
+};
+
 struct nlk_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  hipStream_t aux_stream = nullptr;  // second stream of the banded frame pipeline (run_frame)
+  hipEvent_t sync_ev[8] = {};        // cross-stream dependencies of that pipeline (no timing)
+  NlkRecView rv;                     // set by the orchestration before every launcher call
   char err[512] = "";
   NlkBuf pl_cur, pl_prev, pl_basic, rowok, vmap, topk, tinfo, gcoords, marks, active, acc, tabs, wide;
   NlkBuf skew;                    // mark words in replay-step order (k_marks_skew)

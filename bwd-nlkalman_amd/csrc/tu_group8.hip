@@ -65,9 +65,9 @@ int launch_group_fast_t(nlk_ctx* c, const NlkGeom& g, const float* img, const fl
   HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
   const float* basis = (const float*)c->tabs.p;
-  hipLaunchKernelGGL(kern, dim3(nlk_xcd_grid(tl.ntx * tl.nty)), dim3(64), lds, c->stream, img, cur, prev,
-                     (const uint8_t*)c->vmap.p, g, tl, (const uint32_t*)c->topk.p,
-                     (const NlkTarget*)c->tinfo.p, (const uint32_t*)c->gcoords.p,
+  hipLaunchKernelGGL(kern, dim3(nlk_xcd_grid(tl.ntx * tl.nty)), dim3(64), lds, c->rv.stream, img, cur, prev,
+                     (const uint8_t*)c->vmap.p, g, tl, (const uint32_t*)c->rv.topk,
+                     (const NlkTarget*)c->rv.tinfo, (const uint32_t*)c->rv.gcoords,
                      active, basis, basis + PSZ * PSZ, acc);
   HIPCHK(c, hipGetLastError());
   return NLK_OK;

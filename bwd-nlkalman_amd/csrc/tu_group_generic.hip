@@ -11,14 +11,14 @@ int launch_group_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float* 
   const float* basis = (const float*)c->tabs.p;
   const float* window = basis + PSZ * PSZ;
   if (g.smoother)
-    hipLaunchKernelGGL((k_group<PSZ, CH, true>), dim3(ngrid), dim3(64), 0, c->stream, img,
-                       cur, prev, (const uint8_t*)c->vmap.p, g, (const uint32_t*)c->topk.p,
-                       (const NlkTarget*)c->tinfo.p, (const uint32_t*)c->gcoords.p,
+    hipLaunchKernelGGL((k_group<PSZ, CH, true>), dim3(ngrid), dim3(64), 0, c->rv.stream, img,
+                       cur, prev, (const uint8_t*)c->vmap.p, g, (const uint32_t*)c->rv.topk,
+                       (const NlkTarget*)c->rv.tinfo, (const uint32_t*)c->rv.gcoords,
                        active, basis, window, acc);
   else
-    hipLaunchKernelGGL((k_group<PSZ, CH, false>), dim3(ngrid), dim3(64), 0, c->stream, img,
-                       cur, prev, (const uint8_t*)c->vmap.p, g, (const uint32_t*)c->topk.p,
-                       (const NlkTarget*)c->tinfo.p, (const uint32_t*)c->gcoords.p,
+    hipLaunchKernelGGL((k_group<PSZ, CH, false>), dim3(ngrid), dim3(64), 0, c->rv.stream, img,
+                       cur, prev, (const uint8_t*)c->vmap.p, g, (const uint32_t*)c->rv.topk,
+                       (const NlkTarget*)c->rv.tinfo, (const uint32_t*)c->rv.gcoords,
                        active, basis, window, acc);
   HIPCHK(c, hipGetLastError());
   return NLK_OK;
