@@ -29,7 +29,7 @@ HIP_SYMBOLS = [
     "nlk_dev_frame_accumulate", "nlk_dev_frame_normalize", "nlk_ctx_read_records",
     "nlk_dev_strip_match", "nlk_dev_mask_commit", "nlk_dev_strip_group",
     "nlk_tvl1_default_params", "nlk_tvl1_scales", "nlk_dev_tvl1_flow", "nlk_dev_gray",
-    "nlk_dev_occlusion_mask", "nlk_dev_image_dct", "nlk_dev_copy_block", "nlk_host_tables",
+    "nlk_dev_occlusion_mask", "nlk_dev_image_dct", "nlk_dev_copy_block", "nlk_host_tables", "nlk_ctx_set_deterministic",
 ]
 API_SYMBOLS = [
     "rgb2opp", "opp2rgb", "warp_bicubic", "nlkalman_default_params",
@@ -129,6 +129,7 @@ def hip():
         L.nlk_dev_image_dct.argtypes = [vp, fp, i, i, i, i]
         L.nlk_dev_copy_block.argtypes = [vp, fp, i, fp, i, i, i, i]
         L.nlk_host_tables.argtypes = [i, vp, vp, vp]
+        L.nlk_ctx_set_deterministic.argtypes = [vp, i]
         _hip = L
     return _hip
 
@@ -273,6 +274,10 @@ class Context:
 
     def set_stream(self, hip_stream):
         self._chk(self.L.nlk_ctx_set_stream(self.h, hip_stream))
+
+    def set_deterministic(self, on):
+        """Bit-reproducible aggregation (slabs + ordered gather instead of float atomics)."""
+        self._chk(self.L.nlk_ctx_set_deterministic(self.h, int(on)))
 
     def set_profiling(self, on):
         self._chk(self.L.nlk_ctx_set_profiling(self.h, int(on)))

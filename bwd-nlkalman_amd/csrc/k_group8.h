@@ -44,8 +44,22 @@ struct NlkGTile {
   int tgx, tgy, ntx, nty;
   int rwp, rh_max;  // LDS accumulator region: row stride / rows
   int wmax;         // halo of the LDS tile around its targets (groups reaching further spill to HBM atomics)
-  int plane;        // k_group8m: floats per accumulator plane (padded, see there)
+  int plane;        // k_group8m / k_groupp: floats per accumulator plane (padded, see there)
+  // deterministic aggregation (k_gather.h): where workgroup `tile` writes its planes instead of adding
+  // them to the frame accumulator with atomics, and the flag that says it did
+  float* slab;      // [tiles][planes][plane]
+  uint8_t* tflag;   // [tiles]
+  // A temporal frame has two kinds of groups: those searched with the temporal radius and the few
+  // spatial-branch ones (no valid previous patch) that reach wsz_x. Deterministic mode runs them in
+  // two launches with a tile halo each (far = 0: the former only, far = 1: the latter only), so that
+  // no member ever leaves its tile.
+  int split, far;   // split != 0: this launch takes only the targets of kind `far`
 };
+
+// does this target's group reach beyond the temporal radius? (np0 = its candidates with a valid previous patch)
+__device__ __forceinline__ bool nlk_far_target(const NlkGeom& g, int np0) {
+  return g.have_prev && !g.smoother && np0 == 0;
+}
 
 typedef float nlk_f4u __attribute__((ext_vector_type(4), aligned(4)));
 

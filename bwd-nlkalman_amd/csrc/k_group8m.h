@@ -108,6 +108,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   const int ry1 = min(g.oy + (gy0 + cy - 1) * step + tl.wmax + PSZ, g.h);
   const int rw = rx1 - rx0, rh = ry1 - ry0;
   const int rwp = tl.rwp, plane = tl.plane;
+  bool any_target = false;  // (deterministic mode: a tile without work writes no slab)
   for (int i = lane; i < (CH + 1) * plane / 4; i += 64)  // (plane is a multiple of 16)
     reinterpret_cast<nlk_f4*>(smem)[i] = nlk_f4{0.f, 0.f, 0.f, 0.f};
   // [CH+2][2][4][16]: gains / means between the passes. Pass B treats the weight plane as one more
@@ -164,6 +165,11 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     if (!__builtin_amdgcn_readlane(rec_act, tt)) continue;
     const int nagg = __builtin_amdgcn_readlane(rec_nagg, tt);
     if (nagg == 0) continue;
+    if (tl.split) {  // (deterministic mode: near and far groups in separate launches)
+      const uint32_t anyv = (uint32_t)__builtin_amdgcn_readlane((int)(rec_vb[0] | rec_vb[1] | rec_vb[2] | rec_vb[3]), tt);
+      if (nlk_far_target(g, anyv ? 1 : 0) != (tl.far != 0)) continue;
+    }
+    any_target = true;
     const int ty = tt / cx, tx = tt - ty * cx;
     const size_t t = (size_t)(gy0 + ty) * g.ngx + gx0 + tx;
     const int k = __builtin_amdgcn_readlane(rec_nsel, tt);
@@ -471,9 +477,17 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     }
   }
 
-  // ---------------- flush the tile accumulator (coalesced rows, skip untouched)
+  // ---------------- flush the tile accumulator
   __syncthreads();
-  {
+  if (tl.slab) {
+    // deterministic mode (k_gather.h): the planes as they stand, into this tile's slab
+    if (lane == 0) tl.tflag[tile_id] = any_target;
+    if (any_target) {
+      nlk_f4* dst = reinterpret_cast<nlk_f4*>(tl.slab + (size_t)tile_id * (CH + 1) * plane);
+      for (int i = lane; i < (CH + 1) * plane / 4; i += 64) dst[i] = reinterpret_cast<const nlk_f4*>(smem)[i];
+    }
+  } else {
+    // coalesced rows, untouched entries skipped
     // a narrow tile (<= 32 columns) puts two rows on the 64 lanes
     const bool two = rw <= 32;
     const int fx = two ? (lane & 31) : lane, fy = two ? (lane >> 5) : 0;

@@ -179,10 +179,13 @@ k_groupp(const float* __restrict__ img,   // matching / statistics image (planar
   const int ngrid = g.ngx * g.ngy;
   const int ti = nlk_xcd_tile(blockIdx.x, ngrid);  // one target per workgroup
   if (ti >= ngrid) return;
-  if (!active[ti]) return;
   const NlkTarget info = tinfo[ti];
   const int nagg = info.nagg, k = info.nsel;
-  if (nagg == 0) return;
+  bool work = active[ti] && nagg != 0;
+  // (deterministic mode: near and far groups in separate launches)
+  if (tl.split && nlk_far_target(g, (info.vbits[0] | info.vbits[1]) ? 1 : 0) != (tl.far != 0)) work = false;
+  if (tl.slab && lane == 0) tl.tflag[ti] = work;  // (deterministic mode, k_gather.h)
+  if (!work) return;
   const size_t t = (size_t)ti;
   const int gy = ti / g.ngx, gx = ti - gy * g.ngx;
   const int rx0 = max(gx * step - tl.wmax, 0);
@@ -499,6 +502,15 @@ k_groupp(const float* __restrict__ img,   // matching / statistics image (planar
   const int fx = two_rows ? (lane & 31) : lane, fy = two_rows ? (lane >> 5) : 0;
   const int sx = two_rows ? 32 : 64, sy = two_rows ? 2 : 1;
   auto flush = [&](float* sp, int p, bool clear) {
+    if (tl.slab) {  // deterministic mode: the plane as it stands, into this target's slab
+      nlk_f4* dst = reinterpret_cast<nlk_f4*>(tl.slab + ((size_t)ti * (CH + 1) + p) * plane);
+      for (int i = lane; i < plane / 4; i += 64) {
+        dst[i] = reinterpret_cast<const nlk_f4*>(sp)[i];
+        if (clear) reinterpret_cast<nlk_f4*>(sp)[i] = nlk_f4{0.f, 0.f, 0.f, 0.f};
+      }
+      NLK_PP_SYNC();
+      return;
+    }
     float* dp = acc + (size_t)p * npix + (size_t)ry0 * g.w + rx0;
 #pragma unroll 4
     for (int y = fy; y < rh; y += sy)

@@ -135,6 +135,7 @@ int nlk_ctx_create(nlk_ctx** out, int device) {
     return fail(nullptr, NLK_EHIP, "cannot create a stream on device %d", device);
   }
   c->stream = c->own_stream;
+  c->deterministic = getenv("NLK_DETERMINISTIC") && atoi(getenv("NLK_DETERMINISTIC")) != 0;
   bool ok = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) == hipSuccess;
   for (hipEvent_t& e : c->sync_ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
@@ -151,7 +152,8 @@ void nlk_ctx_destroy(nlk_ctx* c) {
   hipStreamSynchronize(c->stream);
   if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
   Buf* bufs[] = {&c->pl_cur, &c->pl_prev, &c->pl_basic, &c->rowok, &c->vmap, &c->topk,
-                 &c->tinfo, &c->gcoords, &c->marks, &c->active, &c->acc, &c->tabs, &c->wide, &c->tv, &c->skew, &c->ms};
+                 &c->tinfo, &c->gcoords, &c->marks, &c->active, &c->acc, &c->tabs, &c->wide, &c->tv, &c->skew, &c->ms,
+                 &c->slab, &c->tflag};
   for (Buf* b : bufs)
     if (b->p) hipFree(b->p);
   if (c->tv_host) (void)hipHostFree(c->tv_host);
@@ -200,6 +202,12 @@ int nlk_ctx_get_timings(nlk_ctx* c, struct nlk_timings* t) {
                    &t->total_ms};
   for (int i = 0; i < 6; ++i) *dst[i] = (float)(acc[i] / c->nsets);
   c->tm = *t;
+  return NLK_OK;
+}
+
+int nlk_ctx_set_deterministic(nlk_ctx* c, int on) {
+  if (!c) return NLK_EINVAL;
+  c->deterministic = on != 0;
   return NLK_OK;
 }
 
@@ -525,7 +533,7 @@ static int group_rows(nlk_ctx* c, hipStream_t stream, float* acc, const uint8_t*
 // other, and the four cross-stream dependencies and the doubled launches cost what the hidden replay
 // gains. Kept as an option (and as the exactness test of banding); profiling always runs one band.
 static int frame_bands(const nlk_ctx* c, const NlkGeom& g) {
-  if (c->profiling || g.R == 0) return 1;
+  if (c->profiling || c->deterministic || g.R == 0) return 1;  // (deterministic mode: one slab set, one sum order)
   const char* e = getenv("NLK_BANDS");
   int nb = e ? atoi(e) : 1;
   nb = nb < 1 ? 1 : (nb > 8 ? 8 : nb);

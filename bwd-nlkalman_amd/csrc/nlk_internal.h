@@ -44,6 +44,8 @@ struct nlk_ctx {
   NlkBuf skew;                    // mark words in replay-step order (k_marks_skew)
   NlkBuf ms;                      // whole-image DCT: temporary image + the two basis matrices
   NlkBuf tv;                      // TV-L1 pyramids and work images
+  NlkBuf slab, tflag;             // deterministic aggregation: per-tile accumulator slabs + "written" flags (k_gather.h)
+  bool deterministic = false;     // nlk_ctx_set_deterministic / NLK_DETERMINISTIC=1
   NlkTvMail* tv_host = nullptr;   // pinned: the solver state, posted by the kernels (k_tvl1.h)
   unsigned tv_seq = 0;
   int tabs_psz = 0;

@@ -1,87 +1,101 @@
 // tu_group8.hip — launcher of the 8x8 group kernels: k_group8m (matrix cores, default) and
 // k_group8 (registers + DPP, NLK_GROUP_DPP=1)
+#include "k_gather.h"
 #include "k_group8.h"
 #include "k_group8m.h"
 #include "nlk_internal.h"
 
 namespace {
 
-template <int PSZ, int CH, bool SMO>
-int launch_group_fast_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
-                        const float* prev, float* acc, const uint8_t* active) {
-  NlkGTile tl{};
-  // LDS tile halo = reach of the dominant kind of group; the rare spatial-branch
-  // groups of a temporal frame that reach further fall back to HBM atomics
-  tl.wmax = (g.smoother || g.have_prev) ? g.wsz_t : g.wsz_x;
-  // 4 x 1 targets per wavefront measured best for the temporal radius (profiles/README.md);
-  // with a wide halo the tile would leave LDS room for ~1 wavefront per SIMD: 2 x 1 then, and for
-  // the 12x12 kernel (8.0 ms against 8.8 with 4 x 1 at C3).
-  // NLK_GTX/NLK_GTY override for experiments
-  tl.tgx = getenv("NLK_GTX") ? atoi(getenv("NLK_GTX")) : ((PSZ == 8 && tl.wmax > 6) || PSZ == 12 ? 2 : 4);
-  tl.tgy = getenv("NLK_GTY") ? atoi(getenv("NLK_GTY")) : 1;
-  tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
-  tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
+template <int CH, bool SMO>
+int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
+                    const float* prev, float* acc, const uint8_t* active) {
+  constexpr int PSZ = 8;
   // psz 8 runs its DCTs on the matrix cores (k_group8m.h); NLK_GROUP_DPP selects the
-  // register/DPP kernel (k_group8.h) for comparison. psz 12 runs the packed-lane kernel
-  // (k_group12p.h); NLK_GROUP12_ROWS selects the lane = (channel, row) kernel (k_group12.h)
-  const bool mfma = PSZ == 8 && !getenv("NLK_GROUP_DPP");
-  const bool packed = false;
-  const int rw_max = (tl.tgx - 1) * g.step + 2 * tl.wmax + g.psz;
-  tl.rh_max = (tl.tgy - 1) * g.step + 2 * tl.wmax + g.psz;
-  if (mfma) {
-    // one aggregation access = 4x4 pixels of each plane: row stride = 4 and plane
-    // stride = 16 (mod 32 banks) make the 64 lanes hit every bank twice
-    tl.rwp = rw_max + ((4 - rw_max) % 32 + 32) % 32;
-    tl.plane = tl.rwp * tl.rh_max;
-    tl.plane += ((16 - tl.plane) % 32 + 32) % 32;
-  } else if (packed) {
-    // one aggregation access = 12 rows x 4 blocks of 3 pixels (lane = 12 * block + row): the row
-    // stride with the fewest bank collisions among those 48 addresses (two halves of 32 lanes)
-    int best = 1 << 30;
-    tl.rwp = rw_max;
-    for (int r = rw_max; r < rw_max + 32; ++r) {
-      int cost = 0;
-      for (int half = 0; half < 2; ++half) {
-        int cnt[32] = {0}, mx = 0;
-        for (int l = 32 * half; l < 32 * half + 32 && l < 48; ++l) mx = max(mx, ++cnt[((l % 12) * r + 3 * (l / 12)) & 31]);
-        cost += mx;
-      }
-      cost = cost * 64 + (r - rw_max);  // (ties: the narrowest)
-      if (cost < best) { best = cost; tl.rwp = r; }
+  // register/DPP kernel (k_group8.h) for comparison
+  const bool mfma = !getenv("NLK_GROUP_DPP");
+  if (c->deterministic && !mfma)
+    return fail(c, NLK_EUNSUP, "deterministic aggregation is not available in the NLK_GROUP_DPP variant");
+  // Deterministic mode runs a temporal frame's far-reaching (spatial-branch) groups in a second
+  // launch whose tiles have the spatial halo, so that no member ever leaves its tile (k_group8.h)
+  const bool split = c->deterministic && g.have_prev && !g.smoother && g.wsz_x > g.wsz_t;
+  size_t slab_off = 0, flag_off = 0;  // (the second pass's slabs follow the first's)
+  for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
+    NlkGTile tl{};
+    tl.split = split;
+    tl.far = pass;
+    // LDS tile halo = reach of the dominant kind of group; without the split the rare spatial-branch
+    // groups of a temporal frame that reach further fall back to HBM atomics
+    tl.wmax = (g.smoother || g.have_prev) ? g.wsz_t : g.wsz_x;
+    if (pass == 1) tl.wmax = g.wsz_x;
+    // 4 x 1 targets per wavefront measured best for the temporal radius (profiles/README.md);
+    // with a wide halo the tile would leave LDS room for ~1 wavefront per SIMD: 2 x 1 then.
+    // NLK_GTX/NLK_GTY override for experiments
+    tl.tgx = getenv("NLK_GTX") ? atoi(getenv("NLK_GTX")) : (tl.wmax > 6 ? 2 : 4);
+    tl.tgy = getenv("NLK_GTY") ? atoi(getenv("NLK_GTY")) : 1;
+    tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
+    tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
+    const int rw_max = (tl.tgx - 1) * g.step + 2 * tl.wmax + g.psz;
+    tl.rh_max = (tl.tgy - 1) * g.step + 2 * tl.wmax + g.psz;
+    if (mfma) {
+      // one aggregation access = 4x4 pixels of each plane: row stride = 4 and plane
+      // stride = 16 (mod 32 banks) make the 64 lanes hit every bank twice
+      tl.rwp = rw_max + ((4 - rw_max) % 32 + 32) % 32;
+      tl.plane = tl.rwp * tl.rh_max;
+      tl.plane += ((16 - tl.plane) % 32 + 32) % 32;
+    } else {
+      tl.rwp = rw_max | 1;
+      tl.plane = tl.rwp * tl.rh_max;
     }
-    tl.plane = (tl.rwp * tl.rh_max + 3) & ~3;
-  } else {
-    tl.rwp = rw_max | 1;
-    tl.plane = tl.rwp * tl.rh_max;
+    const size_t lds = sizeof(float) * ((size_t)(CH + 1) * tl.plane + (mfma ? (CH + 2) * 128 : 0));
+    if (lds > 160 * 1024) return fail(c, NLK_EUNSUP, "aggregation tile needs %zu bytes of LDS", lds);
+    const size_t ntiles = (size_t)tl.ntx * tl.nty;
+    if (c->deterministic) {
+      // (both passes' slabs are sized before the first launch: growing the buffer frees it)
+      if (pass == 0) {
+        size_t need = ntiles * (CH + 1) * tl.plane, nflag = ntiles;
+        if (split) {
+          const int tgx2 = getenv("NLK_GTX") ? atoi(getenv("NLK_GTX")) : (g.wsz_x > 6 ? 2 : 4);
+          const int rw2 = (tgx2 - 1) * g.step + 2 * g.wsz_x + g.psz, rh2 = (tl.tgy - 1) * g.step + 2 * g.wsz_x + g.psz;
+          const size_t nt2 = (size_t)((g.ngx + tgx2 - 1) / tgx2) * tl.nty;
+          need += nt2 * (CH + 1) * ((size_t)(rw2 + 32) * rh2 + 32);
+          nflag += nt2;
+        }
+        int rc;
+        if ((rc = reserve(c, c->slab, sizeof(float) * need)) || (rc = reserve(c, c->tflag, nflag))) return rc;
+      }
+      tl.slab = (float*)c->slab.p + slab_off;
+      tl.tflag = (uint8_t*)c->tflag.p + flag_off;
+      slab_off += ntiles * (CH + 1) * tl.plane;
+      flag_off += ntiles;
+    }
+    void (*kern)(const float*, const float*, const float*, const uint8_t*, NlkGeom, NlkGTile,
+                 const uint32_t*, const NlkTarget*, const uint32_t*, const uint8_t*, const float*,
+                 const float*, float*);
+    kern = mfma ? k_group8m<CH, SMO> : k_group8<CH, SMO>;
+    HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+    const float* basis = (const float*)c->tabs.p;
+    hipLaunchKernelGGL(kern, dim3(nlk_xcd_grid(tl.ntx * tl.nty)), dim3(64), lds, c->rv.stream, img, cur, prev,
+                       (const uint8_t*)c->vmap.p, g, tl, (const uint32_t*)c->rv.topk,
+                       (const NlkTarget*)c->rv.tinfo, (const uint32_t*)c->rv.gcoords,
+                       active, basis, basis + PSZ * PSZ, acc);
+    if (c->deterministic)
+      hipLaunchKernelGGL(k_gather_tiles, dim3((g.w + 255) / 256, g.h), dim3(256), 0, c->rv.stream, acc,
+                         (const float*)tl.slab, (const uint8_t*)tl.tflag, g, tl, CH + 1);
+    HIPCHK(c, hipGetLastError());
   }
-  // (+ the 12x12 kernels' transposition scratch: k_group12.h, k_group12p.h)
-  const size_t lds = sizeof(float) * ((size_t)(CH + 1) * tl.plane + (mfma ? (CH + 2) * 128 : 0) +
-                                     0);
-  if (lds > 160 * 1024) return fail(c, NLK_EUNSUP, "aggregation tile needs %zu bytes of LDS", lds);
-  void (*kern)(const float*, const float*, const float*, const uint8_t*, NlkGeom, NlkGTile,
-               const uint32_t*, const NlkTarget*, const uint32_t*, const uint8_t*, const float*,
-               const float*, float*);
-  kern = mfma ? k_group8m<CH, SMO> : k_group8<CH, SMO>;
-  HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
-  const float* basis = (const float*)c->tabs.p;
-  hipLaunchKernelGGL(kern, dim3(nlk_xcd_grid(tl.ntx * tl.nty)), dim3(64), lds, c->rv.stream, img, cur, prev,
-                     (const uint8_t*)c->vmap.p, g, tl, (const uint32_t*)c->rv.topk,
-                     (const NlkTarget*)c->rv.tinfo, (const uint32_t*)c->rv.gcoords,
-                     active, basis, basis + PSZ * PSZ, acc);
-  HIPCHK(c, hipGetLastError());
   return NLK_OK;
 }
-
 
 }  // namespace
 
 int nlk_launch_group8(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur, const float* prev,
                       float* acc, const uint8_t* active) {
-#define NLK_FAST(C)                                                                       \
-  if (g.ch == C)                                                                          \
-    return g.smoother ? launch_group_fast_t<8, C, true>(c, g, img, cur, prev, acc, active) \
-                      : launch_group_fast_t<8, C, false>(c, g, img, cur, prev, acc, active);
+#define NLK_FAST(C)                                                                  \
+  if (g.ch == C)                                                                     \
+    return g.smoother ? launch_group8_t<C, true>(c, g, img, cur, prev, acc, active)  \
+                      : launch_group8_t<C, false>(c, g, img, cur, prev, acc, active);
   NLK_FAST(1) NLK_FAST(3)
 #undef NLK_FAST
   return fail(c, NLK_EUNSUP, "%d channels not supported (1 or 3)", g.ch);

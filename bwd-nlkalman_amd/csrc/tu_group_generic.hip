@@ -43,6 +43,9 @@ int launch_group_ch(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
 
 int nlk_launch_group_generic(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
                              const float* prev, float* acc, const uint8_t* active) {
+  if (c->deterministic)
+    return fail(c, NLK_EUNSUP, "deterministic aggregation is not available in the LDS-DCT kernel (candidate lists of "
+                               "more than 128 entries / NLK_GENERIC_GROUP)");
   if (g.ch == 1) return launch_group_ch<1>(c, g, img, cur, prev, acc, active);
   if (g.ch == 3) return launch_group_ch<3>(c, g, img, cur, prev, acc, active);
   return fail(c, NLK_EUNSUP, "%d channels not supported (1 or 3)", g.ch);

@@ -68,6 +68,12 @@ const char *nlk_last_error(const nlk_ctx *ctx); /* ctx may be NULL: last global 
 int nlk_ctx_set_profiling(nlk_ctx *ctx, int on);
 /* mean over the frame calls made since nlk_ctx_set_profiling(ctx, 1); synchronises */
 int nlk_ctx_get_timings(nlk_ctx *ctx, struct nlk_timings *t);
+/* Deterministic aggregation: two calls on the same inputs give bit-identical outputs. By default the
+ * group kernels add their accumulator tiles to the frame with global float atomics, whose order
+ * varies from run to run (as the reference's `omp atomic` adds do, src/nlkalman.c:923-931); with
+ * this switch every workgroup writes its tile to a slab of its own and a gather kernel sums the
+ * slabs in a fixed order. Also set by NLK_DETERMINISTIC=1 in the environment at context creation. */
+int nlk_ctx_set_deterministic(nlk_ctx *ctx, int on);
 /* run the context's work on an externally owned hipStream_t; NULL is the legacy
  * default stream itself (what torch.cuda.current_stream() is unless changed), so
  * that the kernels order with the caller's own work on that stream.

@@ -642,3 +642,94 @@ def test_local_mode_single_patch(ctx, built, O):
             g, rec = _dev_frame(ctx, True, cur, prev, None, 20.0, ps)
             _check_records(rec, tr, f"local smoother ch{ch} {over}")
             cases.assert_close(g, r, f"local smoother ch{ch} {over}")
+
+
+# ---------------------------------------------------------------- deterministic aggregation / bands
+
+def _frame(ctx, args, sigma, p, smoother=False):
+    out, _ = _dev_frame(ctx, smoother, *args, sigma, p)
+    return out
+
+
+@pytest.mark.parametrize("psz", [8, 12, 6])
+def test_deterministic_aggregation_is_bit_reproducible(built, O, synth, psz):
+    """nlk_ctx_set_deterministic: the accumulator tiles go to slabs and are summed in a fixed order
+    (k_gather.h) instead of being added with float atomics. Two runs must then be bit-identical
+    (filter with and without a previous frame, NaN holes, second iteration, smoother), equal the
+    default mode to summation-order noise, and match the oracle like it does."""
+    w, h, ch, sigma = 200, 136, 3, 20.0
+    n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, 17)
+    o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+    p1 = built.default_params(sigma, built.FLT1, patch_sz=psz, search_sz_x=min(10, 3 * (psz // 2)))
+    p2 = built.default_params(sigma, built.FLT2, patch_sz=psz, search_sz_x=min(10, 3 * (psz // 2)))
+    p3 = built.default_params(sigma, built.SMO1, patch_sz=psz)
+    det, dflt = built.Context(0), built.Context(0)
+    det.set_deterministic(True)
+    try:
+        def chain(c):
+            f0 = _frame(c, (o0, None, None), sigma, p1)
+            hole = f0.copy()
+            hole[40:70, 100:160] = np.nan                  # spatial-branch groups inside a temporal frame
+            f1 = _frame(c, (o1, hole, None), sigma, p1)
+            f2 = _frame(c, (o1, hole, f1), sigma, p2)
+            s0 = _frame(c, (f0, f2, None), sigma, p3, smoother=True)
+            return f0, f1, f2, s0
+        a, b, d = chain(det), chain(det), chain(dflt)
+        for name, x, y, z in zip(("flt1 spatial", "flt1 temporal", "flt2", "smo1"), a, b, d):
+            assert np.array_equal(x, y, equal_nan=True), f"psz {psz} {name}: two deterministic runs differ"
+            # (default mode: float atomics in varying order; a pixel whose summed weight sits at the
+            # reference's 1e-6 threshold can fall on either side of it from run to run: a few dozen
+            # samples of the second iteration's single-member groups with the small patches)
+            cases.assert_close(x, z, f"psz {psz} {name}: deterministic vs default mode", flips=150)
+        po = _to_o(O, p1)
+        cases.assert_close(a[0], O.filter_frame(o0, None, None, sigma, po), f"psz {psz}: deterministic vs oracle", flips=4)
+    finally:
+        det.close()
+        dflt.close()
+
+
+def test_deterministic_full_size_1080p_runs_are_identical(built, synth):
+    """Run-to-run equality at BASELINE.json configs[1] size, the property the atomics cannot give."""
+    w, h, ch, sigma = 1920, 1080, 3, 20.0
+    n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, 1)
+    o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+    p = built.default_params(sigma, built.FLT1)
+    det, dflt = built.Context(0), built.Context(0)
+    det.set_deterministic(True)
+    try:
+        prev = _frame(det, (o0, None, None), sigma, p)
+        a = _frame(det, (o1, prev, None), sigma, p)
+        b = _frame(det, (o1, prev, None), sigma, p)
+        assert np.array_equal(a, b)
+        d1 = _frame(dflt, (o1, prev, None), sigma, p)
+        cases.assert_close(a, d1, "deterministic vs atomics at 1080p", flips=40)
+    finally:
+        det.close()
+        dflt.close()
+
+
+@pytest.mark.parametrize("bands", [2, 3])
+def test_banded_two_stream_pipeline_equals_single_stream(built, synth, monkeypatch, bands):
+    """NLK_BANDS: the grid rows of a frame in bands on two streams (match / mask replay / filtering of
+    consecutive bands overlap). Same mask decisions, same records, same pixels up to the order of
+    the accumulator's atomic adds."""
+    w, h, ch, sigma = 320, 400, 3, 20.0
+    n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, 23)
+    o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+    p = built.default_params(sigma, built.FLT1)
+    c = built.Context(0)
+    try:
+        monkeypatch.delenv("NLK_BANDS", raising=False)
+        f0, r0 = _dev_frame(c, False, o0, None, None, sigma, p)
+        f1, r1 = _dev_frame(c, False, o1, f0, None, sigma, p)
+        monkeypatch.setenv("NLK_BANDS", str(bands))
+        g0, q0 = _dev_frame(c, False, o0, None, None, sigma, p)
+        g1, q1 = _dev_frame(c, False, o1, f0, None, sigma, p)
+        for a, b in ((r0, q0), (r1, q1)):
+            for key in ("active", "nsel", "np0", "nagg", "topk", "gcoords"):
+                assert np.array_equal(a[key], b[key]), key
+        assert 0.2 < 1 - r1["active"].mean() < 0.5
+        cases.assert_close(g0, f0, f"{bands} bands vs one, spatial", maxabs=5e-4, rmse=5e-5)
+        cases.assert_close(g1, f1, f"{bands} bands vs one, temporal", maxabs=5e-4, rmse=5e-5)
+    finally:
+        c.close()
