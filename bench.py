@@ -250,6 +250,10 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="workload S1: independent sequences run concurrently on the GPU (one context, "
                          "HIP stream and host thread each); value = aggregate")
+    ap.add_argument("--phase-times", action="store_true",
+                    help="row-strip runs (N > 1 or --force-strips): a third, untimed loop that synchronises after "
+                         "every phase of a step and reports exchange / match / gather / commit / group / exchange / "
+                         "normalise wall times per rank")
     ap.add_argument("--force-strips", action="store_true",
                     help="run the N > 1 strip machinery even at N = 1 (measures its fixed overhead)")
     args = ap.parse_args()
@@ -369,15 +373,44 @@ def main():
     barrier()
     tm = ctx.timings()
     ctx.set_profiling(False)
+    striped = world > 1 or args.force_strips
+    # transforms this rank's group kernel really ran (from its records): the roofline's flops
+    import numpy as np
+    rec = ctx.read_records()
+    if striped and args.workload != "C5":
+        p_ = sf.p
+        act = sf.active_full[p_["gy0"] * sf.ngx:p_["gy1"] * sf.ngx].cpu().numpy().astype(bool)
+    else:
+        act = rec["active"].astype(bool)
+    act = act & (rec["nagg"] > 0)
+    ntr_local = float((rec["nsel"] * (1 + (rec["np0"] > 0)) + 2 * rec["nagg"])[act].sum())
+    phase_ms = None
+    if striped and args.phase_times and args.workload != "C5":
+        sf.timers, sf.phase_s = True, {}
+        for _ in range(args.steps):
+            one_step()
+        barrier()
+        sf.timers = False
+        phase_ms = {k_: round(v / args.steps * 1e3, 4) for k_, v in sf.phase_s.items()}
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt, tm["group_ms"], tm["match_ms"]], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = float(tt[0].item())
+        tm["group_ms"], tm["match_ms"] = float(tt[1].item()), float(tt[2].item())   # slowest rank
+        ts = torch.tensor([ntr_local], dtype=torch.float64, device=dev)
+        dist.all_reduce(ts)
+        ntr_total = float(ts.item())
+        if phase_ms is not None:
+            allp = [None] * world
+            dist.all_gather_object(allp, phase_ms)
+            phase_ms = allp
         y0, y1, rows = sf.own_rows()
         full = torch.zeros_like(t_n1)
         full[y0:y1] = rows
         dist.all_reduce(full)
         t_out = full
+    else:
+        ntr_total = ntr_local
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -394,19 +427,15 @@ def main():
         k, ngrid = p.npatches_t, ngx * ngy
         alg_bytes = {"match": w * h * ch * 4 + ngrid * k * 4,
                      "group": 2 * w * h * ch * 4 + (ch + 1) * w * h * 4 + ngrid * k * 4}
-        if world == 1:
-            rec = ctx.read_records()
-            act = rec["active"].astype(bool) & (rec["nagg"] > 0)
-            ntr = (rec["nsel"] * (1 + (rec["np0"] > 0)) + 2 * rec["nagg"])[act].sum()
-            group_flops = float(ntr) * ch * 2 * 2 * psz ** 3
-        else:
-            group_flops = ngrid * 0.70 * 0.60e6
+        # (all ranks' transforms; per-GPU figures below divide by the world size and use the slowest
+        # rank's kernel time)
+        group_flops = ntr_total * ch * 2 * 2 * psz ** 3
         alg_flops = {"match": ngrid * (121 * 192 * 3), "group": group_flops}
         dom = "group" if tm["group_ms"] >= tm["match_ms"] else "match"
         dur = tm[dom + "_ms"] * 1e-3
         gbs = alg_bytes[dom] / world / dur / 1e9 if dur > 0 else 0.0
         tfl = alg_flops[dom] / world / dur / 1e12 if dur > 0 else 0.0
-        kname = ("k_group8m" if psz == 8 else "k_group12" if psz == 12 else "k_group") if dom == "group" else "k_bm_topk"
+        kname = ("k_group8m" if psz == 8 and ch in (1, 3) else "k_groupp") if dom == "group" else "k_bm_topk"
         # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE in separate runs, tools/pmc_run.sh); valid for the single-GPU C2 launch only
         traffic = None
@@ -421,8 +450,9 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes[dom] // world,
                 "hbm": {"achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 6)},
-                "note": ("12x12 patches: the transforms run on the f32 vector ALU (same FP32 datapath, same peak). "
-                         if psz != 8 else "") +
+                "note": (f"{psz}x{psz} patches: the transforms run as flow graphs on the f32 vector ALU (same FP32 datapath, "
+                         "same peak; algorithmic flops = the row-column matrix form). " if kname == "k_groupp" else "") +
+                        ("per GPU: all ranks' transforms / world size over the slowest rank's kernel time. " if world > 1 else "") +
                         "~550 flop per algorithmic byte: compute bound. f32 MFMA and f32 VALU share "
                         "the FP32 datapath on gfx950 (no co-issue gain measured), so the bound is "
                         "32 cycles per MFMA + 4 per VALU instruction: see DESIGN.md §5"}
@@ -441,6 +471,8 @@ def main():
                "kernels_ms_note": "second loop of the same steps in the single-stream order (HIP events around every "
                                   "kernel); ms_per_step is the timed loop, where the bands of a frame overlap",
                "roofline": roof}
+        if phase_ms is not None:
+            res["strip_phase_ms"] = phase_ms
         if args.workload == "C5":
             res["config"]["workload"] = (f"C5: {w}x{h}x{ch} sigma={sigma:g}: flt1 temporal -> flt2 -> smo1 "
                                          f"(3 frame calls per step), frames resident")

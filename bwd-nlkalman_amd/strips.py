@@ -97,6 +97,23 @@ class StripFrame:
             self.active_full = torch.zeros(self.ngy * self.ngx, dtype=torch.uint8, device=device)
         self.up = rank - 1 if rank > 0 else None
         self.dn = rank + 1 if rank < world - 1 else None
+        # ---- every exchange buffer is allocated once (a frame step allocates nothing):
+        # accumulator halos are packed into / received in contiguous (ch+1, rows, w) buffers
+        l, plan = self._l, self.plan
+        self.n_up = plan[self.up]["Y1"] - p["own0"] if self.up is not None else 0   # my rows the upper rank reads / writes
+        self.n_dn = p["own1"] - plan[self.dn]["Y0"] if self.dn is not None else 0
+        self.h_top, self.h_bot = l(p["own0"]), self.hl - l(p["own1"])               # my halo rows above / below
+        f32 = dict(dtype=torch.float32, device=device)
+        self.snd_top = torch.zeros((ch + 1, self.h_top, w), **f32) if self.up is not None else None
+        self.snd_bot = torch.zeros((ch + 1, self.h_bot, w), **f32) if self.dn is not None else None
+        self.rcv_top = torch.zeros((ch + 1, self.n_up, w), **f32) if self.up is not None else None
+        self.rcv_bot = torch.zeros((ch + 1, self.n_dn, w), **f32) if self.dn is not None else None
+        if stage_host:  # (gloo tests: pinned-size host mirrors, also allocated once)
+            self._host = {}
+        # per-phase wall times of the last step (seconds; `timers=True` synchronises the device
+        # after every phase, for diagnosis only: bench.py --phase-times)
+        self.timers = False
+        self.phase_s = {}
 
     # ---- helpers in strip-local row coordinates
     def _l(self, y):
@@ -110,10 +127,19 @@ class StripFrame:
         self.prev.zero_()
         self.prev[self._l(p["own0"]):self._l(p["own1"])] = prev_own_full[p["own0"]:p["own1"]]
 
-    def _exchange(self, sends, recvs):
+    def _hbuf(self, t, tag):
+        b = self._host.get(tag)
+        if b is None or b.shape != t.shape:
+            b = self._host[tag] = torch.empty(t.shape, dtype=t.dtype)
+        return b
+
+    def _exchange(self, sends, recvs, tag):
+        """Neighbour exchange: every send / receive posted at once (batch_isend_irecv: one RCCL group),
+        then waited for. Tensors are contiguous row ranges or preallocated packed buffers."""
         if self.stage_host:
-            sends = [(t.cpu(), peer) for t, peer in sends]
-            dev_recvs, recvs = recvs, [(torch.empty(t.shape, dtype=t.dtype), peer) for t, peer in recvs]
+            hs = [(self._hbuf(t, (tag, "s", i)).copy_(t), peer) for i, (t, peer) in enumerate(sends)]
+            hr = [(self._hbuf(t, (tag, "r", i)), peer) for i, (t, peer) in enumerate(recvs)]
+            dev_recvs, sends, recvs = recvs, hs, hr
         ops = [dist.P2POp(dist.isend, t, peer) for t, peer in sends]
         ops += [dist.P2POp(dist.irecv, t, peer) for t, peer in recvs]
         if ops:
@@ -131,60 +157,77 @@ class StripFrame:
             else:
                 dist.all_gather(outs, t)
             return
-        houts = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
-        dist.all_gather(houts, t.cpu())
+        houts = [self._hbuf(o, ("ag", i)) for i, o in enumerate(outs)]
+        dist.all_gather(houts, self._hbuf(t, ("ag", "s")).copy_(t))
         flat.copy_(torch.cat(houts))
 
+    def _tick(self, name, t0):
+        if self.timers:
+            import time
+            if self.cur.is_cuda:
+                torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            self.phase_s[name] = self.phase_s.get(name, 0.0) + (t1 - t0)
+            return t1
+        return t0
+
     def step(self):
+        import time
         p, plan, w, ch = self.p, self.plan, self.w, self.ch
         l = self._l
+        t0 = time.perf_counter() if self.timers else 0.0
         # (1) halo rows of the previous denoised frame: row ranges of `prev` are contiguous, so they are
         # sent from and received into place
         sends, recvs = [], []
         if self.up is not None:
-            n_up = plan[self.up]["Y1"] - p["own0"]          # my rows the upper rank reads
-            sends.append((self.prev[l(p["own0"]):l(p["own0"]) + n_up], self.up))
+            sends.append((self.prev[l(p["own0"]):l(p["own0"]) + self.n_up], self.up))
             recvs.append((self.prev[:l(p["own0"])], self.up))
         if self.dn is not None:
-            n_dn = p["own1"] - plan[self.dn]["Y0"]          # my rows the lower rank reads
-            sends.append((self.prev[l(p["own1"]) - n_dn:l(p["own1"])], self.dn))
+            sends.append((self.prev[l(p["own1"]) - self.n_dn:l(p["own1"])], self.dn))
             recvs.append((self.prev[l(p["own1"]):], self.dn))
-        self._exchange(sends, recvs)
+        self._exchange(sends, recvs, "prev")
+        t0 = self._tick("exchange_prev", t0)
         # (2) kernels on the strip
         self.acc.zero_()
         oy, ngy_l = p["gy0"] * self.step_px - p["Y0"], p["gy1"] - p["gy0"]
         if self.phases is None:
             self.accumulate(self.acc, self.cur, self.prev, oy, ngy_l)
+            t0 = self._tick("accumulate", t0)
         else:
             match, commit, group = self.phases
             n_l = ngy_l * self.ngx
             reach = match(self.marks_pad[:n_l], self.cur, self.prev, oy, ngy_l)
+            t0 = self._tick("match", t0)
             if self.world > 1:
                 self._all_gather(self.marks_flat, self.marks_all, self.marks_pad)
                 torch.index_select(self.marks_flat, 0, self.compact, out=self.marks_full)
             else:
                 self.marks_full.copy_(self.marks_pad[:n_l])
+            t0 = self._tick("gather_marks", t0)
             commit(self.marks_full, self.ngx, self.ngy, reach, self.active_full)
+            t0 = self._tick("commit", t0)
             group(self.acc, self.active_full[p["gy0"] * self.ngx:p["gy1"] * self.ngx])
-        # (3) accumulator rows written outside the own rows go to their owner
-        sends, recvs, at, ab = [], [], None, None
+            t0 = self._tick("group", t0)
+        # (3) accumulator rows written outside the own rows go to their owner: packed into the
+        # preallocated buffers (one strided copy each), added on arrival
+        sends, recvs = [], []
         if self.up is not None:
-            sends.append((self.acc[:, :l(p["own0"])].contiguous(), self.up))
-            at = torch.empty((ch + 1, plan[self.up]["Y1"] - p["own0"], w), dtype=torch.float32,
-                             device=self.cur.device)
-            recvs.append((at, self.up))
+            self.snd_top.copy_(self.acc[:, :self.h_top])
+            sends.append((self.snd_top, self.up))
+            recvs.append((self.rcv_top, self.up))
         if self.dn is not None:
-            sends.append((self.acc[:, l(p["own1"]):].contiguous(), self.dn))
-            ab = torch.empty((ch + 1, p["own1"] - plan[self.dn]["Y0"], w), dtype=torch.float32,
-                             device=self.cur.device)
-            recvs.append((ab, self.dn))
-        self._exchange(sends, recvs)
-        if at is not None:
-            self.acc[:, l(p["own0"]):l(p["own0"]) + at.shape[1]] += at
-        if ab is not None:
-            self.acc[:, l(p["own1"]) - ab.shape[1]:l(p["own1"])] += ab
+            self.snd_bot.copy_(self.acc[:, l(p["own1"]):])
+            sends.append((self.snd_bot, self.dn))
+            recvs.append((self.rcv_bot, self.dn))
+        self._exchange(sends, recvs, "acc")
+        if self.up is not None:
+            self.acc[:, l(p["own0"]):l(p["own0"]) + self.n_up] += self.rcv_top
+        if self.dn is not None:
+            self.acc[:, l(p["own1"]) - self.n_dn:l(p["own1"])] += self.rcv_bot
+        t0 = self._tick("exchange_acc", t0)
         # (4) normalise the own rows
         self.normalize(self.out, self.acc, self.cur, l(p["own0"]), l(p["own1"]))
+        self._tick("normalize", t0)
 
     def own_rows(self):
         p = self.p
