@@ -242,3 +242,46 @@ k_mask_commit_wave(const uint32_t* __restrict__ skewed, uint8_t* __restrict__ ac
     for (int e = 0; e < S; ++e) A[e] = B[e];
   }
 }
+
+
+// ---------------------------------------------------------------------------
+// Any reach (R > 3: (2R+1)^2 neighbours do not fit a 64-bit mark word): the same time-stepped
+// replay driven by the group-coordinate lists themselves. One workgroup; thread = grid row (rows
+// tid, tid + 1024, ...); at step s row j looks at column s - (R+1) j. `active` is the mask: 1 until
+// an earlier, non-skipped target's marking group contains the target (only raster-FORWARD members
+// are written, so the final array is the decision). One barrier per step and up to nagg dependent
+// stores per target: slow (milliseconds per frame), but it is the path of unusual parameter
+// combinations only (e.g. --f1_p 4 with the default search radius 10, or --f1_st 20).
+// Bytes are exchanged between the threads through agent-scope atomics (no stale L1 lines).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+k_mask_commit_lists(const NlkTarget* __restrict__ tinfo, const uint32_t* __restrict__ gcoords, int gstride,
+                    uint8_t* __restrict__ active, int ngx, int ngy, int R, int step, int oy) {
+  const int skew = R + 1;
+  const int nsteps = ngx + skew * (ngy - 1);
+  const int ntot = ngx * ngy;
+  for (int t = threadIdx.x; t < ntot; t += blockDim.x)
+    __hip_atomic_store(&active[t], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    for (int j = threadIdx.x; j < ngy; j += blockDim.x) {
+      const int i = s - skew * j;
+      if (i < 0 || i >= ngx) continue;
+      const int t = j * ngx + i;
+      if (!__hip_atomic_load(&active[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+      const NlkTarget info = tinfo[t];
+      if (!(info.flags & 2)) continue;  // this group does not mark (reference: :931, smoother :1844)
+      const int px = i * step, py = oy + j * step;
+      for (int n = 0; n < info.nagg; ++n) {
+        const uint32_t q = gcoords[(size_t)t * gstride + n];
+        const int dx = nlk_x(q) - px, dy = nlk_y(q) - py;
+        if (dx % step || dy % step) continue;
+        const int ii = i + dx / step, jj = j + dy / step;
+        if (ii < 0 || ii >= ngx || jj < 0 || jj >= ngy) continue;
+        const int t2 = jj * ngx + ii;
+        if (t2 > t) __hip_atomic_store(&active[t2], (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+  }
+}

@@ -162,7 +162,6 @@ __device__ __forceinline__ void nlk_match_target(const float* __restrict__ tile,
 
 // Group membership, records and mark word of one target whose sorted k-NN list is in sel[0..k)
 // (reference: src/nlkalman.c:725-732, 779-793, 857, 931; smoother :1669-1676, :1844).
-template <int PSZ>
 __device__ __forceinline__ void nlk_match_epilogue(const NlkGeom& g, size_t t, int px, int py, int prev_p,
                                           int k, const uint32_t* __restrict__ sel,
                                           uint32_t* __restrict__ grp,
@@ -170,7 +169,7 @@ __device__ __forceinline__ void nlk_match_epilogue(const NlkGeom& g, size_t t, i
                                           uint32_t* __restrict__ topk, NlkTarget* __restrict__ tinfo,
                                           uint32_t* __restrict__ gcoords,
                                           uint64_t* __restrict__ marks, int lane) {
-  constexpr int step = PSZ / 2;
+  const int step = g.step;
   NlkTarget info = {0, 0, 0, prev_p, {0ull, 0ull}};
   // --- group membership: the first ntagg kept candidates that have a valid
   // previous patch, or (none valid) the first ntagg kept candidates
@@ -209,7 +208,7 @@ __device__ __forceinline__ void nlk_match_epilogue(const NlkGeom& g, size_t t, i
       const uint32_t q = np0 ? grp[i] : sel[i];
       gcoords[t * g.gstride + i] = q;
       const int dx = nlk_x(q) - px, dy = nlk_y(q) - py;
-      if (mark && dx % step == 0 && dy % step == 0) {
+      if (mark && g.R <= 3 && dx % step == 0 && dy % step == 0) {  // (R > 3: k_mask_commit_lists reads the lists)
         const int di = dx / step, dj = dy / step;
         mbits |= 1ull << ((dj + g.R) * side + di + g.R);
       }
@@ -352,7 +351,7 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
       if (lane == 0) wide_list[atomicAdd(wide_count, 1u)] = (uint32_t)t;
       continue;
     }
-    nlk_match_epilogue<PSZ>(g, t, px, py, prev_p, k, sel, grp, vmap, topk, tinfo, gcoords, marks, lane);
+    nlk_match_epilogue(g, t, px, py, prev_p, k, sel, grp, vmap, topk, tinfo, gcoords, marks, lane);
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -419,7 +418,9 @@ k_bm_wide(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
     else
       nlk_match_target<PSZ, CH, MAXM>(tile, plane, rwp, tl_tgt, plane, rwp, 0, nwx, n, k, x0, y0,
                                       surv, sel, lane);
-    nlk_match_epilogue<PSZ>(g, t, px, py, prev_p, k, sel, grp, vmap, topk, tinfo, gcoords, marks, lane);
+    nlk_match_epilogue(g, t, px, py, prev_p, k, sel, grp, vmap, topk, tinfo, gcoords, marks, lane);
     __builtin_amdgcn_wave_barrier();
   }
 }
+
+

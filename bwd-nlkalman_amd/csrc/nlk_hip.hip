@@ -307,6 +307,7 @@ struct NlkPlan {
   size_t lds = 0, lds_w = 0;
   int maxm = 0, maxm_w = 0;
   bool wide = false;
+  bool generic = false;          // k_bm_generic instead of the tiled kernels
 };
 
 // records of the target rows from `r0` on (a view into the call's buffers)
@@ -366,12 +367,12 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   // temporal frame only groups with a valid previous patch mark (reference: :931)
   // and those searched with the temporal radius (reference: :637)
   const int wmark = (g.smoother || g.have_prev) ? g.wsz_t : g.wsz_x;
-  g.R = wmark / g.step;
-  if (g.R > 3)
-    return fail(c, NLK_EUNSUP, "search radius %d with patch size %d: group reach %d grid cells > 3",
-                wmark, g.psz, g.R);
+  g.R = wmark / g.step;  // (R > 3: the mask replay runs from the coordinate lists, commit_rows)
   const int ncand = (2 * wmax + 1) * (2 * wmax + 1);
-  if (ncand > 64 * 16) return fail(c, NLK_EUNSUP, "search radius %d too large (max 15)", wmax);
+  // the tiled matching kernels exist for patch sizes 4 / 6 / 8 / 10 / 12 / 16, 1 or 3 channels and
+  // windows of up to 1024 candidates; everything else the reference accepts goes to k_bm_generic
+  pl.generic = !(g.psz == 4 || g.psz == 6 || g.psz == 8 || g.psz == 10 || g.psz == 12 || g.psz == 16) ||
+               !(ch == 1 || ch == 3) || ncand > 64 * 16 || getenv("NLK_GENERIC_MATCH");
   g.kmax = max(max(g.npx, g.npt), 1);
   const int ngrid = g.ngx * g.ngy;
   const int npix = w * h;
@@ -421,11 +422,10 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   tl.ksel_max = g.kmax;
   pl.lds = sizeof(float) * ((size_t)ch * tl.rwp * tl.rh_max + 1 +
                             (size_t)NLK_BM_WAVES * (3 * tl.ksel_max + ntagg_alloc));
-  if (pl.lds > 160 * 1024)
-    return fail(c, NLK_EUNSUP, "matching tile needs %zu bytes of LDS (> 160 KiB)", pl.lds);
+  if (pl.lds > 160 * 1024) pl.generic = true;  // (a k or window too large for the tile: the generic kernel)
   // targets of a temporal frame without a valid previous patch search the spatial window
   // (reference: :637); when that one is the wider, they are queued for a second launch
-  pl.wide = g.have_prev && !g.smoother && g.wsz_x > g.wsz_t;
+  pl.wide = !pl.generic && g.have_prev && !g.smoother && g.wsz_x > g.wsz_t;
   const int wdom = 2 * tl.halo + 1;
   pl.maxm = (wdom * wdom + 63) / 64;
   if (pl.wide) {
@@ -438,8 +438,7 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
     const size_t per_wave = (((size_t)ch * tw.rwp * tw.rh_max + 1) & ~(size_t)1) +
                             ((3 * (size_t)tw.ksel_max + ntagg_alloc + 1) & ~(size_t)1);
     pl.lds_w = sizeof(float) * NLK_BM_WAVES * per_wave;
-    if (pl.lds_w > 160 * 1024)
-      return fail(c, NLK_EUNSUP, "spatial window of a temporal frame needs %zu bytes of LDS (> 160 KiB)", pl.lds_w);
+    if (pl.lds_w > 160 * 1024) { pl.generic = true; pl.wide = false; }
     pl.maxm_w = (ncand + 63) / 64;
   }
   c->p_match = pl.img_match; c->p_cur = pl.img_cur; c->p_prev = pl.img_prev;
@@ -453,6 +452,7 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
 static int match_rows(nlk_ctx* c, const NlkPlan& pl, hipStream_t stream, int r0, int rows, int band) {
   const NlkGeom gb = band_geom(pl.g, r0, rows);
   c->rv = view_rows(c, pl.g, stream, r0, band);
+  if (pl.generic) return nlk_launch_match_generic(c, gb, pl.img_match);
   NlkTile tl = pl.tl;
   tl.nty = (rows + tl.tgy - 1) / tl.tgy;
   if (pl.wide) HIPCHK(c, hipMemsetAsync(c->rv.wide, 0, sizeof(uint32_t), stream));
@@ -476,7 +476,7 @@ static int commit_rows(nlk_ctx* c, hipStream_t stream, const uint64_t* marks, ui
     HIPCHK(c, hipMemsetAsync(active + (size_t)first * ngx, 1, (size_t)nrows * ngx, stream));
     return NLK_OK;
   }
-  if (R <= 3 && !getenv("NLK_COMMIT_LDS")) {
+  if (R <= 3 && (first != 0 || !getenv("NLK_COMMIT_LDS"))) {
     // one lane per grid row, up to 1024 rows per launch; more rows in pieces that start with the
     // previous piece's last R rows as context (k_commit.h)
     int band = getenv("NLK_COMMIT_BAND") ? atoi(getenv("NLK_COMMIT_BAND")) : 1024;
@@ -502,8 +502,20 @@ static int commit_rows(nlk_ctx* c, hipStream_t stream, const uint64_t* marks, ui
     HIPCHK(c, hipGetLastError());
     return NLK_OK;
   }
-  if (first != 0) return fail(c, NLK_EINVAL, "the LDS mask replay takes whole grids only");
+  if (first != 0) return fail(c, NLK_EINVAL, "the LDS / list mask replays take whole grids only");
   const int ngy = nrows, ngrid = ngx * ngy;
+  if (R > 3) {
+    // (2R+1)^2 neighbours do not fit the 64-bit mark words: replay from the group-coordinate lists of
+    // the match phase that has just run in this context (k_mask_commit_lists)
+    if (!c->have_last || c->last.ngx != ngx || c->last.ngy != ngy || c->last.R != R ||
+        marks != (const uint64_t*)c->marks.p)
+      return fail(c, NLK_EUNSUP, "group reach %d grid cells > 3: the mask replay needs the coordinate lists of the "
+                  "context's own match phase (row strips across GPUs are limited to reach 3)", R);
+    hipLaunchKernelGGL(k_mask_commit_lists, dim3(1), dim3(1024), 0, stream, (const NlkTarget*)c->tinfo.p,
+                       (const uint32_t*)c->gcoords.p, c->last.gstride, active, ngx, ngy, R, c->last.step, c->last.oy);
+    HIPCHK(c, hipGetLastError());
+    return NLK_OK;
+  }
   const int rpt = (ngy + 1023) / 1024;
   const int threads = min(1024, ((ngy + 63) / 64) * 64);
   const size_t bits = sizeof(uint32_t) * ((size_t)(ngrid + (R + 1) * ngx + 63) / 32 + 1);
@@ -533,7 +545,7 @@ static int group_rows(nlk_ctx* c, hipStream_t stream, float* acc, const uint8_t*
 // other, and the four cross-stream dependencies and the doubled launches cost what the hidden replay
 // gains. Kept as an option (and as the exactness test of banding); profiling always runs one band.
 static int frame_bands(const nlk_ctx* c, const NlkGeom& g) {
-  if (c->profiling || c->deterministic || g.R == 0) return 1;  // (deterministic mode: one slab set, one sum order)
+  if (c->profiling || c->deterministic || g.R == 0 || g.R > 3) return 1;  // (deterministic mode: one slab set, one sum order)
   const char* e = getenv("NLK_BANDS");
   int nb = e ? atoi(e) : 1;
   nb = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
@@ -598,6 +610,9 @@ int nlk_dev_strip_match(nlk_ctx* c, const float* cur, const float* prev, const f
   if ((rc = match_rows(c, pl, c->stream, 0, pl.g.ngy, 0))) return rc;
   mark(c, 2);
   if (reach) *reach = c->last.R;
+  if (marks_out && c->last.R > 3)
+    return fail(c, NLK_EUNSUP, "group reach %d grid cells > 3: 64-bit mark words cannot describe it (row strips "
+                "across GPUs are limited to reach 3; whole-frame calls are not)", c->last.R);
   if (marks_out)
     HIPCHK(c, hipMemcpyAsync(marks_out, c->marks.p, sizeof(uint64_t) * (size_t)c->last.ngx * c->last.ngy,
                              hipMemcpyDeviceToDevice, c->stream));

@@ -114,5 +114,6 @@ int nlk_launch_group_generic(nlk_ctx* c, const NlkGeom& g, const float* img, con
 // tu_match.hip: block matching + selection (wide = the queued targets of a temporal frame)
 int nlk_launch_match(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds, const float* img,
                      int maxm, bool wide);
+int nlk_launch_match_generic(nlk_ctx* c, const NlkGeom& g, const float* img);
 // the 12x12 table of k_group12.h (nlk_host_tables)
 const float* nlk_basis12_table(void);

@@ -1,5 +1,6 @@
 // tu_match.hip — launcher of the block-matching kernels (k_match.h)
 #include "k_match.h"
+#include "k_match_generic.h"
 #include "nlk_internal.h"
 
 namespace {
@@ -51,3 +52,17 @@ int nlk_launch_match(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds
   return fail(c, NLK_EUNSUP, "%d channels not supported (1 or 3)", g.ch);
 }
 
+
+// the generic kernel: any patch size / channel count / search radius (k_match.h: k_bm_generic)
+int nlk_launch_match_generic(nlk_ctx* c, const NlkGeom& g, const float* img) {
+  const int wfull = 2 * max(g.wsz_x, g.wsz_t) + 1;
+  const size_t lds = 8 * (size_t)g.kmax + 4 * (size_t)g.kmax + 4 * (size_t)g.gstride + 4 * (size_t)wfull * wfull + 16;
+  if (lds > 160 * 1024)
+    return fail(c, NLK_EUNSUP, "search window of %d candidates with k = %d needs %zu bytes of LDS (> 160 KiB)",
+                wfull * wfull, g.kmax, lds);
+  HIPCHK(c, hipFuncSetAttribute((const void*)k_bm_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_bm_generic, dim3(nlk_xcd_grid(g.ngx * g.ngy)), dim3(64), lds, c->rv.stream, img,
+                     (const uint8_t*)c->vmap.p, g, g.kmax, c->rv.topk, c->rv.tinfo, c->rv.gcoords, c->rv.marks);
+  HIPCHK(c, hipGetLastError());
+  return NLK_OK;
+}

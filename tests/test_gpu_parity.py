@@ -135,15 +135,17 @@ def test_edge_cases(ctx, built, O):
 
 
 def test_unsupported_parameters_fail_loudly(ctx, built):
-    im = np.zeros((32, 32, 1), np.float32)
+    """What is left outside the kernels: patches above 16x16, and - across GPUs only - a marking
+    group that reaches more than 3 grid cells (64-bit mark words)."""
+    im = np.zeros((40, 40, 1), np.float32)
     d, o = ctx.upload(im), ctx.alloc(im.nbytes)
     with pytest.raises(built.NlkError, match="not supported"):
-        ctx.filter_frame(o, d, None, None, 32, 32, 1, 20.0, built.default_params(20.0, 0, patch_sz=7))
+        ctx.filter_frame(o, d, None, None, 40, 40, 1, 20.0, built.default_params(20.0, 0, patch_sz=18))
+    marks = ctx.upload(np.zeros(19 * 19, np.uint64))
     with pytest.raises(built.NlkError, match="reach"):
-        ctx.filter_frame(o, d, None, None, 32, 32, 1, 20.0,
-                         built.default_params(20.0, 0, patch_sz=4, search_sz_x=10))
-    ctx.free(d)
-    ctx.free(o)
+        ctx.strip_match(marks, d, None, None, 40, 40, 1, 20.0, built.default_params(20.0, 0, patch_sz=4, search_sz_x=10), 0, 19)
+    for x in (d, o, marks):
+        ctx.free(x)
 
 
 def test_strip_accumulate_equals_whole_frame(ctx, built):
@@ -733,3 +735,52 @@ def test_banded_two_stream_pipeline_equals_single_stream(built, synth, monkeypat
         cases.assert_close(g1, f1, f"{bands} bands vs one, temporal", maxabs=5e-4, rmse=5e-5)
     finally:
         c.close()
+
+
+# ---------------------------------------------------------------- the rest of the reference's parameter space
+
+def test_odd_patch_sizes_other_channel_counts_and_long_reaches(ctx, built, O):
+    """What round 1 rejected (VERDICT r1 "missing" 5): the reference takes any patch size
+    (src/nlkalman.c:524-525), any channel count (:555-560) and any search radius (:637-639).
+    Odd patch sizes and 2 / 4 channels run on k_bm_generic + k_groupp; a group reach of more than 3
+    grid cells (e.g. patch 4 with the default radius 10, or --f1_st 20) replays the mask from the
+    coordinate lists; a radius above 15 (more than 1024 candidates) searches with k_bm_generic.
+    Records exact, pixels within tolerance, for filter (spatial, temporal with NaN holes, second
+    iteration) and smoother."""
+    rng = np.random.default_rng(77)
+    configs = [
+        dict(psz=7, ch=3, w=61, h=47, over={}),
+        dict(psz=5, ch=1, w=40, h=52, over=dict(search_sz_x=6, search_sz_t=3)),
+        dict(psz=9, ch=2, w=57, h=44, over={}),
+        dict(psz=8, ch=4, w=48, h=40, over={}),
+        dict(psz=11, ch=3, w=50, h=46, over=dict(npatches_t=12)),
+        dict(psz=13, ch=1, w=70, h=48, over={}),
+        dict(psz=15, ch=3, w=64, h=50, over=dict(npatches_x=20, npatches_t=20)),
+        dict(psz=3, ch=3, w=33, h=30, over=dict(search_sz_x=3, search_sz_t=2)),
+        dict(psz=4, ch=3, w=44, h=36, over={}),                                 # reach 5 (radius 10 / step 2)
+        dict(psz=8, ch=3, w=80, h=64, over=dict(search_sz_t=20, search_sz_x=4)),  # reach 5, 1681 candidates
+        dict(psz=8, ch=1, w=90, h=70, over=dict(search_sz_x=17)),                # 1225 candidates
+        dict(psz=6, ch=3, w=50, h=44, over=dict(search_sz_x=12, search_sz_t=12)),  # reach 4
+    ]
+    for cfg in configs:
+        psz, ch, w, h = cfg["psz"], cfg["ch"], cfg["w"], cfg["h"]
+        cur = rng.uniform(0, 255, (h, w, ch)).astype(np.float32)
+        prev = (cur + rng.normal(0, 8, cur.shape)).astype(np.float32)
+        prev[h // 3:h // 3 + 5, w // 2:w // 2 + 6] = np.nan
+        prev[:, :1] = np.nan
+        basic = (cur + rng.normal(0, 3, cur.shape)).astype(np.float32)
+        for mode, pv, bs, smo in ((built.FLT1, None, None, False), (built.FLT1, prev, None, False),
+                                  (built.FLT2, prev, basic, False), (built.SMO1, prev, None, True)):
+            over = dict(cfg["over"])
+            if smo:
+                over.pop("search_sz_x", None)
+                over.pop("npatches_x", None)
+            p = built.default_params(20.0, mode, patch_sz=psz, **over)
+            fn = O.smooth_frame if smo else O.filter_frame
+            r, tr = fn(cur, pv, bs, 20.0, _to_o(O, p), trace=True)
+            g, rec = _dev_frame(ctx, smo, cur, pv, bs, 20.0, p)
+            what = f"psz {psz} ch {ch} {w}x{h} {cfg['over']} mode {mode} prev {pv is not None}"
+            _check_records(rec, tr, what)
+            edge = np.abs(tr["aggr"] - 1e-6) <= 1e-10   # (see test_randomised_parameters_and_shapes)
+            g = np.where(edge[..., None], r, g)
+            cases.assert_close(g, r, what, maxabs=5e-3, rmse=5e-4)
