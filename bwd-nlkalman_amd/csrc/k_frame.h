@@ -55,6 +55,12 @@ __global__ void k_normalize(float* __restrict__ out, const float* __restrict__ a
   }
 }
 
+// dst += src (accumulator halo rows received from a neighbouring strip)
+__global__ void k_add(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] += src[i];
+}
+
 // reference: src/nlkalman.c:92-110 (in place, ch == 3)
 __global__ void k_rgb2opp(float* __restrict__ im, size_t npix) {
   const float a = 1.f / sqrtf(3.f), b = 1.f / sqrtf(2.f);

@@ -253,6 +253,30 @@ int nlk_d2d(nlk_ctx* c, void* dst, const void* src, size_t n) {
   HIPCHK(c, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, c->stream));
   return NLK_OK;
 }
+int nlk_dev_zero(nlk_ctx* c, void* d, size_t n) {
+  if (!c || !d) return fail(c, NLK_EINVAL, "null argument");
+  HIPCHK(c, hipMemsetAsync(d, 0, n, c->stream));
+  return NLK_OK;
+}
+int nlk_dev_add(nlk_ctx* c, float* dst, const float* src, size_t n) {
+  if (!c || !dst || !src) return fail(c, NLK_EINVAL, "null argument");
+  if (n == 0) return NLK_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_add, dim3(1024), dim3(256), 0, c->stream, dst, src, n);
+  HIPCHK(c, hipGetLastError());
+  return NLK_OK;
+}
+// everything enqueued on src_ctx's stream so far has run when the copy starts; the copy itself is
+// ordered on dst_ctx's stream
+int nlk_dev_copy_peer(nlk_ctx* dc, void* dst, nlk_ctx* sc, const void* src, size_t n) {
+  if (!dc || !sc || !dst || !src) return fail(dc, NLK_EINVAL, "null argument");
+  HIPCHK(dc, hipSetDevice(sc->device));
+  HIPCHK(dc, hipEventRecord(sc->sync_ev[7], sc->stream));
+  HIPCHK(dc, hipSetDevice(dc->device));
+  HIPCHK(dc, hipStreamWaitEvent(dc->stream, sc->sync_ev[7], 0));
+  HIPCHK(dc, hipMemcpyPeerAsync(dst, dc->device, src, sc->device, n, dc->stream));
+  return NLK_OK;
+}
 int nlk_host_alloc(nlk_ctx* c, void** h, size_t n) {
   if (!c || !h) return NLK_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));

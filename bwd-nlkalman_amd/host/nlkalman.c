@@ -8,7 +8,8 @@
  *
  * A process-wide device context is created on first use (the CLI makes one
  * call per process; a long-running caller reuses the context and its scratch
- * buffers) and torn down at exit. NLK_DEVICE selects the HIP device (default 0).
+ * buffers) and torn down at exit. NLK_DEVICE selects the HIP device (default 0);
+ * NLK_DEVICES=0,1,... splits the two frame functions over several devices (multidev.c).
  */
 #include <math.h>
 #include <stdio.h>
@@ -145,8 +146,17 @@ static float *slot(nlk_ctx *c, int i, size_t bytes) {
   return (float *)g_slot[i].p;
 }
 
+/* host/multidev.c: the same call split over the devices of NLK_DEVICES */
+int nlk_multi_devices(void);
+void nlk_multi_frame(int smoother, float *out, const float *cur, const float *prev, const float *basic, int w, int h,
+                     int ch, float sigma, const struct nlkalman_params *P);
+
 static void frame_call(int smoother, float *out, float *cur, float *prev, float *basic, int w,
                        int h, int ch, float sigma, const struct nlkalman_params *prms) {
+  if (nlk_multi_devices() > 1) {
+    nlk_multi_frame(smoother, out, cur, prev, basic, w, h, ch, sigma, prms);
+    return;
+  }
   nlk_ctx *c = ctx();
   const size_t bytes = (size_t)w * h * ch * sizeof(float);
   float *d_cur = slot(c, 0, bytes), *d_out = slot(c, 3, bytes);

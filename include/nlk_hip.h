@@ -89,6 +89,12 @@ int nlk_h2d(nlk_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int nlk_d2h(nlk_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int nlk_d2d(nlk_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);
 int nlk_sync(nlk_ctx *ctx);
+/* building blocks of the row-strip split across devices (host/multidev.c): clear, dst += src on
+ * device memory, and a copy between two contexts' devices (hipMemcpyPeerAsync on dst_ctx's stream,
+ * after everything enqueued so far on src_ctx's stream) */
+int nlk_dev_zero(nlk_ctx *ctx, void *dptr, size_t bytes);
+int nlk_dev_add(nlk_ctx *ctx, float *dst, const float *src, size_t count);
+int nlk_dev_copy_peer(nlk_ctx *dst_ctx, void *dst, nlk_ctx *src_ctx, const void *src, size_t bytes);
 /* page-locked host memory: transfers from / to it run at the link's rate instead of through a
  * staging copy (file-based callers that keep a pool of frame buffers: host/main_seq.c) */
 int nlk_host_alloc(nlk_ctx *ctx, void **hptr, size_t bytes);

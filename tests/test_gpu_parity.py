@@ -784,3 +784,52 @@ def test_odd_patch_sizes_other_channel_counts_and_long_reaches(ctx, built, O):
             edge = np.abs(tr["aggr"] - 1e-6) <= 1e-10   # (see test_randomised_parameters_and_shapes)
             g = np.where(edge[..., None], r, g)
             cases.assert_close(g, r, what, maxabs=5e-3, rmse=5e-4)
+
+
+_MULTIDEV_SCRIPT = r"""
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+pkg = importlib.import_module("bwd-nlkalman_amd")
+synth = importlib.import_module("bwd-nlkalman_amd.synth")
+w, h, ch, sigma = 320, 256, 3, 20.0
+n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, 5)
+o0, o1 = pkg.rgb2opp(n0), pkg.rgb2opp(n1)
+p1, p2, p3 = (pkg.default_params(sigma, m) for m in (pkg.FLT1, pkg.FLT2, pkg.SMO1))
+# every stage is fed the FIRST run's outputs of the stages before it (a 1e-4 difference in an input
+# can flip a near-tied k-NN rank and move a few output samples by tenths)
+ref = dict(np.load(sys.argv[3])) if len(sys.argv) > 3 else {}
+f0 = pkg.filter_frame(o0, None, None, sigma, p1)
+hole = ref.get("f0", f0).copy(); hole[100:130, 50:90] = np.nan
+f1 = pkg.filter_frame(o1, hole, None, sigma, p1)
+f2 = pkg.filter_frame(o1, hole, ref.get("f1", f1), sigma, p2)
+s0 = pkg.smooth_frame(ref.get("f0", f0), ref.get("f2", f2), None, sigma, p3)
+np.savez(sys.argv[2], f0=f0, f1=f1, f2=f2, s0=s0)
+"""
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0"])
+def test_c_api_split_over_devices(built, tmp_path, devices):
+    """NLK_DEVICES: the drop-in C API (libnlkalman.so, host/multidev.c) cuts a frame call into row
+    strips over the listed devices - match per strip, mark words to every device, whole-grid mask
+    replay, group per strip, accumulator halos device to device - all in C. The one-GPU test box lists
+    device 0 several times (separate contexts, peer copies onto the same device): the result must
+    equal the single-device call up to the order of the accumulator's atomic adds."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "run.py"
+    script.write_text(_MULTIDEV_SCRIPT)
+    outs = {}
+    for tag, env in (("one", {}), ("split", {"NLK_DEVICES": devices})):
+        e = dict(os.environ, **env)
+        e.pop("NLK_DEVICES", None) if tag == "one" else None
+        args = [sys.executable, str(script), root, str(tmp_path / f"{tag}.npz")]
+        if tag == "split":
+            args.append(str(tmp_path / "one.npz"))
+        r = subprocess.run(args, env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        with np.load(tmp_path / f"{tag}.npz") as z:
+            outs[tag] = {k: z[k] for k in z.files}
+    for k in ("f0", "f1", "f2", "s0"):
+        cases.assert_close(outs["split"][k], outs["one"][k], f"NLK_DEVICES={devices}: {k}", maxabs=5e-4, rmse=5e-5, flips=8)
