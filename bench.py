@@ -58,6 +58,35 @@ def cpu_baseline(O, o1, prev, sigma, p):
                            f"{nthr} threads, {dt:.2f} s wall"}
 
 
+def kernel_sources_sha():
+    """sha256 over the HIP sources of the product (csrc/*.h, *.hip): what a PMC table was measured on."""
+    import glob
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "bwd-nlkalman_amd", "csrc", "*"))):
+        if f.endswith((".h", ".hip")):
+            hsh.update(os.path.basename(f).encode())
+            hsh.update(open(f, "rb").read())
+    return hsh.hexdigest()
+
+
+def measured_traffic(workload, kname):
+    """HBM-side bytes per launch from the committed PMC passes (profiles/r02_traffic.json, made by
+    tools/profile_round.sh + tools/make_traffic.py) - only while the kernel sources are still the ones
+    the table was measured on; otherwise (None, why)."""
+    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    if not os.path.exists(tpath):
+        return None, "no PMC table committed"
+    tab = json.load(open(tpath))
+    if tab.get("kernel_sources_sha256") != kernel_sources_sha():
+        return None, ("the kernel sources differ from the ones profiles/r02_traffic.json was measured on "
+                      f"(git {tab.get('git_head', '?')[:10]}): re-run tools/profile_round.sh")
+    ent = tab.get("workloads", {}).get(workload, {}).get(kname)
+    if not ent:
+        return None, f"no entry for {kname} at {workload}"
+    return ent["traffic_bytes"], f"FETCH_SIZE + WRITE_SIZE per launch, git {tab['git_head'][:10]} (fetch x2 bound: {ent['traffic_bytes_fetch_x2']:.4g})"
+
+
 def bench_flow(args, pkg, synth, ctx, torch, dist, rank, world, dev):
     """Workload F1: one step = one multiscale TV-L1 flow between two resident gray frames.
     The path does not shard (every iteration couples the whole image): N > 1 runs N independent
@@ -436,15 +465,11 @@ def main():
         gbs = alg_bytes[dom] / world / dur / 1e9 if dur > 0 else 0.0
         tfl = alg_flops[dom] / world / dur / 1e12 if dur > 0 else 0.0
         kname = ("k_group8m" if psz == 8 and ch in (1, 3) else "k_groupp") if dom == "group" else "k_bm_topk"
-        # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE in separate runs, tools/pmc_run.sh); valid for the single-GPU C2 launch only
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if world == 1 and args.workload == "C2" and os.path.exists(tpath):
-            traffic = json.load(open(tpath))["kernels"].get(kname, {}).get("traffic_bytes")
+        # HBM-side bytes per launch: PMC passes of the same sources (see measured_traffic)
+        traffic, traffic_note = (None, "single-GPU runs only") if world > 1 else measured_traffic(args.workload, kname)
         roof = {"kernel": kname, "bound": "mfma",
                 "achieved": round(tfl, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                 "launch_ms": round(tm[dom + "_ms"], 4),
                 "algorithmic_flops_per_launch": int(alg_flops[dom] / world),
                 "algorithmic_bytes_per_launch": alg_bytes[dom] // world,

@@ -1,20 +1,34 @@
 #!/bin/bash
-# End-of-round evidence run (gpurun): kernel-trace statistics of the C2 and F1 bench commands and
-# the FETCH_SIZE / WRITE_SIZE passes of F1 (separate --pmc runs, kernel-trace only).
-#   tools/profile_round.sh <tag>
+# End-of-round evidence run (gpurun): bench lines, rocprofv3 kernel statistics and PMC passes
+# (separate --pmc runs, kernel-trace only, program directly after `--`) for the C2 and C3 workloads.
+#   tools/profile_round.sh <tag>      -> gpurun_out/<tag>/ ; then tools/make_traffic.py <tag>
 set -u
-TAG=${1:-r01_h}
-OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+TAG=${1:-r02}
+ROOT=$GRAFT_REPO_ROOT
+OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python3 $GRAFT_REPO_ROOT/bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
-python3 $GRAFT_REPO_ROOT/bench.py --workload F1 > $OUT/bench_f1.json 2> $OUT/bench_f1.err
-python3 $GRAFT_REPO_ROOT/bench.py --workload S1 --steps 10 --warmup 2 > $OUT/bench_s1.json 2> $OUT/bench_s1.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2 -o c2 -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu > $OUT/bench_c2_under_rocprof.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/f1 -o f1 -- python3 $GRAFT_REPO_ROOT/bench.py --workload F1 --no-cpu > $OUT/bench_f1_under_rocprof.json 2>/dev/null
-for SET in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/pmc_$SET -o f1 -- python3 $GRAFT_REPO_ROOT/bench.py --workload F1 --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1
+for W in C2 C3 C1; do python3 $ROOT/bench.py --workload $W > $OUT/bench_$W.json 2> $OUT/bench_$W.err; done
+python3 $ROOT/bench.py --workload C5 --no-cpu > $OUT/bench_C5.json 2> $OUT/bench_C5.err
+python3 $ROOT/bench.py --workload F1 > $OUT/bench_F1.json 2> $OUT/bench_F1.err
+python3 $ROOT/bench.py --workload S1 --steps 10 --warmup 2 > $OUT/bench_S1.json 2> $OUT/bench_S1.err
+NLK_DETERMINISTIC=1 python3 $ROOT/bench.py --no-cpu > $OUT/bench_C2_deterministic.json 2>/dev/null
+NLK_DETERMINISTIC=1 python3 $ROOT/bench.py --no-cpu --workload C3 > $OUT/bench_C3_deterministic.json 2>/dev/null
+NLK_GROUP_PACKED=1 python3 $ROOT/bench.py --no-cpu > $OUT/bench_C2_packed.json 2>/dev/null
+NLK_GROUP12_ROWS=1 python3 $ROOT/bench.py --no-cpu --workload C3 > $OUT/bench_C3_rows.json 2>/dev/null
+for W in C2 C3; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -o s -- python3 $ROOT/bench.py --no-cpu --workload $W > $OUT/bench_${W}_under_rocprof.json 2>/dev/null
+  i=0
+  for SET in \
+   "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" \
+   "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS" \
+   "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 GRBM_GUI_ACTIVE" \
+   "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum"; do
+    i=$((i+1))
+    rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/pmc_$W/p$i -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --workload $W > /dev/null 2>&1
+  done
+  python3 $ROOT/tools/pmc_summary.py $OUT/pmc_$W > $OUT/pmc_${W}_summary.txt 2>&1
 done
-find $OUT -name "*.csv" | head -20
-# keep the merged output small: the raw traces are large
-find $OUT -name "*kernel_trace.csv" -size +8M -delete
+find $OUT -name "*_kernel_stats.csv" | head
+find $OUT -name "*.csv" -size +6M -delete
+find $OUT -name "*.db" -delete
