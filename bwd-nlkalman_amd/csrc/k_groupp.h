@@ -523,9 +523,32 @@ k_groupp(const float* __restrict__ img,   // matching / statistics image (planar
       }
     NLK_PP_SYNC();
   };
-  for (int c = 0; c < CH; ++c) {
+  // The member rows of a step are requested one step ahead (also across the change of channel), and
+  // a channel's plane is flushed only after the next step's rows have ARRIVED: vector-memory
+  // operations complete in issue order, so rows requested behind some sixty flush atomics would wait
+  // for every one of them (microseconds under load); this way nothing ever waits for an atomic.
+  const int per = SMO ? NS : 2 * NS;                          // members per step
+  const int nst = passthrough ? 1 : (nagg + per - 1) / per;   // steps per channel
+  float a[PSZ], b[PSZ], na[PSZ], nb[PSZ], gain[PSZ], mu[PSZ];
+#pragma unroll
+  for (int r = 0; r < PSZ; ++r) { b[r] = nb[r] = 0.f; gain[r] = mu[r] = 0.f; }
+  auto request = [&](int c, int st, float (&ra)[PSZ], float (&rb)[PSZ]) {  // rows of step `st` of channel c
     const float* img_c = img + c * npix;
-    float gain[PSZ], mu[PSZ], a[PSZ], b[PSZ];
+    const int n0 = st * per;
+    if (passthrough) {
+      nlk_pp_load_row<PSZ>(img_c + src_off + memb_org(0), ra);
+    } else if (!SMO) {  // member n0 + slot in a[], member n0 + NS + slot in b[]
+      const int ma = min(n0 + sl, nagg - 1), mb = min(n0 + NS + sl, nagg - 1);
+      nlk_pp_load_row<PSZ>(img_c + src_off + memb_org(ma), ra);
+      nlk_pp_load_row<PSZ>(img_c + src_off + memb_org(mb), rb);
+    } else {            // image and previous-frame patch of member n0 + slot
+      const int org = memb_org(min(n0 + sl, nagg - 1));
+      nlk_pp_load_row<PSZ>(img_c + src_off + org, ra);
+      nlk_pp_load_row<PSZ>(img_c + prev_off + org, rb);
+    }
+  };
+  request(0, 0, a, b);
+  for (int c = 0; c < CH; ++c) {
     if (!passthrough) {
       const float* gp = gbuf + ((c * 2 + 0) * PSZ + u) * PP;
       const float* mp = gbuf + ((c * 2 + 1) * PSZ + u) * PP;
@@ -537,15 +560,12 @@ k_groupp(const float* __restrict__ img,   // matching / statistics image (planar
           if (4 * j + e < PSZ) { gain[4 * j + e < PSZ ? 4 * j + e : 0] = gv[e]; mu[4 * j + e < PSZ ? 4 * j + e : 0] = mv[e]; }
       }
     }
-    if (passthrough) {
-      nlk_pp_load_row<PSZ>(img_c + src_off + memb_org(0), a);
-      add_round(a, 0, c);
-    } else if (!SMO) {
-      for (int n0 = 0; n0 < nagg; n0 += 2 * NS) {  // member n0 + slot in a[], member n0 + NS + slot in b[]
-        const int ma = min(n0 + sl, nagg - 1), mb = min(n0 + NS + sl, nagg - 1);
+    for (int st = 0; st < nst; ++st) {
+      const int n0 = st * per;
+      const bool last_of_channel = st + 1 == nst, more = !last_of_channel || c + 1 < CH;
+      if (passthrough) {
+      } else if (!SMO) {
         const bool two = n0 + NS < nagg;
-        nlk_pp_load_row<PSZ>(img_c + src_off + memb_org(ma), a);
-        if (two) nlk_pp_load_row<PSZ>(img_c + src_off + memb_org(mb), b);
         NLK_PP_FWD(a);
         if (two) NLK_PP_FWD(b);
 #pragma unroll
@@ -555,24 +575,25 @@ k_groupp(const float* __restrict__ img,   // matching / statistics image (planar
         }
         NLK_PP_INV(a);
         if (two) NLK_PP_INV(b);
-        add_round(a, n0, c);
-        if (two) add_round(b, n0 + NS, c);
-      }
-    } else {
-      for (int n0 = 0; n0 < nagg; n0 += NS) {  // image and previous-frame patch of member n0 + slot
-        const int ma = min(n0 + sl, nagg - 1);
-        const int org = memb_org(ma);
-        nlk_pp_load_row<PSZ>(img_c + src_off + org, a);
-        nlk_pp_load_row<PSZ>(img_c + prev_off + org, b);
+      } else {
         NLK_PP_FWD(a);
         NLK_PP_FWD(b);
 #pragma unroll
         for (int r = 0; r < PSZ; ++r) a[r] = (1 - gain[r]) * a[r] + gain[r] * b[r];  // reference: :1775
         NLK_PP_INV(a);
-        add_round(a, n0, c);
       }
+      if (more) request(last_of_channel ? c + 1 : c, last_of_channel ? 0 : st + 1, na, nb);
+      add_round(a, n0, c);
+      if (!passthrough && !SMO && n0 + NS < nagg) add_round(b, n0 + NS, c);
+      if (last_of_channel) {
+        // (the requested rows are consumed here, i.e. waited for, BEFORE the flush's atomics are issued)
+#pragma unroll
+        for (int r = 0; r < PSZ; ++r) { asm volatile("" : "+v"(na[r])); asm volatile("" : "+v"(nb[r])); }
+        flush(vplane, c, c + 1 < CH);
+      }
+#pragma unroll
+      for (int r = 0; r < PSZ; ++r) { a[r] = na[r]; b[r] = nb[r]; }
     }
-    flush(vplane, c, c + 1 < CH);
   }
   flush(wplane, CH, false);
 }

@@ -30,9 +30,9 @@ typedef struct {
   nlk_ctx *c;
   buf_t cur, prev, basic, out, acc, marks, marks_full, active, rtop, rbot;
   int gy0, gy1, Y0, Y1, own0, own1;
-} dev_t;
+} mdev_t;
 
-static dev_t g_dev[NLK_MAXDEV];
+static mdev_t g_dev[NLK_MAXDEV];
 static int g_ndev = -1; /* -1: NLK_DEVICES not looked at yet */
 
 static void md_die(const char *what, nlk_ctx *c) {
@@ -78,7 +78,7 @@ int nlk_multi_devices(void) {
   return n;
 }
 
-static void *grow(dev_t *D, buf_t *b, size_t bytes) {
+static void *grow(mdev_t *D, buf_t *b, size_t bytes) {
   if (b->cap < bytes) {
     if (b->p) nlk_dev_free(D->c, b->p);
     b->p = NULL;
@@ -102,7 +102,7 @@ void nlk_multi_frame(int smoother, float *out, const float *cur, const float *pr
   while (n > 1 && ngy / n < 1) --n;
   /* strips (the plan of strips.py): rows of the patch grid, pixel rows incl. the search halo, own rows */
   for (int d = 0; d < n; ++d) {
-    dev_t *D = &g_dev[d];
+    mdev_t *D = &g_dev[d];
     D->gy0 = (int)((long)ngy * d / n);
     D->gy1 = (int)((long)ngy * (d + 1) / n);
     D->Y0 = imax(0, D->gy0 * step - halo);
@@ -121,7 +121,7 @@ void nlk_multi_frame(int smoother, float *out, const float *cur, const float *pr
   int reach = 0;
   /* 1 + 2a: upload, match */
   for (int d = 0; d < n; ++d) {
-    dev_t *D = &g_dev[d];
+    mdev_t *D = &g_dev[d];
     const int hl = D->Y1 - D->Y0;
     float *dc = (float *)grow(D, &D->cur, row * hl);
     float *dp = prev ? (float *)grow(D, &D->prev, row * hl) : NULL;
@@ -145,7 +145,7 @@ void nlk_multi_frame(int smoother, float *out, const float *cur, const float *pr
                 (size_t)(g_dev[d].gy1 - g_dev[d].gy0) * ngx * 8))
       md_die("mark words", g_dev[d].c);
   for (int d = 0; d < n; ++d) {
-    dev_t *D = &g_dev[d];
+    mdev_t *D = &g_dev[d];
     const int hl = D->Y1 - D->Y0;
     if (nlk_h2d(D->c, D->marks_full.p, marks_host, nmark * 8) ||
         nlk_dev_mask_commit(D->c, D->marks_full.p, ngx, ngy, reach, (unsigned char *)D->active.p) ||
@@ -156,10 +156,10 @@ void nlk_multi_frame(int smoother, float *out, const float *cur, const float *pr
   free(marks_host);
   /* 4: accumulator rows outside the own rows -> the neighbour that owns them (device to device) */
   for (int d = 0; d < n; ++d) {
-    dev_t *D = &g_dev[d];
+    mdev_t *D = &g_dev[d];
     const int hl = D->Y1 - D->Y0;
     if (d > 0) { /* rows [Y0, own0) belong to device d-1 */
-      dev_t *U = &g_dev[d - 1];
+      mdev_t *U = &g_dev[d - 1];
       const int nr = D->own0 - D->Y0, hu = U->Y1 - U->Y0;
       float *rb = (float *)grow(U, &U->rbot, (size_t)(ch + 1) * nr * w * sizeof(float));
       for (int p = 0; p <= ch; ++p)
@@ -169,7 +169,7 @@ void nlk_multi_frame(int smoother, float *out, const float *cur, const float *pr
       (void)hu;
     }
     if (d + 1 < n) { /* rows [own1, Y1) belong to device d+1 */
-      dev_t *L = &g_dev[d + 1];
+      mdev_t *L = &g_dev[d + 1];
       const int nr = D->Y1 - D->own1;
       float *rt = (float *)grow(L, &L->rtop, (size_t)(ch + 1) * nr * w * sizeof(float));
       for (int p = 0; p <= ch; ++p)
@@ -179,7 +179,7 @@ void nlk_multi_frame(int smoother, float *out, const float *cur, const float *pr
     }
   }
   for (int d = 0; d < n; ++d) {
-    dev_t *D = &g_dev[d];
+    mdev_t *D = &g_dev[d];
     const int hl = D->Y1 - D->Y0;
     if (d > 0) { /* what device d-1 wrote into my first rows: its rows [own1(d-1), Y1(d-1)) = my [own0, ...) */
       const int nr = g_dev[d - 1].Y1 - g_dev[d - 1].own1;
@@ -201,7 +201,7 @@ void nlk_multi_frame(int smoother, float *out, const float *cur, const float *pr
       md_die("normalize", D->c);
   }
   for (int d = 0; d < n; ++d) {
-    dev_t *D = &g_dev[d];
+    mdev_t *D = &g_dev[d];
     if (nlk_d2h(D->c, out + (size_t)D->own0 * w * ch, (float *)D->out.p + (size_t)(D->own0 - D->Y0) * w * ch,
                 row * (D->own1 - D->own0)))
       md_die("download", D->c);
