@@ -14,6 +14,7 @@ static int nlk_groupp_launch_t(nlk_ctx* c, const NlkGeom& g, const float* img, c
   const bool split = c->deterministic && g.have_prev && !g.smoother && g.wsz_x > g.wsz_t;
   const size_t ntiles = (size_t)g.ngx * g.ngy;
   size_t slab_off = 0;
+  int* cnt_base = nullptr;
   for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
     NlkGTile tl{};
     tl.split = split;
@@ -52,10 +53,15 @@ static int nlk_groupp_launch_t(nlk_ctx* c, const NlkGeom& g, const float* img, c
         size_t need = ntiles * (g.ch + 1) * tl.plane;
         if (split) need += ntiles * (g.ch + 1) * ((size_t)(2 * g.wsz_x + g.psz + 8) * (2 * g.wsz_x + g.psz) + 4);
         int rc;
-        if ((rc = reserve(c, c->slab, sizeof(float) * need)) || (rc = reserve(c, c->tflag, 2 * ntiles))) return rc;
+        // (flags of both passes, then their tile-row counters: 2 x (1 + nty) ints, cleared per call)
+        const size_t cnt_off = (2 * ntiles + 15) & ~(size_t)15, cnt_bytes = sizeof(int) * 2 * (1 + (size_t)g.ngy);
+        if ((rc = reserve(c, c->slab, sizeof(float) * need)) || (rc = reserve(c, c->tflag, cnt_off + cnt_bytes))) return rc;
+        HIPCHK(c, hipMemsetAsync((uint8_t*)c->tflag.p + cnt_off, 0, cnt_bytes, c->rv.stream));
+        cnt_base = (int*)((uint8_t*)c->tflag.p + cnt_off);
       }
       tl.slab = (float*)c->slab.p + slab_off;
       tl.tflag = (uint8_t*)c->tflag.p + (size_t)pass * ntiles;
+      tl.tcount = cnt_base + pass * (1 + g.ngy);
       slab_off += ntiles * (g.ch + 1) * tl.plane;
     }
     auto kern = g.smoother ? k_groupp<PSZ, true> : k_groupp<PSZ, false>;
@@ -65,8 +71,7 @@ static int nlk_groupp_launch_t(nlk_ctx* c, const NlkGeom& g, const float* img, c
                        (const uint32_t*)c->rv.topk, (const NlkTarget*)c->rv.tinfo, (const uint32_t*)c->rv.gcoords,
                        active, basis, basis + PSZ * PSZ, acc);
     if (c->deterministic)
-      hipLaunchKernelGGL(k_gather_tiles, dim3((g.w + 255) / 256, g.h), dim3(256), 0, c->rv.stream, acc,
-                         (const float*)tl.slab, (const uint8_t*)tl.tflag, g, tl, g.ch + 1);
+      nlk_launch_gather(c->rv.stream, acc, tl.slab, tl.tflag, tl.tcount, g, tl, g.ch + 1);
     HIPCHK(c, hipGetLastError());
   }
   return NLK_OK;

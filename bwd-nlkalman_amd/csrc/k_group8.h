@@ -49,6 +49,7 @@ struct NlkGTile {
   // them to the frame accumulator with atomics, and the flag that says it did
   float* slab;      // [tiles][planes][plane]
   uint8_t* tflag;   // [tiles]
+  int* tcount;      // [1 + nty]: flagged tiles of the launch / of every tile row (zeroed by the host)
   // A temporal frame has two kinds of groups: those searched with the temporal radius and the few
   // spatial-branch ones (no valid previous patch) that reach wsz_x. Deterministic mode runs them in
   // two launches with a tile halo each (far = 0: the former only, far = 1: the latter only), so that

@@ -108,6 +108,26 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   const int ry1 = min(g.oy + (gy0 + cy - 1) * step + tl.wmax + PSZ, g.h);
   const int rw = rx1 - rx0, rh = ry1 - ry0;
   const int rwp = tl.rwp, plane = tl.plane;
+  // the tile's target records (requested first: they arrive while the tile is cleared)
+  int rec_act = 0, rec_nsel = 0, rec_nagg = 0;
+  uint32_t rec_vb[4] = {0u, 0u, 0u, 0u};
+  if (lane < cx * cy) {
+    const int ty = lane / cx, tx = lane - ty * cx;
+    const size_t t = (size_t)(gy0 + ty) * g.ngx + gx0 + tx;
+    rec_act = active[t];
+    const NlkTarget info = tinfo[t];
+    rec_nsel = info.nsel; rec_nagg = info.nagg;
+    rec_vb[0] = (uint32_t)info.vbits[0]; rec_vb[1] = (uint32_t)(info.vbits[0] >> 32);
+    rec_vb[2] = (uint32_t)info.vbits[1]; rec_vb[3] = (uint32_t)(info.vbits[1] >> 32);
+  }
+  if (tl.split) {  // (the two launches of deterministic mode: most tiles of the far one have nothing to do)
+    const bool work = rec_act && rec_nagg != 0 &&
+                      nlk_far_target(g, (rec_vb[0] | rec_vb[1] | rec_vb[2] | rec_vb[3]) ? 1 : 0) == (tl.far != 0);
+    if (!__ballot(work)) {
+      if (threadIdx.x == 0) tl.tflag[tile_id] = 0;
+      return;
+    }
+  }
   bool any_target = false;  // (deterministic mode: a tile without work writes no slab)
   for (int i = lane; i < (CH + 1) * plane / 4; i += 64)  // (plane is a multiple of 16)
     reinterpret_cast<nlk_f4*>(smem)[i] = nlk_f4{0.f, 0.f, 0.f, 0.f};
@@ -150,17 +170,6 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   // pass-B role of the lane as a load slot: channel / member of slot lo
   const int bch = lo >> 2, bm = lo & 3;
 
-  int rec_act = 0, rec_nsel = 0, rec_nagg = 0;
-  uint32_t rec_vb[4] = {0u, 0u, 0u, 0u};
-  if (lane < cx * cy) {
-    const int ty = lane / cx, tx = lane - ty * cx;
-    const size_t t = (size_t)(gy0 + ty) * g.ngx + gx0 + tx;
-    rec_act = active[t];
-    const NlkTarget info = tinfo[t];
-    rec_nsel = info.nsel; rec_nagg = info.nagg;
-    rec_vb[0] = (uint32_t)info.vbits[0]; rec_vb[1] = (uint32_t)(info.vbits[0] >> 32);
-    rec_vb[2] = (uint32_t)info.vbits[1]; rec_vb[3] = (uint32_t)(info.vbits[1] >> 32);
-  }
   for (int tt = 0; tt < cx * cy; ++tt) {
     if (!__builtin_amdgcn_readlane(rec_act, tt)) continue;
     const int nagg = __builtin_amdgcn_readlane(rec_nagg, tt);
@@ -481,7 +490,10 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   __syncthreads();
   if (tl.slab) {
     // deterministic mode (k_gather.h): the planes as they stand, into this tile's slab
-    if (lane == 0) tl.tflag[tile_id] = any_target;
+    if (lane == 0) {
+      tl.tflag[tile_id] = any_target;
+      if (any_target) { atomicAdd(&tl.tcount[0], 1); atomicAdd(&tl.tcount[1 + tile_y], 1); }
+    }
     if (any_target) {
       nlk_f4* dst = reinterpret_cast<nlk_f4*>(tl.slab + (size_t)tile_id * (CH + 1) * plane);
       for (int i = lane; i < (CH + 1) * plane / 4; i += 64) dst[i] = reinterpret_cast<const nlk_f4*>(smem)[i];

@@ -184,7 +184,10 @@ k_groupp(const float* __restrict__ img,   // matching / statistics image (planar
   bool work = active[ti] && nagg != 0;
   // (deterministic mode: near and far groups in separate launches)
   if (tl.split && nlk_far_target(g, (info.vbits[0] | info.vbits[1]) ? 1 : 0) != (tl.far != 0)) work = false;
-  if (tl.slab && lane == 0) tl.tflag[ti] = work;  // (deterministic mode, k_gather.h)
+  if (tl.slab && lane == 0) {  // (deterministic mode, k_gather.h)
+    tl.tflag[ti] = work;
+    if (work) { atomicAdd(&tl.tcount[0], 1); atomicAdd(&tl.tcount[1 + ti / g.ngx], 1); }
+  }
   if (!work) return;
   const size_t t = (size_t)ti;
   const int gy = ti / g.ngx, gx = ti - gy * g.ngx;

@@ -20,6 +20,7 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
   // launch whose tiles have the spatial halo, so that no member ever leaves its tile (k_group8.h)
   const bool split = c->deterministic && g.have_prev && !g.smoother && g.wsz_x > g.wsz_t;
   size_t slab_off = 0, flag_off = 0;  // (the second pass's slabs follow the first's)
+  int* cnt_base = nullptr;
   for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
     NlkGTile tl{};
     tl.split = split;
@@ -62,10 +63,15 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
           nflag += nt2;
         }
         int rc;
-        if ((rc = reserve(c, c->slab, sizeof(float) * need)) || (rc = reserve(c, c->tflag, nflag))) return rc;
+        // (flags, then the tile-row counters of both passes: 2 x (1 + nty) ints, cleared per call)
+        const size_t cnt_off = (nflag + 15) & ~(size_t)15, cnt_bytes = sizeof(int) * 2 * (1 + (size_t)tl.nty);
+        if ((rc = reserve(c, c->slab, sizeof(float) * need)) || (rc = reserve(c, c->tflag, cnt_off + cnt_bytes))) return rc;
+        HIPCHK(c, hipMemsetAsync((uint8_t*)c->tflag.p + cnt_off, 0, cnt_bytes, c->rv.stream));
+        cnt_base = (int*)((uint8_t*)c->tflag.p + cnt_off);
       }
       tl.slab = (float*)c->slab.p + slab_off;
       tl.tflag = (uint8_t*)c->tflag.p + flag_off;
+      tl.tcount = cnt_base + pass * (1 + tl.nty);
       slab_off += ntiles * (CH + 1) * tl.plane;
       flag_off += ntiles;
     }
@@ -81,8 +87,7 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
                        (const NlkTarget*)c->rv.tinfo, (const uint32_t*)c->rv.gcoords,
                        active, basis, basis + PSZ * PSZ, acc);
     if (c->deterministic)
-      hipLaunchKernelGGL(k_gather_tiles, dim3((g.w + 255) / 256, g.h), dim3(256), 0, c->rv.stream, acc,
-                         (const float*)tl.slab, (const uint8_t*)tl.tflag, g, tl, CH + 1);
+      nlk_launch_gather(c->rv.stream, acc, tl.slab, tl.tflag, tl.tcount, g, tl, CH + 1);
     HIPCHK(c, hipGetLastError());
   }
   return NLK_OK;
