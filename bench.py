@@ -370,13 +370,17 @@ def main():
             return ctx.strip_match(marks.data_ptr(), cur.data_ptr(), prev.data_ptr(), None, w,
                                    cur.shape[0], ch, sigma, p, oy, ngy_)
 
+        def match_rows(marks, cur, prev, oy, ngy_, r0, rows):
+            return ctx.strip_match_rows(marks.data_ptr(), cur.data_ptr(), prev.data_ptr(), None, w,
+                                        cur.shape[0], ch, sigma, p, oy, ngy_, r0, rows)
+
         def commit(marks_full, ngx_, ngy_, reach, active_full):
             ctx.mask_commit(marks_full.data_ptr(), ngx_, ngy_, reach, active_full.data_ptr())
 
         def group(acc, active):
             ctx.strip_group(acc.data_ptr(), active.data_ptr())
         sf = strips.StripFrame(rank, world, w, h, ch, psz, max(p.search_sz_x, p.search_sz_t), dev,
-                               accumulate, normalize, phases=(match, commit, group), stage_host=one_gpu)
+                               accumulate, normalize, phases=(match, commit, group, match_rows), stage_host=one_gpu)
         sf.load(t_n1, t_prev)
         one_step = sf.step
 

@@ -27,7 +27,7 @@ HIP_SYMBOLS = [
     "nlk_d2d", "nlk_sync", "nlk_host_alloc", "nlk_host_free", "nlk_dev_rgb2opp", "nlk_dev_opp2rgb",
     "nlk_dev_warp_bicubic", "nlk_dev_filter_frame", "nlk_dev_smooth_frame",
     "nlk_dev_frame_accumulate", "nlk_dev_frame_normalize", "nlk_ctx_read_records",
-    "nlk_dev_strip_match", "nlk_dev_mask_commit", "nlk_dev_strip_group",
+    "nlk_dev_strip_match", "nlk_dev_strip_match_rows", "nlk_dev_mask_commit", "nlk_dev_strip_group",
     "nlk_tvl1_default_params", "nlk_tvl1_scales", "nlk_dev_tvl1_flow", "nlk_dev_gray",
     "nlk_dev_occlusion_mask", "nlk_dev_image_dct", "nlk_dev_copy_block", "nlk_host_tables", "nlk_ctx_set_deterministic", "nlk_dev_zero", "nlk_dev_add", "nlk_dev_copy_peer",
 ]
@@ -116,6 +116,8 @@ def hip():
         L.nlk_dev_frame_normalize.argtypes = [vp, fp, fp, fp, i, i, i, i, i]
         L.nlk_dev_strip_match.argtypes = [vp, fp, fp, fp, i, i, i, f, C.POINTER(Params), i, i, i,
                                           vp, C.POINTER(i)]
+        L.nlk_dev_strip_match_rows.argtypes = [vp, fp, fp, fp, i, i, i, f, C.POINTER(Params), i, i, i, i, i,
+                                               vp, C.POINTER(i)]
         L.nlk_dev_mask_commit.argtypes = [vp, vp, i, i, i, vp]
         L.nlk_dev_strip_group.argtypes = [vp, fp, vp]
         L.nlk_ctx_read_records.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i),
@@ -361,6 +363,15 @@ class Context:
         self._chk(self.L.nlk_dev_strip_match(self.h, d_cur, d_prev, d_basic, w, h, ch, float(sigma),
                                              C.byref(params), oy, ngy, int(smoother), d_marks,
                                              C.byref(r)))
+        return r.value
+
+    def strip_match_rows(self, d_marks, d_cur, d_prev, d_basic, w, h, ch, sigma, params, oy, ngy, r0, rows,
+                         smoother=False):
+        """Phase 1 for the strip's target rows [r0, r0 + rows) only (marks / records at their place)."""
+        r = C.c_int()
+        self._chk(self.L.nlk_dev_strip_match_rows(self.h, d_cur, d_prev, d_basic, w, h, ch, float(sigma),
+                                                  C.byref(params), oy, ngy, int(smoother), r0, rows, d_marks,
+                                                  C.byref(r)))
         return r.value
 
     def mask_commit(self, d_marks, ngx, ngy, reach, d_active):

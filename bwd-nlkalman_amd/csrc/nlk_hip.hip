@@ -97,14 +97,22 @@ int check_images(nlk_ctx* c, const void* out, const void* cur, int w, int h, int
 // event i of the current frame call; event 0 opens a new set
 // (once MAXSETS frame calls have been recorded, recording stops: the averages then cover the
 // first MAXSETS calls, and no set is ever overwritten or left half-recorded)
+// A set opens with event 0 and closes with event 6 (normalisation). A strip whose matching comes in
+// several calls (nlk_dev_strip_match_rows) stays in ONE set: events 0 / 1 keep their first recording,
+// event 2 its last, so that match_ms spans all the parts (and the halo wait between them).
 void mark(nlk_ctx* c, int i) {
   if (!c->profiling) return;
-  if (i == 0) {
+  if (i == 0 && !c->set_open) {
     c->recording = c->nsets < nlk_ctx::MAXSETS;
     if (c->recording) c->nsets++;
+    c->set_open = true;
+    c->set_seen = 0;
   }
   if (!c->recording || c->nsets < 1) return;
+  if (i <= 1 && (c->set_seen >> i) & 1u) return;
+  c->set_seen |= 1u << i;
   (void)hipEventRecord(c->ev[(c->nsets - 1) * nlk_ctx::NEV + i], c->stream);
+  if (i == 6) c->set_open = false;
 }
 
 }  // namespace
@@ -178,6 +186,7 @@ int nlk_ctx_set_profiling(nlk_ctx* c, int on) {
   }
   c->profiling = on != 0;
   c->recording = false;
+  c->set_open = false;
   c->nsets = 0;  // (re)start averaging
   return NLK_OK;
 }
@@ -189,7 +198,9 @@ int nlk_ctx_get_timings(nlk_ctx* c, struct nlk_timings* t) {
   if (!c->ev || c->nsets == 0) return NLK_OK;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   double acc[6] = {0, 0, 0, 0, 0, 0};
-  for (int s = 0; s < c->nsets; ++s) {
+  const int nclosed = c->nsets - ((c->set_open && c->recording) ? 1 : 0);  // (a call still under way is left out)
+  if (nclosed <= 0) return NLK_OK;
+  for (int s = 0; s < nclosed; ++s) {
     hipEvent_t* e = c->ev + s * nlk_ctx::NEV;
     const int a[6] = {0, 1, 2, 3, 5, 0}, b[6] = {1, 2, 3, 4, 6, 6};
     for (int i = 0; i < 6; ++i) {
@@ -200,7 +211,7 @@ int nlk_ctx_get_timings(nlk_ctx* c, struct nlk_timings* t) {
   }
   float* dst[6] = {&t->layout_ms, &t->match_ms, &t->commit_ms, &t->group_ms, &t->normalize_ms,
                    &t->total_ms};
-  for (int i = 0; i < 6; ++i) *dst[i] = (float)(acc[i] / c->nsets);
+  for (int i = 0; i < 6; ++i) *dst[i] = (float)(acc[i] / nclosed);
   c->tm = *t;
   return NLK_OK;
 }
@@ -625,22 +636,32 @@ int nlk_dev_frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const flo
 }
 
 // ---- the same three phases as separate entry points (exact masks across GPUs)
-int nlk_dev_strip_match(nlk_ctx* c, const float* cur, const float* prev, const float* basic, int w,
-                        int h, int ch, float sigma, const struct nlkalman_params* P, int oy,
-                        int ngy, int smoother, void* marks_out, int* reach) {
+// rows [r0, r0 + rows) of the strip's target rows (a whole strip: r0 = 0, rows = ngy). Every call lays
+// the strip out again (planar copies, validity map), so a caller may match the rows that do not depend
+// on a halo still in flight first and the others once it has arrived.
+int nlk_dev_strip_match_rows(nlk_ctx* c, const float* cur, const float* prev, const float* basic, int w,
+                             int h, int ch, float sigma, const struct nlkalman_params* P, int oy,
+                             int ngy, int smoother, int r0, int rows, void* marks_out, int* reach) {
   NlkPlan pl;
   int rc = plan_frame(c, pl, cur, prev, basic, w, h, ch, sigma, P, oy, ngy, smoother, 1);
   if (rc) return rc;
-  if ((rc = match_rows(c, pl, c->stream, 0, pl.g.ngy, 0))) return rc;
+  if (r0 < 0 || rows < 0 || r0 + rows > pl.g.ngy) return fail(c, NLK_EINVAL, "rows [%d, %d) outside the strip's %d target rows", r0, r0 + rows, pl.g.ngy);
+  if (rows > 0 && (rc = match_rows(c, pl, c->stream, r0, rows, 0))) return rc;
   mark(c, 2);
   if (reach) *reach = c->last.R;
   if (marks_out && c->last.R > 3)
     return fail(c, NLK_EUNSUP, "group reach %d grid cells > 3: 64-bit mark words cannot describe it (row strips "
                 "across GPUs are limited to reach 3; whole-frame calls are not)", c->last.R);
-  if (marks_out)
-    HIPCHK(c, hipMemcpyAsync(marks_out, c->marks.p, sizeof(uint64_t) * (size_t)c->last.ngx * c->last.ngy,
-                             hipMemcpyDeviceToDevice, c->stream));
+  if (marks_out && rows > 0)
+    HIPCHK(c, hipMemcpyAsync((uint64_t*)marks_out + (size_t)r0 * c->last.ngx, (const uint64_t*)c->marks.p + (size_t)r0 * c->last.ngx,
+                             sizeof(uint64_t) * (size_t)c->last.ngx * rows, hipMemcpyDeviceToDevice, c->stream));
   return NLK_OK;
+}
+
+int nlk_dev_strip_match(nlk_ctx* c, const float* cur, const float* prev, const float* basic, int w,
+                        int h, int ch, float sigma, const struct nlkalman_params* P, int oy,
+                        int ngy, int smoother, void* marks_out, int* reach) {
+  return nlk_dev_strip_match_rows(c, cur, prev, basic, w, h, ch, sigma, P, oy, ngy, smoother, 0, ngy, marks_out, reach);
 }
 
 int nlk_dev_mask_commit(nlk_ctx* c, const void* marks, int ngx, int ngy, int reach,

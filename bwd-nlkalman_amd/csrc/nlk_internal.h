@@ -57,6 +57,8 @@ struct nlk_ctx {
   static constexpr int NEV = 7, MAXSETS = 512;
   bool profiling = false;
   bool recording = false;    // the current frame call has an event set (false once MAXSETS are used)
+  bool set_open = false;     // between event 0 and event 6 of a call
+  unsigned set_seen = 0;     // events of the open set recorded so far
   hipEvent_t* ev = nullptr;  // [MAXSETS][NEV], created lazily
   int nsets = 0;             // completed + current
   nlk_timings tm{};

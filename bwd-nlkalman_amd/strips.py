@@ -61,8 +61,10 @@ class StripFrame:
 
     def __init__(self, rank, world, w, h, ch, psz, halo, device, accumulate, normalize,
                  phases=None, stage_host=False):
-        """phases = (match, commit, group) callbacks selects the exact mode:
+        """phases = (match, commit, group[, match_rows]) callbacks selects the exact mode:
         match(marks[int64, ngy_l*ngx], cur, prev, oy, ngy_l) -> reach R;
+        match_rows(marks, cur, prev, oy, ngy_l, r0, rows) -> R: the same for the target rows [r0, r0+rows)
+        only (optional: overlaps the matching of the interior rows with the previous-frame halo exchange);
         commit(marks_full[int64], ngx, ngy, R, active_full[uint8]);
         group(acc, active_slice[uint8], ...) (state of the last match)."""
         self.rank, self.world, self.w, self.h, self.ch = rank, world, w, h, ch
@@ -110,6 +112,13 @@ class StripFrame:
         self.rcv_bot = torch.zeros((ch + 1, self.n_dn, w), **f32) if self.dn is not None else None
         if stage_host:  # (gloo tests: pinned-size host mirrors, also allocated once)
             self._host = {}
+        # target rows of the strip (strip-local indices [i0, i1)) whose search windows and candidate patches
+        # lie inside this rank's OWN rows of the previous frame: they can be matched before the halo arrives
+        gy0, gy1 = p["gy0"], p["gy1"]
+        lo = gy0 if self.up is None else -(-(p["own0"] + halo) // self.step_px)                  # ceil
+        hi = gy1 if self.dn is None else (p["own1"] - halo - psz) // self.step_px + 1
+        lo, hi = max(lo, gy0), min(hi, gy1)
+        self.interior = (lo - gy0, max(hi, lo) - gy0)
         # per-phase wall times of the last step (seconds; `timers=True` synchronises the device
         # after every phase, for diagnosis only: bench.py --phase-times)
         self.timers = False
@@ -133,21 +142,28 @@ class StripFrame:
             b = self._host[tag] = torch.empty(t.shape, dtype=t.dtype)
         return b
 
-    def _exchange(self, sends, recvs, tag):
-        """Neighbour exchange: every send / receive posted at once (batch_isend_irecv: one RCCL group),
-        then waited for. Tensors are contiguous row ranges or preallocated packed buffers."""
+    def _post(self, sends, recvs, tag):
+        """Neighbour exchange, posted: every send / receive at once (batch_isend_irecv: one RCCL group).
+        Returns what _wait needs. Tensors are contiguous row ranges or preallocated packed buffers."""
+        dev_recvs = None
         if self.stage_host:
             hs = [(self._hbuf(t, (tag, "s", i)).copy_(t), peer) for i, (t, peer) in enumerate(sends)]
             hr = [(self._hbuf(t, (tag, "r", i)), peer) for i, (t, peer) in enumerate(recvs)]
             dev_recvs, sends, recvs = recvs, hs, hr
         ops = [dist.P2POp(dist.isend, t, peer) for t, peer in sends]
         ops += [dist.P2POp(dist.irecv, t, peer) for t, peer in recvs]
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        if self.stage_host:
+        return (dist.batch_isend_irecv(ops) if ops else []), dev_recvs, recvs
+
+    def _wait(self, posted):
+        reqs, dev_recvs, recvs = posted
+        for req in reqs:
+            req.wait()
+        if dev_recvs is not None:
             for (d, _), (hbuf, _) in zip(dev_recvs, recvs):
                 d.copy_(hbuf)
+
+    def _exchange(self, sends, recvs, tag):
+        self._wait(self._post(sends, recvs, tag))
 
     def _all_gather(self, flat, outs, t):
         """t of every rank -> flat (= the views `outs`, rank-major)."""
@@ -185,19 +201,37 @@ class StripFrame:
         if self.dn is not None:
             sends.append((self.prev[l(p["own1"]) - self.n_dn:l(p["own1"])], self.dn))
             recvs.append((self.prev[l(p["own1"]):], self.dn))
-        self._exchange(sends, recvs, "prev")
-        t0 = self._tick("exchange_prev", t0)
+        posted = self._post(sends, recvs, "prev")
         # (2) kernels on the strip
         self.acc.zero_()
         oy, ngy_l = p["gy0"] * self.step_px - p["Y0"], p["gy1"] - p["gy0"]
         if self.phases is None:
+            self._wait(posted)
+            t0 = self._tick("exchange_prev", t0)
             self.accumulate(self.acc, self.cur, self.prev, oy, ngy_l)
             t0 = self._tick("accumulate", t0)
         else:
-            match, commit, group = self.phases
+            match, commit, group = self.phases[:3]
+            match_rows = self.phases[3] if len(self.phases) > 3 else None
             n_l = ngy_l * self.ngx
-            reach = match(self.marks_pad[:n_l], self.cur, self.prev, oy, ngy_l)
-            t0 = self._tick("match", t0)
+            i0, i1 = self.interior
+            if match_rows is not None and i1 > i0 and (self.up is not None or self.dn is not None):
+                # the target rows that see only this rank's own rows of the previous frame are matched while
+                # the halo rows travel; the seam rows (and a fresh layout of the strip) follow their arrival
+                reach = match_rows(self.marks_pad[:n_l], self.cur, self.prev, oy, ngy_l, i0, i1 - i0)
+                t0 = self._tick("match_interior", t0)
+                self._wait(posted)
+                t0 = self._tick("exchange_prev", t0)
+                if i0 > 0:
+                    match_rows(self.marks_pad[:n_l], self.cur, self.prev, oy, ngy_l, 0, i0)
+                if i1 < ngy_l:
+                    match_rows(self.marks_pad[:n_l], self.cur, self.prev, oy, ngy_l, i1, ngy_l - i1)
+                t0 = self._tick("match_seams", t0)
+            else:
+                self._wait(posted)
+                t0 = self._tick("exchange_prev", t0)
+                reach = match(self.marks_pad[:n_l], self.cur, self.prev, oy, ngy_l)
+                t0 = self._tick("match", t0)
             if self.world > 1:
                 self._all_gather(self.marks_flat, self.marks_all, self.marks_pad)
                 torch.index_select(self.marks_flat, 0, self.compact, out=self.marks_full)

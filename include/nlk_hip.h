@@ -177,6 +177,14 @@ int nlk_dev_strip_match(nlk_ctx *ctx, const float *cur, const float *prev,
                         const float *basic, int w, int h, int ch, float sigma,
                         const struct nlkalman_params *prms, int oy, int ngy,
                         int smoother, void *marks_out, int *reach);
+/* the same for the target rows [r0, r0 + rows) of the strip only (their records and mark words land at
+ * their place in the strip's arrays): lets a rank match the rows that do not depend on the previous
+ * frame's halo while that halo is still in flight, and the seam rows afterwards. Every call lays the
+ * strip out again (the halo may have arrived in between). */
+int nlk_dev_strip_match_rows(nlk_ctx *ctx, const float *cur, const float *prev,
+                             const float *basic, int w, int h, int ch, float sigma,
+                             const struct nlkalman_params *prms, int oy, int ngy,
+                             int smoother, int r0, int rows, void *marks_out, int *reach);
 int nlk_dev_mask_commit(nlk_ctx *ctx, const void *marks, int ngx, int ngy, int reach,
                         unsigned char *active);
 int nlk_dev_strip_group(nlk_ctx *ctx, float *acc, const unsigned char *active);

@@ -295,13 +295,18 @@ def _two_rank_worker(rank, world, port, q):
         return ctx.strip_match(marks.data_ptr(), cur.data_ptr(), prev.data_ptr(), None, w, cur.shape[0],
                                ch, sigma, p, oy, ngy)
 
+    def match_rows(marks, cur, prev, oy, ngy, r0, rows):
+        return ctx.strip_match_rows(marks.data_ptr(), cur.data_ptr(), prev.data_ptr(), None, w, cur.shape[0],
+                                    ch, sigma, p, oy, ngy, r0, rows)
+
     def commit(marks_full, ngx, ngy, reach, active_full):
         ctx.mask_commit(marks_full.data_ptr(), ngx, ngy, reach, active_full.data_ptr())
 
     def group(acc, active):
         ctx.strip_group(acc.data_ptr(), active.data_ptr())
     res = {}
-    for mode, phases in (("exact", (match, commit, group)), ("per-strip", None)):
+    for mode, phases in (("exact", (match, commit, group)), ("exact-overlap", (match, commit, group, match_rows)),
+                         ("per-strip", None)):
         sf = strips.StripFrame(rank, world, w, h, ch, p.patch_sz, max(p.search_sz_x, p.search_sz_t), dev,
                                accumulate, normalize, phases=phases, stage_host=True)
         sf.load(t_n1, t_prev)
@@ -337,6 +342,8 @@ def test_two_processes_drive_gpu_strips(built):
         pr.join(timeout=120)
         assert pr.exitcode == 0
     cases.assert_close(res["exact"], whole, "2 processes, exact mode, vs whole frame", maxabs=5e-4, rmse=5e-5)
+    cases.assert_close(res["exact-overlap"], whole, "2 processes, interior rows matched during the halo exchange",
+                       maxabs=5e-4, rmse=5e-5)
     d = np.abs(res["per-strip"] - whole)
     assert np.isfinite(res["per-strip"]).all() and (d > 1e-2).mean() < 0.2  # seam-order differences only
 

@@ -64,10 +64,21 @@ def _phases(O, p, state):
     def group(acc, active):
         O.strip_group(acc.numpy(), active.numpy(), state["cur"], state["prev"], None, SIGMA, p,
                       state["oy"], state["ngy"])
-    return match, commit, group
+
+    def match_rows(marks, cur, prev, oy, ngy, r0, rows):
+        # (the interior rows are matched while the halo is in flight: `prev` is read at call time, so a
+        # seam row matched too early would see the stale halo and the result would differ from the serial run)
+        step = p.patch_sz // 2
+        ngx = marks.numel() // ngy
+        m = np.zeros(rows * ngx, np.uint64)
+        state.update(cur=cur.numpy(), prev=prev.numpy(), oy=oy, ngy=ngy)
+        r = O.strip_match(m, cur.numpy().copy(), prev.numpy().copy(), None, SIGMA, p, oy + r0 * step, rows)
+        marks[r0 * ngx:(r0 + rows) * ngx].copy_(torch.from_numpy(m.view(np.int64)))
+        return r
+    return (match, commit, group, match_rows) if state.get("rows") else (match, commit, group)
 
 
-def _worker(rank, world, port, q, exact=False):
+def _worker(rank, world, port, q, exact=False, rows=False):
     _setup_paths()
     import oracle as O
     strips = importlib.import_module("bwd-nlkalman_amd.strips")
@@ -77,7 +88,7 @@ def _worker(rank, world, port, q, exact=False):
     acc_fn, norm_fn = _callbacks(O, p)
     sf = strips.StripFrame(rank, world, W, H, CH, p.patch_sz, max(p.search_sz_x, p.search_sz_t),
                            torch.device("cpu"), acc_fn, norm_fn,
-                           phases=_phases(O, p, {}) if exact else None)
+                           phases=_phases(O, p, {"rows": rows}) if exact else None)
     sf.load(torch.from_numpy(o1), torch.from_numpy(prev))
     sf.step()
     sf.step()  # a second step must give the same result (buffers fully re-initialised)
@@ -129,15 +140,17 @@ def test_strips_over_gloo(world, O, synth):
     assert np.isfinite(got).all()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_exact_strips_over_gloo_equal_serial_order(world, O, synth):
+@pytest.mark.parametrize("world,rows", [(2, False), (3, False), (2, True), (3, True)])
+def test_exact_strips_over_gloo_equal_serial_order(world, rows, O, synth):
     """Exact mode: all-gather of the mark words + whole-grid mask replay on every
-    rank. The result must equal the serial whole-frame order (not just PSNR-wise)."""
+    rank. The result must equal the serial whole-frame order (not just PSNR-wise).
+    rows=True: the interior target rows are matched while the previous-frame halo is still in flight
+    (it holds zeros then: a seam row matched too early would change the result)."""
     import cases
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, True)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, True, rows)) for r in range(world)]
     for pr in procs:
         pr.start()
     got = q.get(timeout=240)
