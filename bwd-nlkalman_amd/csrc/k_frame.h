@@ -3,31 +3,40 @@
 #pragma once
 #include "nlk_common.h"
 
-// HWC interleaved -> planar (one thread per pixel; reads ch consecutive floats)
-__global__ void k_hwc_to_planar(const float* __restrict__ src, float* __restrict__ dst,
-                                int npix, int ch) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix;
-       i += gridDim.x * blockDim.x) {
-    for (int c = 0; c < ch; ++c) dst[(size_t)c * npix + i] = src[(size_t)i * ch + c];
+// The layout work of a frame call in one pass over the pixels: up to three HWC images -> planar, the
+// row test of the validity map on the previous frame's channel 0 (see k_nan_cols), and the
+// accumulator cleared (whole-frame calls; a strip's accumulator belongs to the caller).
+__global__ void __launch_bounds__(256)
+k_layout(const float* __restrict__ cur, float* __restrict__ pl_cur, const float* __restrict__ prev,
+         float* __restrict__ pl_prev, const float* __restrict__ basic, float* __restrict__ pl_basic,
+         uint8_t* __restrict__ rowok, float* __restrict__ acc_zero, int w, int h, int ch, int psz, int planar) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const size_t npix = (size_t)w * h, i = (size_t)y * w + x;
+  if (planar) {  // (one channel: planar == interleaved, the images are used in place)
+    for (int c = 0; c < ch; ++c) {
+      pl_cur[c * npix + i] = cur[i * ch + c];
+      if (prev) pl_prev[c * npix + i] = prev[i * ch + c];
+      if (basic) pl_basic[c * npix + i] = basic[i * ch + c];
+    }
   }
+  if (prev) {
+    uint8_t ok = (x + psz <= w);
+    if (ok)
+      for (int j = 0; j < psz; ++j) {
+        const float v = prev[(i + j) * ch];
+        if (v != v) ok = 0;
+      }
+    rowok[i] = ok;
+  }
+  if (acc_zero)
+    for (int c = 0; c <= ch; ++c) acc_zero[c * npix + i] = 0.f;
 }
 
 // valid[y][x] = 1 iff the psz x psz patch of plane 0 of the previous frame with
 // origin (x,y) lies in the image and holds no NaN
 // (reference: src/nlkalman.c:605-609, 725-730 — only channel 0 is tested).
-// Two separable passes over a byte map: rows then columns.
-__global__ void k_nan_rows(const float* __restrict__ p0, uint8_t* __restrict__ rowok,
-                           int w, int h, int psz) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= w) return;
-  uint8_t ok = (x + psz <= w);
-  if (ok)
-    for (int i = 0; i < psz; ++i) {
-      const float v = p0[(size_t)y * w + x + i];
-      if (v != v) ok = 0;
-    }
-  rowok[(size_t)y * w + x] = ok;
-}
+// Two separable passes over a byte map: rows (in k_layout) then columns.
 __global__ void k_nan_cols(const uint8_t* __restrict__ rowok, uint8_t* __restrict__ valid,
                            int w, int h, int psz) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;

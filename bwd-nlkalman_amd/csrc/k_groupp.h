@@ -57,7 +57,7 @@ struct NlkPP {
   static constexpr int NOWN = PP / 4;                  // slots whose lanes own 4 coefficients each
   static constexpr int PB = (PSZ + NS - 1) / NS;       // aggregation: pixels per lane ...
   static constexpr int NBK = (PSZ + PB - 1) / PB;      // ... and blocks per row (lanes: PSZ x NBK)
-  static constexpr int WAVES = PSZ <= 12 ? 3 : 2;      // wavefronts per SIMD the registers are cut for
+  static constexpr int WAVES = PSZ <= 8 ? 4 : (PSZ <= 12 ? 3 : 2);      // wavefronts per SIMD the registers are cut for
   static __host__ __device__ constexpr int gains(int ch) { return ch * 2 * PSZ * PP; }
 };
 

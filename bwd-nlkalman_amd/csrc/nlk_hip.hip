@@ -72,20 +72,6 @@ int launch_group(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cu
   return nlk_launch_groupp_c(c, g, img, cur, prev, acc, active);
 }
 
-int to_planar(nlk_ctx* c, Buf& dst, const float* src, int npix, int ch, const float** out) {
-  if (ch == 1) {  // planar == interleaved
-    *out = src;
-    return NLK_OK;
-  }
-  int rc = reserve(c, dst, sizeof(float) * (size_t)npix * ch);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_hwc_to_planar, dim3(2048), dim3(256), 0, c->stream, src,
-                     (float*)dst.p, npix, ch);
-  HIPCHK(c, hipGetLastError());
-  *out = (const float*)dst.p;
-  return NLK_OK;
-}
-
 int check_images(nlk_ctx* c, const void* out, const void* cur, int w, int h, int ch) {
   if (!c) return fail(nullptr, NLK_EINVAL, "null context");
   if (!out || !cur) return fail(c, NLK_EINVAL, "null image pointer");
@@ -369,7 +355,7 @@ static NlkGeom band_geom(const NlkGeom& g, int r0, int rows) {
 // phase 0: checks, geometry, layout (planar copies + validity map), scratch. Runs on c->stream.
 static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* prev, const float* basic, int w,
                       int h, int ch, float sigma, const struct nlkalman_params* P, int oy, int ngy,
-                      int smoother, int nbands) {
+                      int smoother, int nbands, float* acc_zero = nullptr) {
   int rc = check_images(c, cur, cur, w, h, ch);
   if (rc) return rc;
   if (!P) return fail(c, NLK_EINVAL, "null parameters");
@@ -415,17 +401,27 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   g.gstride = ntagg_alloc;
 
   mark(c, 0);
-  // ---- layout: planar copies, validity map
-  if ((rc = to_planar(c, c->pl_cur, cur, npix, ch, &pl.img_cur))) return rc;
-  if (prev && (rc = to_planar(c, c->pl_prev, prev, npix, ch, &pl.img_prev))) return rc;
-  if (basic && (rc = to_planar(c, c->pl_basic, basic, npix, ch, &pl.img_basic))) return rc;
-  if (prev) {
-    if ((rc = reserve(c, c->rowok, npix)) || (rc = reserve(c, c->vmap, npix))) return rc;
+  // ---- layout: planar copies + the row test of the validity map (+ clearing the accumulator of a
+  // whole-frame call) in one kernel, the column test in a second
+  {
+    const bool planar = ch != 1;  // (one channel: planar == interleaved)
+    pl.img_cur = cur; pl.img_prev = prev; pl.img_basic = basic;
+    if (planar) {
+      if ((rc = reserve(c, c->pl_cur, sizeof(float) * (size_t)npix * ch))) return rc;
+      if (prev && (rc = reserve(c, c->pl_prev, sizeof(float) * (size_t)npix * ch))) return rc;
+      if (basic && (rc = reserve(c, c->pl_basic, sizeof(float) * (size_t)npix * ch))) return rc;
+      pl.img_cur = (const float*)c->pl_cur.p;
+      if (prev) pl.img_prev = (const float*)c->pl_prev.p;
+      if (basic) pl.img_basic = (const float*)c->pl_basic.p;
+    }
+    if (prev && ((rc = reserve(c, c->rowok, npix)) || (rc = reserve(c, c->vmap, npix)))) return rc;
     const dim3 grd((w + 255) / 256, h);
-    hipLaunchKernelGGL(k_nan_rows, grd, dim3(256), 0, c->stream, pl.img_prev, (uint8_t*)c->rowok.p,
-                       w, h, g.psz);
-    hipLaunchKernelGGL(k_nan_cols, grd, dim3(256), 0, c->stream, (const uint8_t*)c->rowok.p,
-                       (uint8_t*)c->vmap.p, w, h, g.psz);
+    if (planar || prev || acc_zero)
+      hipLaunchKernelGGL(k_layout, grd, dim3(256), 0, c->stream, cur, (float*)c->pl_cur.p, prev, (float*)c->pl_prev.p,
+                         basic, (float*)c->pl_basic.p, (uint8_t*)c->rowok.p, acc_zero, w, h, ch, g.psz, planar ? 1 : 0);
+    if (prev)
+      hipLaunchKernelGGL(k_nan_cols, grd, dim3(256), 0, c->stream, (const uint8_t*)c->rowok.p,
+                         (uint8_t*)c->vmap.p, w, h, g.psz);
     HIPCHK(c, hipGetLastError());
   }
   if ((rc = upload_tables(c, g.psz))) return rc;
@@ -588,12 +584,13 @@ static int frame_bands(const nlk_ctx* c, const NlkGeom& g) {
   return nb;
 }
 
-int nlk_dev_frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const float* prev,
-                             const float* basic, int w, int h, int ch, float sigma,
-                             const struct nlkalman_params* P, int oy, int ngy, int smoother) {
+// `clear`: the accumulator is cleared by the layout kernel (whole-frame calls)
+static int frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const float* prev,
+                            const float* basic, int w, int h, int ch, float sigma,
+                            const struct nlkalman_params* P, int oy, int ngy, int smoother, bool clear) {
   if (!acc) return fail(c, NLK_EINVAL, "null accumulator");
   NlkPlan pl;
-  int rc = plan_frame(c, pl, cur, prev, basic, w, h, ch, sigma, P, oy, ngy, smoother, 8);
+  int rc = plan_frame(c, pl, cur, prev, basic, w, h, ch, sigma, P, oy, ngy, smoother, 8, clear ? acc : nullptr);
   if (rc) return rc;
   const NlkGeom& g = pl.g;
   const int nb = frame_bands(c, g);
@@ -633,6 +630,12 @@ int nlk_dev_frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const flo
   HIPCHK(c, hipEventRecord(ev[3], st[1]));
   HIPCHK(c, hipStreamWaitEvent(st[0], ev[3], 0));
   return NLK_OK;
+}
+
+int nlk_dev_frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const float* prev,
+                             const float* basic, int w, int h, int ch, float sigma,
+                             const struct nlkalman_params* P, int oy, int ngy, int smoother) {
+  return frame_accumulate(c, acc, cur, prev, basic, w, h, ch, sigma, P, oy, ngy, smoother, false);
 }
 
 // ---- the same three phases as separate entry points (exact masks across GPUs)
@@ -704,12 +707,10 @@ static int run_frame(nlk_ctx* c, float* out, const float* cur, const float* prev
   if (P->patch_sz < 2) return fail(c, NLK_EUNSUP, "patch size %d not supported", P->patch_sz);
   const size_t accb = sizeof(float) * (size_t)w * h * (ch + 1);
   if ((rc = reserve(c, c->acc, accb))) return rc;
-  HIPCHK(c, hipMemsetAsync(c->acc.p, 0, accb, c->stream));
   const int step = P->patch_sz / 2;
   if (h < P->patch_sz || w < P->patch_sz) return fail(c, NLK_EINVAL, "image smaller than a patch");
   const int ngy = (h - P->patch_sz) / step + 1;
-  rc = nlk_dev_frame_accumulate(c, (float*)c->acc.p, cur, prev, basic, w, h, ch, sigma, P, 0,
-                                ngy, smoother);
+  rc = frame_accumulate(c, (float*)c->acc.p, cur, prev, basic, w, h, ch, sigma, P, 0, ngy, smoother, true);
   if (rc) return rc;
   rc = nlk_dev_frame_normalize(c, out, (const float*)c->acc.p, cur, w, h, ch, 0, h);
   return rc;
