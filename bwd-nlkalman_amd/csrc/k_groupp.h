@@ -302,9 +302,12 @@ k_groupp(const float* __restrict__ img,   // matching / statistics image (planar
         const float* img_c = img + c * npix;
         // S0/S1 image, S2/S3 previous frame, S4 squared image-previous difference: sums of
         // deviations from x0 (see the header)
-        float S[HP ? 5 : 2][PSZ], x0[PSZ];
+        // (the filter's Kalman branch uses no image statistics, reference :859-904: three sums there)
+        constexpr bool IMG = !HP || SMO;
+        constexpr int NSUM = (IMG ? 2 : 0) + (HP ? 3 : 0), P0 = IMG ? 2 : 0;  // previous-frame sums from P0
+        float S[NSUM][PSZ], x0[PSZ];
 #pragma unroll
-        for (int a = 0; a < (HP ? 5 : 2); ++a)
+        for (int a = 0; a < NSUM; ++a)
 #pragma unroll
           for (int r = 0; r < PSZ; ++r) S[a][r] = 0.f;
         nlk_f4 tot5 = nlk_f4{0.f, 0.f, 0.f, 0.f};  // previous frame over the group members (owners)
@@ -347,7 +350,7 @@ k_groupp(const float* __restrict__ img,   // matching / statistics image (planar
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                   const int r = 4 * j + e < PSZ ? 4 * j + e : 0;
-                  v4[e] = 4 * j + e < PSZ ? fmaf(gm, b[r] - x0[r], S[HP ? 2 : 0][r]) : 0.f;
+                  v4[e] = 4 * j + e < PSZ ? fmaf(gm, b[r] - x0[r], S[HP ? P0 : 0][r]) : 0.f;
                 }
                 ((nlk_f4*)red)[j] = v4;
               }
@@ -359,12 +362,14 @@ k_groupp(const float* __restrict__ img,   // matching / statistics image (planar
 #pragma unroll
             for (int r = 0; r < PSZ; ++r) {
               const float da = a[r] - x0[r], db = b[r] - x0[r];
-              S[0][r] += da;
-              S[1][r] = fmaf(da, da, S[1][r]);
-              S[2][r] += db;
-              S[3][r] = fmaf(db, db, S[3][r]);
+              if constexpr (IMG) {
+                S[0][r] += da;
+                S[1][r] = fmaf(da, da, S[1][r]);
+              }
+              S[P0][r] += db;
+              S[P0 + 1][r] = fmaf(db, db, S[P0 + 1][r]);
               const float df = db - da;  // reference: :769-783, smoother :1659-1667
-              S[4][r] = fmaf(vm * df, df, S[4][r]);
+              S[P0 + 2][r] = fmaf(vm * df, df, S[P0 + 2][r]);
             }
           } else {
 #pragma unroll
@@ -394,10 +399,11 @@ k_groupp(const float* __restrict__ img,   // matching / statistics image (planar
         x04 = owner ? *(const nlk_f4*)rd : nlk_f4{0.f, 0.f, 0.f, 0.f};  // (every slot holds the same x0)
         NLK_PP_SYNC();
 #pragma unroll
-        for (int st = 0; st < 5; ++st) {
+        for (int st = 0; st < 5; ++st) {  // tot[0..1] image, tot[2..4] previous frame
           tot[st] = nlk_f4{0.f, 0.f, 0.f, 0.f};
-          if (st < (HP ? 5 : 2)) {
-            put(S[st < (HP ? 5 : 2) ? st : 0]);
+          const int si = st < 2 ? (IMG ? st : -1) : (HP ? P0 + st - 2 : -1);
+          if (si >= 0) {
+            put(S[si >= 0 && si < NSUM ? si : 0]);
             tot[st] = sum_slots();
           }
         }
@@ -501,9 +507,9 @@ k_groupp(const float* __restrict__ img,   // matching / statistics image (planar
     NLK_PP_SYNC();
   };
   // a tile plane -> HBM (coalesced rows, untouched entries skipped), cleared for the next channel
-  const bool two_rows = rw <= 32;  // a narrow tile puts two rows on the 64 lanes
-  const int fx = two_rows ? (lane & 31) : lane, fy = two_rows ? (lane >> 5) : 0;
-  const int sx = two_rows ? 32 : 64, sy = two_rows ? 2 : 1;
+  // (a narrow tile puts two or four rows on the 64 lanes: fewer, fuller atomic instructions)
+  const int sx = rw <= 16 ? 16 : (rw <= 32 ? 32 : 64), sy = 64 / sx;
+  const int fx = lane & (sx - 1), fy = lane / sx;
   auto flush = [&](float* sp, int p, bool clear) {
     if (tl.slab) {  // deterministic mode: the plane as it stands, into this target's slab
       nlk_f4* dst = reinterpret_cast<nlk_f4*>(tl.slab + ((size_t)ti * (CH + 1) + p) * plane);

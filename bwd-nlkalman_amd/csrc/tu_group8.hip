@@ -39,9 +39,9 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
     const int rw_max = (tl.tgx - 1) * g.step + 2 * tl.wmax + g.psz;
     tl.rh_max = (tl.tgy - 1) * g.step + 2 * tl.wmax + g.psz;
     if (mfma) {
-      // one aggregation access = 4x4 pixels of each plane: row stride = 4 and plane
+      // one aggregation access = 4x4 pixels of each plane: row stride = 4 (mod 8) and plane
       // stride = 16 (mod 32 banks) make the 64 lanes hit every bank twice
-      tl.rwp = rw_max + ((4 - rw_max) % 32 + 32) % 32;
+      tl.rwp = rw_max + ((4 - rw_max) % 8 + 8) % 8;
       tl.plane = tl.rwp * tl.rh_max;
       tl.plane += ((16 - tl.plane) % 32 + 32) % 32;
     } else {
