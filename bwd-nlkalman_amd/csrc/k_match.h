@@ -40,44 +40,13 @@ __device__ inline uint64_t nlk_wave_or(uint64_t v) {
   return v;
 }
 
-// Distances + selection for one target whose window holds n <= 64*M candidates.
-// Leaves the k kept candidates, sorted, in sel[0..k).
-// (forced inline: as a real call the LDS tile pointer becomes a generic one, the candidate reads
-// turn into FLAT loads and the spatial search runs 3x slower)
+// Selection for one target whose window holds n <= 64*M candidates and whose sums of squared
+// differences are in acc[] (candidate lane + 64*m in acc[m]). Leaves the k kept candidates, sorted, in
+// sel[0..k).
 template <int PSZ, int CH, int M>
-__device__ __forceinline__ void nlk_match_target(const float* __restrict__ tile, int plane, int rwp,
-                                        const float* __restrict__ tgt, int tplane, int trw,
-                                        int cbase, int nwx, int n, int k, int x0, int y0,
-                                        uint64_t* __restrict__ surv, uint32_t* __restrict__ sel,
-                                        int lane) {
-  int cq[M];
-  float acc[M];
-#pragma unroll
-  for (int m = 0; m < M; ++m) {
-    const int i = min(lane + 64 * m, n - 1);
-    const int wy = i / nwx, wx = i - wy * nwx;
-    cq[m] = cbase + wy * rwp + wx;
-    acc[m] = 0.f;
-  }
-#pragma unroll 1
-  for (int hy = 0; hy < PSZ; ++hy) {
-#pragma clang fp contract(off)
-    // the target patch is wave-uniform (broadcast LDS reads, or scalar loads on
-    // the image path)
-    const float* trow = tgt + hy * trw;
-#pragma unroll
-    for (int hx = 0; hx < PSZ; ++hx)
-#pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const float tv = trow[c * tplane + hx];
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-          const float e = tile[c * plane + cq[m] + hy * rwp + hx] - tv;
-          const float e2 = e * e;
-          acc[m] = acc[m] + e2;
-        }
-      }
-  }
+__device__ __forceinline__ void nlk_match_select(const float (&acc)[M], int nwx, int n, int k, int x0, int y0,
+                                                 uint64_t* __restrict__ surv, uint32_t* __restrict__ sel,
+                                                 int lane) {
   uint32_t key[M];
   bool ok[M];
   const float norm = (float)(PSZ * PSZ * CH);
@@ -158,6 +127,104 @@ __device__ __forceinline__ void nlk_match_target(const float* __restrict__ tile,
     }
   }
   nlk_wave_lds_fence();
+}
+
+// Distances + selection for one target whose window holds n <= 64*M candidates.
+// Leaves the k kept candidates, sorted, in sel[0..k).
+// (forced inline: as a real call the LDS tile pointer becomes a generic one, the candidate reads
+// turn into FLAT loads and the spatial search runs 3x slower)
+template <int PSZ, int CH, int M>
+__device__ __forceinline__ void nlk_match_target(const float* __restrict__ tile, int plane, int rwp,
+                                        const float* __restrict__ tgt, int tplane, int trw,
+                                        int cbase, int nwx, int n, int k, int x0, int y0,
+                                        uint64_t* __restrict__ surv, uint32_t* __restrict__ sel,
+                                        int lane) {
+  int cq[M];
+  float acc[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int i = min(lane + 64 * m, n - 1);
+    const int wy = i / nwx, wx = i - wy * nwx;
+    cq[m] = cbase + wy * rwp + wx;
+    acc[m] = 0.f;
+  }
+#pragma unroll 1
+  for (int hy = 0; hy < PSZ; ++hy) {
+#pragma clang fp contract(off)
+    // the target patch is wave-uniform (broadcast LDS reads, or scalar loads on
+    // the image path)
+    const float* trow = tgt + hy * trw;
+#pragma unroll
+    for (int hx = 0; hx < PSZ; ++hx)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const float tv = trow[c * tplane + hx];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          const float e = tile[c * plane + cq[m] + hy * rwp + hx] - tv;
+          const float e2 = e * e;
+          acc[m] = acc[m] + e2;
+        }
+      }
+  }
+  nlk_match_select<PSZ, CH, M>(acc, nwx, n, k, x0, y0, surv, sel, lane);
+}
+
+// Distances of a block of BX x BY grid-adjacent targets with the same full window (side 2 wsz + 1,
+// n <= 128 candidates, lane + 64 m = candidate), all inside the LDS region. Targets half a patch apart
+// share three quarters of their pixels, and the squared difference of a pixel for a given candidate
+// OFFSET is the same number whichever target it is summed for: it is computed once per pixel of the
+// block's union and added to the accumulator of every target whose patch holds the pixel. Rows
+// ascending, columns ascending inside a row, channels innermost: every target still receives its terms
+// in the reference's (hy, hx, c) order with one rounding per subtract, multiply and add, i.e. the sums
+// are bit-identical to nlk_match_target's; subtractions and multiplications drop by 2.1x (4 x 2 blocks).
+template <int PSZ, int CH, int BX, bool B0, bool B1>
+__device__ __forceinline__ void nlk_block_rows(const float* __restrict__ tile, int plane, int rwp, int tbase,
+                                               const int (&cq)[2], int ry0, int ry1, float (&acc)[2][BX][2]) {
+  constexpr int step = PSZ / 2, UW = (BX - 1) * step + PSZ;
+#pragma unroll 1
+  for (int ry = ry0; ry < ry1; ++ry) {
+#pragma clang fp contract(off)
+    const float* trow = tile + tbase + ry * rwp;
+#pragma unroll
+    for (int rx = 0; rx < UW; ++rx)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const float tv = trow[c * plane + rx];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const float e = tile[c * plane + cq[m] + ry * rwp + rx] - tv;
+          const float e2 = e * e;
+#pragma unroll
+          for (int bx = 0; bx < BX; ++bx)
+            if (rx >= bx * step && rx < bx * step + PSZ) {
+              if (B0) acc[0][bx][m] = acc[0][bx][m] + e2;
+              if (B1) acc[1][bx][m] = acc[1][bx][m] + e2;
+            }
+        }
+      }
+  }
+}
+template <int PSZ, int CH, int BX>
+__device__ __forceinline__ void nlk_match_block(const float* __restrict__ tile, int plane, int rwp, int tbase,
+                                                int wsz, int n, int lane, float (&acc)[2][BX][2]) {
+  constexpr int step = PSZ / 2;
+  const int nwx = 2 * wsz + 1;
+  int cq[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int i = min(lane + 64 * m, n - 1);
+    const int wy = i / nwx, wx = i - wy * nwx;
+    cq[m] = tbase + (wy - wsz) * rwp + (wx - wsz);
+#pragma unroll
+    for (int by = 0; by < 2; ++by)
+#pragma unroll
+      for (int bx = 0; bx < BX; ++bx) acc[by][bx][m] = 0.f;
+  }
+  // (rows of the upper targets only, of both, of the lower targets only)
+  nlk_block_rows<PSZ, CH, BX, true, false>(tile, plane, rwp, tbase, cq, 0, step, acc);
+  nlk_block_rows<PSZ, CH, BX, true, true>(tile, plane, rwp, tbase, cq, step, PSZ, acc);
+  nlk_block_rows<PSZ, CH, BX, false, true>(tile, plane, rwp, tbase, cq, PSZ, PSZ + step, acc);
 }
 
 // Group membership, records and mark word of one target whose sorted k-NN list is in sel[0..k)
@@ -304,7 +371,8 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
   uint32_t* sel = sel_all + wave * tl.ksel_max;
   uint32_t* grp = grp_all + wave * g.gstride;
 
-  for (int tt = wave; tt < cx * cy; tt += NLK_BM_WAVES) {
+  // one target: distances over its own (possibly clipped) window
+  auto do_target = [&](int tt) {
     const int ty = tt / cx, tx = tt - ty * cx;
     const int gx = gx0 + tx, gy = gy0 + ty;
     const int px = gx * step, py = g.oy + gy * step;
@@ -320,7 +388,7 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
         if (lane == 0) gcoords[t * g.gstride] = nlk_pack_xy(px, py);
       }
       if (lane == 0) { tinfo[t] = info; marks[t] = 0; }
-      continue;
+      return;
     }
     const int wsz = (g.smoother || prev_p) ? g.wsz_t : g.wsz_x;
     const int x0 = max(px - wsz, 0), x1 = min(px + wsz, g.w - PSZ) + 1;
@@ -349,10 +417,60 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
       // window leaves the LDS region (a target without a valid previous patch in a
       // temporal frame): queued for k_bm_wide, which stages a window of its own
       if (lane == 0) wide_list[atomicAdd(wide_count, 1u)] = (uint32_t)t;
-      continue;
+      return;
     }
     nlk_match_epilogue(g, t, px, py, prev_p, k, sel, grp, vmap, topk, tinfo, gcoords, marks, lane);
     __builtin_amdgcn_wave_barrier();
+  };
+
+  // A wavefront takes blocks of BX x BY targets. A block whose targets all search the same full
+  // window of at most 128 candidates inside the LDS region (the bulk of a temporal frame) shares the
+  // squared differences between its targets (nlk_match_block); any other block - image border, a
+  // target without a valid previous patch in a temporal frame, spatial frames - goes target by target.
+  constexpr int BX = 4, BY = 2;
+  const int nbx = (tl.tgx + BX - 1) / BX, nby = (tl.tgy + BY - 1) / BY;
+  for (int blk = wave; blk < nbx * nby; blk += NLK_BM_WAVES) {
+    const int bty = blk / nbx, tx0 = (blk - bty * nbx) * BX, ty0 = bty * BY;
+    if (tx0 >= cx || ty0 >= cy) continue;
+    bool regular = tx0 + BX <= cx && ty0 + BY <= cy && g.npt > 1 && g.npx > 1;
+    int nprev = 0;
+    if (regular)
+      for (int j = 0; j < BX * BY; ++j)
+        nprev += __builtin_amdgcn_readlane(rec_prev, (ty0 + j / BX) * cx + tx0 + j % BX) ? 1 : 0;
+    const bool all_t = g.smoother || nprev == BX * BY;
+    regular = regular && (all_t || nprev == 0);
+    const int wsz = all_t ? g.wsz_t : g.wsz_x;
+    const int nwx = 2 * wsz + 1, n = nwx * nwx;
+    const int px0 = (gx0 + tx0) * step, py0 = g.oy + (gy0 + ty0) * step;
+    regular = regular && n <= 128 && wsz <= wmax && px0 - wsz >= rx0 && py0 - wsz >= ry0 &&
+              px0 + (BX - 1) * step + wsz + PSZ <= min(rx1, g.w) && py0 + (BY - 1) * step + wsz + PSZ <= min(ry1, g.h);
+    if (!regular) {
+      for (int j = 0; j < BX * BY; ++j) {
+        const int tx = tx0 + j % BX, ty = ty0 + j / BX;
+        if (tx < cx && ty < cy) do_target(ty * cx + tx);
+      }
+      continue;
+    }
+    float acc[2][BX][2];
+    nlk_match_block<PSZ, CH, BX>(tile, plane, rwp, (py0 - ry0) * rwp + (px0 - rx0), wsz, n, lane, acc);
+#pragma unroll 1
+    for (int j = 0; j < BX * BY; ++j) {
+      float a2[2] = {0.f, 0.f};
+#pragma unroll
+      for (int by = 0; by < BY; ++by)
+#pragma unroll
+        for (int bx = 0; bx < BX; ++bx)
+          if (j == by * BX + bx) { a2[0] = acc[by][bx][0]; a2[1] = acc[by][bx][1]; }
+      const int tx = tx0 + j % BX, ty = ty0 + j / BX;
+      const int gx = gx0 + tx, gy = gy0 + ty;
+      const int px = gx * step, py = g.oy + gy * step;
+      const size_t t = (size_t)gy * g.ngx + gx;
+      const int prev_p = __builtin_amdgcn_readlane(rec_prev, ty * cx + tx);
+      const int k = min(prev_p ? g.npt : g.npx, n);
+      nlk_match_select<PSZ, CH, 2>(a2, nwx, n, k, px - wsz, py - wsz, surv, sel, lane);
+      nlk_match_epilogue(g, t, px, py, prev_p, k, sel, grp, vmap, topk, tinfo, gcoords, marks, lane);
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 }
 
