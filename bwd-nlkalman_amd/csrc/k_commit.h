@@ -245,6 +245,117 @@ k_mask_commit_wave(const uint32_t* __restrict__ skewed, uint8_t* __restrict__ ac
 
 
 // ---------------------------------------------------------------------------
+// Reach 1 (8 x 8 patches with the default temporal radius: the steady state of the pipelines): the
+// replay one grid ROW per step instead of one diagonal per step.
+//
+// With R = 1 a target (i, j) is skipped iff it was marked by an active target of the row above
+// (columns i-1, i, i+1) or by its active left neighbour. Row j-1 is final when row j starts, so the marks
+// from above are three bit-plane ANDs and two one-bit shifts of whole rows: a = marked from above. Inside
+// the row, with x = active, ms = "marks its right neighbour": x_i = !a_i & !(x_{i-1} & ms_{i-1}); the
+// carry c_i = x_i & ms_i obeys c_i = g_i & !c_{i-1} with g = ms & ~a, i.e. inside every run of ones of g
+// the carries alternate 1, 0, 1, ... from the run's first bit. Bits at an even distance from the start of
+// their run are picked word-parallel with the run-start / add-carry trick (adding the even-positioned run
+// starts to g clears exactly the runs that start on even bits). A row of up to 2048 targets is 64 lanes
+// x 32 bits: 1-bit shifts across lanes by DPP wave_shr / wave_shl; a run that crosses a word boundary
+// enters the next word as its carry-in (one DPP move: a word's carry-out depends on its carry-in only if
+// the word is ALL ones, which takes the serial fix-up loop below). ~35 dependent vector instructions per
+// row of the grid instead of ~20 per target of its longest diagonal: 269 steps instead of 1015 at 1080p.
+// ---------------------------------------------------------------------------
+
+// bit planes of the mark words of every grid row: planes[(j * 4 + p) * 64 + word], p = 0: marks (i+1, j),
+// 1..3: marks (i-1, j+1), (i, j+1), (i+1, j+1); bit b of word w = column 32 w + b. All 64 words of a row
+// are written (zeros past the grid), launched over 2048 columns.
+__global__ void __launch_bounds__(256)
+k_marks_planes1(const uint64_t* __restrict__ marks, uint32_t* __restrict__ planes, int ngx) {
+  constexpr int R = 1, side = 3, centre = R * side + R;
+  const int j = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t fwd = i < ngx ? (uint32_t)(marks[(size_t)j * ngx + i] >> (centre + 1)) : 0u;
+  const int lane = threadIdx.x & 63, w0 = i >> 5;  // (i of lane 0 of the wavefront is a multiple of 64)
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const uint64_t b = __ballot((fwd >> p) & 1u);
+    if (lane == 0) *(uint64_t*)(planes + ((size_t)j * 4 + p) * 64 + w0) = b;
+  }
+}
+
+// One wavefront; lane = word of the row. A lone wavefront issues an instruction every ~6 cycles whatever
+// it is, so the loop is written for instruction count: fixed row strides (immediate offsets, no
+// predicates: planes and decisions are padded to whole batches), two register sets for the planes in
+// flight that swap roles (no copies).
+#define NLK_CR_BATCH 16  // rows per batch: the next batch's planes load while this one is replayed
+__global__ void __launch_bounds__(64)
+k_mask_commit_rows1(const uint32_t* __restrict__ planes, uint32_t* __restrict__ actbits, int ngx, int ngy) {
+  const int lane = threadIdx.x;
+  // columns of this word that exist
+  const int nb = ngx - 32 * lane;
+  const uint32_t colmask = nb <= 0 ? 0u : (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u));
+  auto from_prev = [](uint32_t v) {  // lane l <- lane l-1 (lane 0 <- 0)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+  };
+  auto from_next = [](uint32_t v) {  // lane l <- lane l+1 (lane 63 <- 0)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
+  };
+  constexpr int PF = NLK_CR_BATCH;
+  const uint32_t* pp = planes + lane;
+  uint32_t* ap = actbits + lane;
+  uint32_t a = 0;  // marked from above
+  auto load_batch = [&](uint32_t (&D)[PF][4], int jb) {
+    const uint32_t* q = pp + (size_t)jb * 256;
+#pragma unroll
+    for (int r = 0; r < PF; ++r)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) D[r][p] = q[(r * 4 + p) * 64];
+  };
+  auto run_batch = [&](const uint32_t (&D)[PF][4], int jb) {
+    uint32_t* o = ap + (size_t)jb * 64;
+#pragma unroll
+    for (int r = 0; r < PF; ++r) {  // (rows past the grid in the last batch: decisions land in the padding)
+      const uint32_t g = D[r][0] & ~a;
+      // carries, assuming no carry enters the word
+      const uint32_t sw = g & ~(g << 1);
+      const uint32_t er = g & ~(g + (sw & 0x55555555u));  // runs that start on an even bit
+      const uint32_t c0 = g & ((er & 0x55555555u) | (~er & 0xAAAAAAAAu));
+      uint32_t cout = c0 >> 31;
+      const uint64_t full = __ballot(g == 0xFFFFFFFFu);
+      if (full) {  // a word of ones hands its carry-in on: resolve those in lane order
+        uint64_t m = full;
+        while (m) {
+          const int l = __builtin_ctzll(m);
+          const uint32_t cin_l = l ? (uint32_t)__builtin_amdgcn_readlane((int)cout, l - 1) : 0u;
+          if (lane == l) cout = cin_l;  // (32 ones: the last carry equals the carry-in)
+          m &= m - 1;
+        }
+      }
+      const uint32_t cin = from_prev(cout);
+      const uint32_t low = g & ~(g + 1u);              // the run of ones at bit 0
+      const uint32_t c = c0 ^ (low & (0u - cin));       // an entering carry flips that run's pattern
+      const uint32_t cl = (c << 1) | cin;               // carry INTO every column
+      const uint32_t x = ~(a | cl) & colmask;
+      o[r * 64] = x;
+      // marks for the row below
+      const uint32_t ml = x & D[r][1], md = x & D[r][2], mr = x & D[r][3];
+      a = ((ml >> 1) | (from_next(ml) << 31)) | md | ((mr << 1) | (from_prev(mr) >> 31));
+    }
+  };
+  uint32_t P[PF][4], Q[PF][4];
+  load_batch(P, 0);
+  for (int j0 = 0; j0 < ngy; j0 += 2 * PF) {
+    load_batch(Q, j0 + PF);
+    run_batch(P, j0);
+    if (j0 + PF >= ngy) break;
+    load_batch(P, j0 + 2 * PF);
+    run_batch(Q, j0 + PF);
+  }
+}
+
+// bits -> the byte per target the group kernels read
+__global__ void __launch_bounds__(256)
+k_active_bytes(const uint32_t* __restrict__ actbits, uint8_t* __restrict__ active, int ngx) {
+  const int j = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i < ngx) active[(size_t)j * ngx + i] = (actbits[(size_t)j * 64 + (i >> 5)] >> (i & 31)) & 1u;
+}
+
+// ---------------------------------------------------------------------------
 // Any reach (R > 3: (2R+1)^2 neighbours do not fit a 64-bit mark word): the same time-stepped
 // replay driven by the group-coordinate lists themselves. One workgroup; thread = grid row (rows
 // tid, tid + 1024, ...); at step s row j looks at column s - (R+1) j. `active` is the mask: 1 until

@@ -43,10 +43,12 @@ __device__ inline uint64_t nlk_wave_or(uint64_t v) {
 // Selection for one target whose window holds n <= 64*M candidates and whose sums of squared
 // differences are in acc[] (candidate lane + 64*m in acc[m]). Leaves the k kept candidates, sorted, in
 // sel[0..k).
+// wxy[m] = (wy << 16) | wx of candidate lane + 64*m in its window: the same order as the window index
+// wy * nwx + wx, and no division when the kept candidates are turned into coordinates.
 template <int PSZ, int CH, int M>
-__device__ __forceinline__ void nlk_match_select(const float (&acc)[M], int nwx, int n, int k, int x0, int y0,
-                                                 uint64_t* __restrict__ surv, uint32_t* __restrict__ sel,
-                                                 int lane) {
+__device__ __forceinline__ void nlk_match_select(const float (&acc)[M], const uint32_t (&wxy)[M], int n, int k,
+                                                 int x0, int y0, uint64_t* __restrict__ surv,
+                                                 uint32_t* __restrict__ sel, int lane) {
   uint32_t key[M];
   bool ok[M];
   const float norm = (float)(PSZ * PSZ * CH);
@@ -106,9 +108,9 @@ __device__ __forceinline__ void nlk_match_select(const float (&acc)[M], int nwx,
     const bool mine = (be >> lane) & 1ull;
     const bool keep = ((less[m] >> lane) & 1ull) || (mine && my_tie < kk);
     const uint64_t bk = __ballot(keep);
-    if (keep) {  // survivors as one 64-bit sort key: distance bits above, window index below
+    if (keep) {  // survivors as one 64-bit sort key: distance bits above, window position below
       const int pos = npos + __popcll(bk & lt_mask);
-      surv[pos] = ((uint64_t)key[m] << 32) | (uint32_t)(lane + 64 * m);
+      surv[pos] = ((uint64_t)key[m] << 32) | wxy[m];
     }
     npos += __popcll(bk);
   }
@@ -121,9 +123,8 @@ __device__ __forceinline__ void nlk_match_select(const float (&acc)[M], int nwx,
     int rank = 0;
     for (int j = 0; j < k; ++j) rank += surv[j] < mine;
     if (p < k) {
-      const int mi = (int)(uint32_t)mine;
-      const int wy = mi / nwx, wx = mi - wy * nwx;
-      sel[rank] = nlk_pack_xy(x0 + wx, y0 + wy);
+      const uint32_t mi = (uint32_t)mine;
+      sel[rank] = nlk_pack_xy(x0 + (int)(mi & 0xFFFFu), y0 + (int)(mi >> 16));
     }
   }
   nlk_wave_lds_fence();
@@ -140,12 +141,14 @@ __device__ __forceinline__ void nlk_match_target(const float* __restrict__ tile,
                                         uint64_t* __restrict__ surv, uint32_t* __restrict__ sel,
                                         int lane) {
   int cq[M];
+  uint32_t wxy[M];
   float acc[M];
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     const int i = min(lane + 64 * m, n - 1);
     const int wy = i / nwx, wx = i - wy * nwx;
     cq[m] = cbase + wy * rwp + wx;
+    wxy[m] = ((uint32_t)wy << 16) | (uint32_t)wx;
     acc[m] = 0.f;
   }
 #pragma unroll 1
@@ -167,7 +170,7 @@ __device__ __forceinline__ void nlk_match_target(const float* __restrict__ tile,
         }
       }
   }
-  nlk_match_select<PSZ, CH, M>(acc, nwx, n, k, x0, y0, surv, sel, lane);
+  nlk_match_select<PSZ, CH, M>(acc, wxy, n, k, x0, y0, surv, sel, lane);
 }
 
 // Distances of a block of BX x BY grid-adjacent targets with the same full window (side 2 wsz + 1,
@@ -207,7 +210,8 @@ __device__ __forceinline__ void nlk_block_rows(const float* __restrict__ tile, i
 }
 template <int PSZ, int CH, int BX>
 __device__ __forceinline__ void nlk_match_block(const float* __restrict__ tile, int plane, int rwp, int tbase,
-                                                int wsz, int n, int lane, float (&acc)[2][BX][2]) {
+                                                int wsz, int n, int lane, float (&acc)[2][BX][2],
+                                                uint32_t (&wxy)[2]) {
   constexpr int step = PSZ / 2;
   const int nwx = 2 * wsz + 1;
   int cq[2];
@@ -215,6 +219,7 @@ __device__ __forceinline__ void nlk_match_block(const float* __restrict__ tile, 
   for (int m = 0; m < 2; ++m) {
     const int i = min(lane + 64 * m, n - 1);
     const int wy = i / nwx, wx = i - wy * nwx;
+    wxy[m] = ((uint32_t)wy << 16) | (uint32_t)wx;
     cq[m] = tbase + (wy - wsz) * rwp + (wx - wsz);
 #pragma unroll
     for (int by = 0; by < 2; ++by)
@@ -229,6 +234,8 @@ __device__ __forceinline__ void nlk_match_block(const float* __restrict__ tile, 
 
 // Group membership, records and mark word of one target whose sorted k-NN list is in sel[0..k)
 // (reference: src/nlkalman.c:725-732, 779-793, 857, 931; smoother :1669-1676, :1844).
+// STEP = grid step when known at compile time (no integer divisions), 0 = g.step.
+template <int STEP = 0>
 __device__ __forceinline__ void nlk_match_epilogue(const NlkGeom& g, size_t t, int px, int py, int prev_p,
                                           int k, const uint32_t* __restrict__ sel,
                                           uint32_t* __restrict__ grp,
@@ -236,7 +243,7 @@ __device__ __forceinline__ void nlk_match_epilogue(const NlkGeom& g, size_t t, i
                                           uint32_t* __restrict__ topk, NlkTarget* __restrict__ tinfo,
                                           uint32_t* __restrict__ gcoords,
                                           uint64_t* __restrict__ marks, int lane) {
-  const int step = g.step;
+  const int step = STEP ? STEP : g.step;
   NlkTarget info = {0, 0, 0, prev_p, {0ull, 0ull}};
   // --- group membership: the first ntagg kept candidates that have a valid
   // previous patch, or (none valid) the first ntagg kept candidates
@@ -419,7 +426,7 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
       if (lane == 0) wide_list[atomicAdd(wide_count, 1u)] = (uint32_t)t;
       return;
     }
-    nlk_match_epilogue(g, t, px, py, prev_p, k, sel, grp, vmap, topk, tinfo, gcoords, marks, lane);
+    nlk_match_epilogue<PSZ / 2>(g, t, px, py, prev_p, k, sel, grp, vmap, topk, tinfo, gcoords, marks, lane);
     __builtin_amdgcn_wave_barrier();
   };
 
@@ -452,7 +459,8 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
       continue;
     }
     float acc[2][BX][2];
-    nlk_match_block<PSZ, CH, BX>(tile, plane, rwp, (py0 - ry0) * rwp + (px0 - rx0), wsz, n, lane, acc);
+    uint32_t wxy[2];
+    nlk_match_block<PSZ, CH, BX>(tile, plane, rwp, (py0 - ry0) * rwp + (px0 - rx0), wsz, n, lane, acc, wxy);
 #pragma unroll 1
     for (int j = 0; j < BX * BY; ++j) {
       float a2[2] = {0.f, 0.f};
@@ -467,8 +475,8 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
       const size_t t = (size_t)gy * g.ngx + gx;
       const int prev_p = __builtin_amdgcn_readlane(rec_prev, ty * cx + tx);
       const int k = min(prev_p ? g.npt : g.npx, n);
-      nlk_match_select<PSZ, CH, 2>(a2, nwx, n, k, px - wsz, py - wsz, surv, sel, lane);
-      nlk_match_epilogue(g, t, px, py, prev_p, k, sel, grp, vmap, topk, tinfo, gcoords, marks, lane);
+      nlk_match_select<PSZ, CH, 2>(a2, wxy, n, k, px - wsz, py - wsz, surv, sel, lane);
+      nlk_match_epilogue<PSZ / 2>(g, t, px, py, prev_p, k, sel, grp, vmap, topk, tinfo, gcoords, marks, lane);
       __builtin_amdgcn_wave_barrier();
     }
   }
@@ -536,7 +544,7 @@ k_bm_wide(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
     else
       nlk_match_target<PSZ, CH, MAXM>(tile, plane, rwp, tl_tgt, plane, rwp, 0, nwx, n, k, x0, y0,
                                       surv, sel, lane);
-    nlk_match_epilogue(g, t, px, py, prev_p, k, sel, grp, vmap, topk, tinfo, gcoords, marks, lane);
+    nlk_match_epilogue<PSZ / 2>(g, t, px, py, prev_p, k, sel, grp, vmap, topk, tinfo, gcoords, marks, lane);
     __builtin_amdgcn_wave_barrier();
   }
 }

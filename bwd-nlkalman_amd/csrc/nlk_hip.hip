@@ -507,6 +507,20 @@ static int commit_rows(nlk_ctx* c, hipStream_t stream, const uint64_t* marks, ui
     HIPCHK(c, hipMemsetAsync(active + (size_t)first * ngx, 1, (size_t)nrows * ngx, stream));
     return NLK_OK;
   }
+  if (R == 1 && first == 0 && ngx <= 2048 && !getenv("NLK_COMMIT_WAVE") && !getenv("NLK_COMMIT_LDS")) {
+    // reach 1: one grid row per step on bit planes (k_commit.h); both arrays padded to whole batches
+    const int rows_pad = (nrows + NLK_CR_BATCH - 1) / NLK_CR_BATCH * NLK_CR_BATCH + 2 * NLK_CR_BATCH;
+    int rc = reserve(c, c->skew, sizeof(uint32_t) * (size_t)rows_pad * 5 * 64);  // 4 planes + the decisions
+    if (rc) return rc;
+    uint32_t* planes = (uint32_t*)c->skew.p;
+    uint32_t* actbits = planes + (size_t)rows_pad * 4 * 64;
+    hipLaunchKernelGGL(k_marks_planes1, dim3(8, nrows), dim3(256), 0, stream, marks, planes, ngx);
+    hipLaunchKernelGGL(k_mask_commit_rows1, dim3(1), dim3(64), 0, stream, (const uint32_t*)planes, actbits, ngx, nrows);
+    hipLaunchKernelGGL(k_active_bytes, dim3((ngx + 255) / 256, nrows), dim3(256), 0, stream, (const uint32_t*)actbits,
+                       active, ngx);
+    HIPCHK(c, hipGetLastError());
+    return NLK_OK;
+  }
   if (R <= 3 && (first != 0 || !getenv("NLK_COMMIT_LDS"))) {
     // one lane per grid row, up to 1024 rows per launch; more rows in pieces that start with the
     // previous piece's last R rows as context (k_commit.h)
