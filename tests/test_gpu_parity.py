@@ -408,6 +408,40 @@ def test_banded_mask_replay_is_exact(ctx, built, O, synth, monkeypatch, band):
     assert 0.2 < 1 - r1["active"].mean() < 0.5   # (the skip really is exercised)
 
 
+@pytest.mark.parametrize("reach", [1, 2])
+def test_mask_replay_on_synthetic_mark_words(ctx, O, monkeypatch, reach):
+    """The processed-mask replay alone, on mark words no image produces: dense marks, rows where every
+    target marks its right neighbour (runs of ones that fill whole 32-bit words, the carry fix-up of
+    k_mask_commit_rows1), grid widths around the word and lane limits. Reach 1 runs the row replay on
+    bit planes, NLK_COMMIT_WAVE=1 the diagonal replay; both must equal the oracle's serial loop."""
+    rng = np.random.default_rng(7 + reach)
+    side = 2 * reach + 1
+    shapes = [(1, 1), (31, 5), (32, 9), (33, 17), (64, 3), (65, 40), (479, 37), (512, 8), (1000, 13), (2048, 5),
+              (2049, 4)]
+    for ngx, ngy in shapes:
+        for density, right in ((0.5, 0.5), (0.9, 0.97), (0.15, 1.0), (1.0, 1.0)):
+            bits = rng.random((ngx * ngy, side * side)) < density
+            c = reach * side + reach
+            bits[:, c + 1] = rng.random(ngx * ngy) < right   # (di = +1, dj = 0)
+            if right == 1.0 and density < 1.0:                # some rows with nothing from above: pure runs
+                bits[:, c + 2:] &= (rng.random((ngx * ngy, 1)) < 0.3)
+            marks = (bits.astype(np.uint64) << np.arange(side * side, dtype=np.uint64)).sum(axis=1).astype(np.uint64)
+            want = O.mask_commit(marks, ngx, ngy, reach)
+            d_marks = ctx.upload(marks)
+            for wave in (False, True):
+                if wave:
+                    monkeypatch.setenv("NLK_COMMIT_WAVE", "1")
+                else:
+                    monkeypatch.delenv("NLK_COMMIT_WAVE", raising=False)
+                d_active = ctx.upload(np.full(ngx * ngy, 7, np.uint8))
+                ctx.mask_commit(d_marks, ngx, ngy, reach, d_active)
+                got = ctx.download(d_active, (ngx * ngy,), np.uint8)
+                ctx.free(d_active)
+                assert np.array_equal(got, want), (ngx, ngy, density, right, wave, int((got != want).sum()))
+            ctx.free(d_marks)
+    monkeypatch.delenv("NLK_COMMIT_WAVE", raising=False)
+
+
 def test_group_kernels_agree_matrix_vs_dpp(ctx, built, synth, monkeypatch):
     """The 8x8 group kernel has two implementations: k_group8m (DCTs on the f32
     matrix cores, the default) and k_group8 (registers + DPP, NLK_GROUP_DPP=1).
