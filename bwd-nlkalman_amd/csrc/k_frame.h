@@ -46,6 +46,16 @@ __global__ void k_nan_cols(const uint8_t* __restrict__ rowok, uint8_t* __restric
     for (int i = 0; i < psz; ++i) ok &= rowok[(size_t)(y + i) * w + x];
   valid[(size_t)y * w + x] = ok;
 }
+// the same on four pixels per thread (w % 4 == 0: rows of 32-bit words of 0 / 1 bytes)
+__global__ void k_nan_cols4(const uint32_t* __restrict__ rowok, uint32_t* __restrict__ valid,
+                            int w4, int h, int psz) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w4) return;
+  uint32_t ok = (y + psz <= h) ? 0x01010101u : 0u;
+  if (ok)
+    for (int i = 0; i < psz; ++i) ok &= rowok[(size_t)(y + i) * w4 + x];
+  valid[(size_t)y * w4 + x] = ok;
+}
 
 // out = acc_c / acc_w where acc_w > 1e-6 else the input frame
 // (reference: src/nlkalman.c:939-942, 1853-1856; the double literal 1e-6 there

@@ -419,7 +419,10 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
     if (planar || prev || acc_zero)
       hipLaunchKernelGGL(k_layout, grd, dim3(256), 0, c->stream, cur, (float*)c->pl_cur.p, prev, (float*)c->pl_prev.p,
                          basic, (float*)c->pl_basic.p, (uint8_t*)c->rowok.p, acc_zero, w, h, ch, g.psz, planar ? 1 : 0);
-    if (prev)
+    if (prev && w % 4 == 0)
+      hipLaunchKernelGGL(k_nan_cols4, dim3((w / 4 + 255) / 256, h), dim3(256), 0, c->stream, (const uint32_t*)c->rowok.p,
+                         (uint32_t*)c->vmap.p, w / 4, h, g.psz);
+    else if (prev)
       hipLaunchKernelGGL(k_nan_cols, grd, dim3(256), 0, c->stream, (const uint8_t*)c->rowok.p,
                          (uint8_t*)c->vmap.p, w, h, g.psz);
     HIPCHK(c, hipGetLastError());
