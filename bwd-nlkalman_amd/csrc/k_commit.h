@@ -5,12 +5,17 @@
 // In the reference a target is skipped when an EARLIER, non-skipped target's
 // group contained it. Whether a target is skipped therefore depends only on
 // integer records (group coordinates, np0) that the matching kernel already
-// produced for every target, not on any filtered pixel. A marking group
-// reaches at most R grid cells, so the serial order can be replayed as a
-// wavefront: target (i, j) is decided at time i + (R+1)*j, when every target
-// that can mark it has already been decided. One workgroup, one thread per
-// grid row (RPT rows when the grid has more than 1024 rows), one barrier per
-// time step.
+// produced for every target, not on any filtered pixel. Four replays, all exact:
+//   k_mask_commit_rows1   reach 1 (the steady state of the pipelines): one grid ROW per step on bit
+//                         planes, a carry chain per row solved word-parallel (below)
+//   k_mask_commit_wave<R> reach <= 3: anti-diagonal wavefront, lane = grid row, marks handed down by DPP
+//   k_mask_commit<RPT>    the same wavefront with the mask as an LDS bitmap (first version, kept
+//                         for comparison)
+//   k_mask_commit_lists   any reach, from the group-coordinate lists
+// The wavefront replays: a marking group reaches at most R grid cells, so target (i, j) can be decided
+// at time i + (R+1)*j, when every target that can mark it has already been decided. k_mask_commit:
+// one workgroup, one thread per grid row (RPT rows when the grid has more than 1024 rows), one barrier
+// per time step.
 //
 // The mask lives in LDS as one bit per grid target (only grid-aligned
 // coordinates are ever tested). Only FORWARD marks (targets later in raster
