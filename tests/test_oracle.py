@@ -214,3 +214,67 @@ def test_oracle_edge_cases(O):
     assert np.abs(out - 100).max() < 1e-3
     t0 = tr["topk"][0][:tr["nsel"][0]]
     assert (t0[:5] == np.array([0, 1, 2, 3, 4])).all()      # ties keep raster (window) order
+
+
+# ------------------------------------------------------------ the row formulation of the mask replay
+
+def _rows_replay_words(marks, ngx, ngy):
+    """numpy restatement of k_mask_commit_rows1 (csrc/k_commit.h), word for word: 32 columns per uint32
+    word, run-start / add-carry parity trick per word, carry-in across words with the all-ones fix-up."""
+    nw = (ngx + 31) // 32
+    fwd = (marks.reshape(ngy, ngx) >> np.uint64(5)).astype(np.uint32)   # reach 1: bits after the centre bit
+
+    def planes(j):
+        out = np.zeros((4, nw), np.uint32)
+        for p in range(4):
+            bits = (fwd[j] >> np.uint32(p)) & np.uint32(1)
+            for i in np.nonzero(bits)[0]:
+                out[p, i >> 5] |= np.uint32(1) << np.uint32(i & 31)
+        return out
+
+    colmask = np.zeros(nw, np.uint32)
+    for wd in range(nw):
+        nb = ngx - 32 * wd
+        colmask[wd] = 0xFFFFFFFF if nb >= 32 else (1 << nb) - 1
+    E, Od, ONES = np.uint32(0x55555555), np.uint32(0xAAAAAAAA), np.uint32(0xFFFFFFFF)
+    a = np.zeros(nw, np.uint32)
+    act = np.zeros((ngy, ngx), np.uint8)
+    with np.errstate(over="ignore"):
+        for j in range(ngy):
+            ms, ml, md, mr = planes(j)
+            g = ms & ~a
+            sw = g & ~(g << np.uint32(1))
+            er = g & ~(g + (sw & E))
+            c0 = g & ((er & E) | (~er & Od))
+            cout = c0 >> np.uint32(31)
+            for wd in np.nonzero(g == ONES)[0]:          # ascending: a word of ones hands its carry-in on
+                cout[wd] = cout[wd - 1] if wd else 0
+            cin = np.concatenate(([0], cout[:-1])).astype(np.uint32)
+            low = g & ~(g + np.uint32(1))
+            c = c0 ^ (low & (np.uint32(0) - cin))
+            cl = (c << np.uint32(1)) | cin
+            x = ~(a | cl) & colmask
+            for i in range(ngx):
+                act[j, i] = (x[i >> 5] >> np.uint32(i & 31)) & 1
+            xl, xd, xr = x & ml, x & md, x & mr
+            nxt = np.concatenate((xl[1:], [0])).astype(np.uint32)
+            prv = np.concatenate(([0], xr[:-1])).astype(np.uint32)
+            a = ((xl >> np.uint32(1)) | (nxt << np.uint32(31))) | xd | ((xr << np.uint32(1)) | (prv >> np.uint32(31)))
+    return act.ravel()
+
+
+def test_row_formulation_of_the_mask_replay(O):
+    """The GPU replays the reach-1 processed mask one grid ROW per step as a word-parallel carry chain
+    (k_mask_commit_rows1). Its arithmetic, restated on uint32 words, must give the serial loop's decisions
+    (reference: src/nlkalman.c:597-600, 930-931) — also for rows whose marks fill whole words."""
+    rng = np.random.default_rng(5)
+    for ngx, ngy in ((1, 1), (31, 4), (32, 6), (33, 9), (64, 3), (97, 12), (130, 5)):
+        for density, right in ((0.5, 0.5), (0.9, 0.97), (0.15, 1.0), (1.0, 1.0)):
+            bits = rng.random((ngx * ngy, 9)) < density
+            bits[:, 5] = rng.random(ngx * ngy) < right          # (di = +1, dj = 0)
+            if right == 1.0 and density < 1.0:
+                bits[:, 6:] &= (rng.random((ngx * ngy, 1)) < 0.3)
+            marks = (bits.astype(np.uint64) << np.arange(9, dtype=np.uint64)).sum(axis=1).astype(np.uint64)
+            want = O.mask_commit(marks, ngx, ngy, 1)
+            got = _rows_replay_words(marks, ngx, ngy)
+            assert np.array_equal(got, want), (ngx, ngy, density, right)
