@@ -33,6 +33,7 @@ struct NlkTile {
   int rwp, rh_max;    // LDS region: padded row stride (floats) / rows
   int ksel_max;       // capacity of the per-wave survivor arrays
   int halo;           // search halo held in LDS (windows reaching further read HBM/L2)
+  int block;          // 4 x 2-target blocks share their squared differences (0: NLK_MATCH_NOBLOCK, target by target)
 };
 
 __device__ inline uint64_t nlk_wave_or(uint64_t v) {
@@ -443,7 +444,7 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
   for (int blk = wave; blk < nbx * nby; blk += NLK_BM_WAVES) {
     const int bty = blk / nbx, tx0 = (blk - bty * nbx) * BX, ty0 = bty * BY;
     if (tx0 >= cx || ty0 >= cy) continue;
-    bool regular = tx0 + BX <= cx && ty0 + BY <= cy && g.npt > 1 && g.npx > 1;
+    bool regular = tl.block && tx0 + BX <= cx && ty0 + BY <= cy && g.npt > 1 && g.npx > 1;
     int nprev = 0;
     if (regular)
       for (int j = 0; j < BX * BY; ++j)

@@ -443,6 +443,7 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   tl.tgx = getenv("NLK_MTX") ? atoi(getenv("NLK_MTX")) : 8;
   tl.tgy = getenv("NLK_MTY") ? atoi(getenv("NLK_MTY")) : 4;
   tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
+  tl.block = getenv("NLK_MATCH_NOBLOCK") ? 0 : 1;
   // LDS holds the halo of the dominant window; its row stride = window width
   // (mod 32): candidate i of a window then sits on bank i mod 32, so a
   // wavefront's 64 candidate reads are conflict free

@@ -408,6 +408,31 @@ def test_banded_mask_replay_is_exact(ctx, built, O, synth, monkeypatch, band):
     assert 0.2 < 1 - r1["active"].mean() < 0.5   # (the skip really is exercised)
 
 
+def test_block_matching_equals_target_by_target(ctx, built, synth, monkeypatch):
+    """k_bm_topk shares the squared differences inside blocks of 4 x 2 targets (nlk_match_block);
+    NLK_MATCH_NOBLOCK=1 runs every target on its own (nlk_match_target). Same per-target summation
+    order, so ALL records - every target's sorted k-NN list, group, counters, mark decisions - must be
+    identical, for the filter with and without a basic estimate, the smoother, and with NaN holes."""
+    w, h, ch, sigma = 1000, 560, 3, 20.0
+    n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, 21)
+    o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+    p1, p2, p3 = (built.default_params(sigma, m) for m in (built.FLT1, built.FLT2, built.SMO1))
+    prev, _ = _dev_frame(ctx, False, o0, None, None, sigma, p1)
+    holes = prev.copy()
+    holes[100:140, 300:420] = np.nan
+    holes[:, :2] = np.nan
+    calls = [(False, o1, prev, None, p1), (False, o1, holes, None, p1), (False, n1, prev, o1, p2),
+             (True, o1, prev, None, p3), (True, o1, holes, None, p3)]
+    for smo, cur, pv, basic, p in calls:
+        monkeypatch.delenv("NLK_MATCH_NOBLOCK", raising=False)
+        _, ra = _dev_frame(ctx, smo, cur, pv, basic, sigma, p)
+        monkeypatch.setenv("NLK_MATCH_NOBLOCK", "1")
+        _, rb = _dev_frame(ctx, smo, cur, pv, basic, sigma, p)
+        for f in ("active", "nsel", "np0", "nagg", "topk", "gcoords"):
+            assert np.array_equal(ra[f], rb[f]), f
+    monkeypatch.delenv("NLK_MATCH_NOBLOCK", raising=False)
+
+
 @pytest.mark.parametrize("reach", [1, 2])
 def test_mask_replay_on_synthetic_mark_words(ctx, O, monkeypatch, reach):
     """The processed-mask replay alone, on mark words no image produces: dense marks, rows where every

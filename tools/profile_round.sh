@@ -16,6 +16,9 @@ NLK_DETERMINISTIC=1 python3 $ROOT/bench.py --no-cpu > $OUT/bench_C2_deterministi
 NLK_DETERMINISTIC=1 python3 $ROOT/bench.py --no-cpu --workload C3 > $OUT/bench_C3_deterministic.json 2>/dev/null
 NLK_GROUP_PACKED=1 python3 $ROOT/bench.py --no-cpu > $OUT/bench_C2_packed.json 2>/dev/null
 NLK_GROUP12_ROWS=1 python3 $ROOT/bench.py --no-cpu --workload C3 > $OUT/bench_C3_rows.json 2>/dev/null
+NLK_MATCH_NOBLOCK=1 python3 $ROOT/bench.py --no-cpu > $OUT/bench_C2_noblock.json 2>/dev/null
+NLK_MATCH_NOBLOCK=1 python3 $ROOT/bench.py --no-cpu --workload C3 > $OUT/bench_C3_noblock.json 2>/dev/null
+NLK_COMMIT_WAVE=1 python3 $ROOT/bench.py --no-cpu > $OUT/bench_C2_commit_wave.json 2>/dev/null
 for W in C2 C3; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -o s -- python3 $ROOT/bench.py --no-cpu --workload $W > $OUT/bench_${W}_under_rocprof.json 2>/dev/null
   i=0
