@@ -187,8 +187,8 @@ k_mask_commit_wave(const uint32_t* __restrict__ skewed, uint8_t* __restrict__ ac
           const int sp = s0 + e - 1;  // producing step
           uint32_t acc = 0;
 #pragma unroll
-          for (int dj = lane + 1; dj <= R; ++dj)  // source lane 64 + lane - dj of the previous wavefront
-            if (sp >= 0)
+          for (int dj = 1; dj <= R; ++dj)  // dj > lane: source lane 64 + lane - dj of the previous wavefront
+            if (dj > lane && sp >= 0)
               acc |= ((edge[wave - 1][sp % NLK_CW_RING][R + lane - dj] >> ((dj - 1) * side)) & rowmask)
                      << (skew * dj - 1 - R);
           above[e] = acc;
