@@ -9,7 +9,8 @@
 // reference's element order (hy, hx, c) with one rounding per subtract, multiply
 // and add, so that the ranking is reproducible bit for bit by the CPU
 // restatement. A wavefront takes a block of 4 x 2 targets: where all eight search
-// the same full window of <= 128 candidates (the bulk of a temporal frame) the
+// the same full window of <= 448 candidates (the bulk of any frame: 121 in a
+// temporal one, 441 in a spatial one) the
 // squared differences of the pixels they share are computed once and added to
 // each target's sum in that target's own order (nlk_match_block: identical sums,
 // 2.1x fewer subtractions, multiplications and LDS reads); otherwise one target at
@@ -24,6 +25,10 @@
 #pragma once
 #include "nlk_common.h"
 
+#include <type_traits>
+#ifndef NLK_BM_BLOCK7
+#define NLK_BM_BLOCK7 1  // spatial windows (<= 448 candidates) in blocks too
+#endif
 #define NLK_BM_THREADS 256
 #define NLK_BM_WAVES (NLK_BM_THREADS / 64)
 
@@ -179,16 +184,16 @@ __device__ __forceinline__ void nlk_match_target(const float* __restrict__ tile,
 }
 
 // Distances of a block of BX x BY grid-adjacent targets with the same full window (side 2 wsz + 1,
-// n <= 128 candidates, lane + 64 m = candidate), all inside the LDS region. Targets half a patch apart
+// n <= 64 M candidates, lane + 64 m = candidate), all inside the LDS region. Targets half a patch apart
 // share three quarters of their pixels, and the squared difference of a pixel for a given candidate
 // OFFSET is the same number whichever target it is summed for: it is computed once per pixel of the
 // block's union and added to the accumulator of every target whose patch holds the pixel. Rows
 // ascending, columns ascending inside a row, channels innermost: every target still receives its terms
 // in the reference's (hy, hx, c) order with one rounding per subtract, multiply and add, i.e. the sums
 // are bit-identical to nlk_match_target's; subtractions and multiplications drop by 2.1x (4 x 2 blocks).
-template <int PSZ, int CH, int BX, bool B0, bool B1>
+template <int PSZ, int CH, int BX, int M, bool B0, bool B1>
 __device__ __forceinline__ void nlk_block_rows(const float* __restrict__ tile, int plane, int rwp, int tbase,
-                                               const int (&cq)[2], int ry0, int ry1, float (&acc)[2][BX][2]) {
+                                               const int (&cq)[M], int ry0, int ry1, float (&acc)[2][BX][M]) {
   constexpr int step = PSZ / 2, UW = (BX - 1) * step + PSZ;
 #pragma unroll 1
   for (int ry = ry0; ry < ry1; ++ry) {
@@ -200,7 +205,7 @@ __device__ __forceinline__ void nlk_block_rows(const float* __restrict__ tile, i
       for (int c = 0; c < CH; ++c) {
         const float tv = trow[c * plane + rx];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < M; ++m) {
           const float e = tile[c * plane + cq[m] + ry * rwp + rx] - tv;
           const float e2 = e * e;
 #pragma unroll
@@ -213,15 +218,15 @@ __device__ __forceinline__ void nlk_block_rows(const float* __restrict__ tile, i
       }
   }
 }
-template <int PSZ, int CH, int BX>
+template <int PSZ, int CH, int BX, int M>
 __device__ __forceinline__ void nlk_match_block(const float* __restrict__ tile, int plane, int rwp, int tbase,
-                                                int wsz, int n, int lane, float (&acc)[2][BX][2],
-                                                uint32_t (&wxy)[2]) {
+                                                int wsz, int n, int lane, float (&acc)[2][BX][M],
+                                                uint32_t (&wxy)[M]) {
   constexpr int step = PSZ / 2;
   const int nwx = 2 * wsz + 1;
-  int cq[2];
+  int cq[M];
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
+  for (int m = 0; m < M; ++m) {
     const int i = min(lane + 64 * m, n - 1);
     const int wy = i / nwx, wx = i - wy * nwx;
     wxy[m] = ((uint32_t)wy << 16) | (uint32_t)wx;
@@ -232,9 +237,9 @@ __device__ __forceinline__ void nlk_match_block(const float* __restrict__ tile, 
       for (int bx = 0; bx < BX; ++bx) acc[by][bx][m] = 0.f;
   }
   // (rows of the upper targets only, of both, of the lower targets only)
-  nlk_block_rows<PSZ, CH, BX, true, false>(tile, plane, rwp, tbase, cq, 0, step, acc);
-  nlk_block_rows<PSZ, CH, BX, true, true>(tile, plane, rwp, tbase, cq, step, PSZ, acc);
-  nlk_block_rows<PSZ, CH, BX, false, true>(tile, plane, rwp, tbase, cq, PSZ, PSZ + step, acc);
+  nlk_block_rows<PSZ, CH, BX, M, true, false>(tile, plane, rwp, tbase, cq, 0, step, acc);
+  nlk_block_rows<PSZ, CH, BX, M, true, true>(tile, plane, rwp, tbase, cq, step, PSZ, acc);
+  nlk_block_rows<PSZ, CH, BX, M, false, true>(tile, plane, rwp, tbase, cq, PSZ, PSZ + step, acc);
 }
 
 // Group membership, records and mark word of one target whose sorted k-NN list is in sel[0..k)
@@ -310,7 +315,7 @@ __device__ __forceinline__ void nlk_match_epilogue(const NlkGeom& g, size_t t, i
 }
 
 template <int PSZ, int CH, int MAXM>
-__global__ void __launch_bounds__(NLK_BM_THREADS)
+__global__ void __launch_bounds__(NLK_BM_THREADS, MAXM == 7 ? 3 : 1)  // (7 rounds in blocks: 168 registers, the LDS tile allows 3 wavefronts per SIMD)
 k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGeom g,
           NlkTile tl, uint32_t* __restrict__ topk, NlkTarget* __restrict__ tinfo,
           uint32_t* __restrict__ gcoords, uint64_t* __restrict__ marks,
@@ -436,9 +441,10 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
   };
 
   // A wavefront takes blocks of BX x BY targets. A block whose targets all search the same full
-  // window of at most 128 candidates inside the LDS region (the bulk of a temporal frame) shares the
-  // squared differences between its targets (nlk_match_block); any other block - image border, a
-  // target without a valid previous patch in a temporal frame, spatial frames - goes target by target.
+  // window of at most 448 candidates inside the LDS region (the bulk of a frame) shares the squared
+  // differences between its targets (nlk_match_block, two or seven rounds of 64 candidates); any other
+  // block - image border, a target without a valid previous patch in a temporal frame, windows of more
+  // than 448 candidates - goes target by target.
   constexpr int BX = 4, BY = 2;
   const int nbx = (tl.tgx + BX - 1) / BX, nby = (tl.tgy + BY - 1) / BY;
   for (int blk = wave; blk < nbx * nby; blk += NLK_BM_WAVES) {
@@ -454,7 +460,8 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
     const int wsz = all_t ? g.wsz_t : g.wsz_x;
     const int nwx = 2 * wsz + 1, n = nwx * nwx;
     const int px0 = (gx0 + tx0) * step, py0 = g.oy + (gy0 + ty0) * step;
-    regular = regular && n <= 128 && wsz <= wmax && px0 - wsz >= rx0 && py0 - wsz >= ry0 &&
+    constexpr int MB = (MAXM >= 7 && NLK_BM_BLOCK7) ? 7 : 2;  // rounds of 64 candidates a block may take
+    regular = regular && n <= 64 * MB && wsz <= wmax && px0 - wsz >= rx0 && py0 - wsz >= ry0 &&
               px0 + (BX - 1) * step + wsz + PSZ <= min(rx1, g.w) && py0 + (BY - 1) * step + wsz + PSZ <= min(ry1, g.h);
     if (!regular) {
       for (int j = 0; j < BX * BY; ++j) {
@@ -463,27 +470,37 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
       }
       continue;
     }
-    float acc[2][BX][2];
-    uint32_t wxy[2];
-    nlk_match_block<PSZ, CH, BX>(tile, plane, rwp, (py0 - ry0) * rwp + (px0 - rx0), wsz, n, lane, acc, wxy);
+    auto run_block = [&](auto mtag) {
+      constexpr int M = decltype(mtag)::value;
+      float acc[2][BX][M];
+      uint32_t wxy[M];
+      nlk_match_block<PSZ, CH, BX, M>(tile, plane, rwp, (py0 - ry0) * rwp + (px0 - rx0), wsz, n, lane, acc, wxy);
 #pragma unroll 1
-    for (int j = 0; j < BX * BY; ++j) {
-      float a2[2] = {0.f, 0.f};
+      for (int j = 0; j < BX * BY; ++j) {
+        float a2[M];
 #pragma unroll
-      for (int by = 0; by < BY; ++by)
+        for (int m = 0; m < M; ++m) a2[m] = 0.f;
 #pragma unroll
-        for (int bx = 0; bx < BX; ++bx)
-          if (j == by * BX + bx) { a2[0] = acc[by][bx][0]; a2[1] = acc[by][bx][1]; }
-      const int tx = tx0 + j % BX, ty = ty0 + j / BX;
-      const int gx = gx0 + tx, gy = gy0 + ty;
-      const int px = gx * step, py = g.oy + gy * step;
-      const size_t t = (size_t)gy * g.ngx + gx;
-      const int prev_p = __builtin_amdgcn_readlane(rec_prev, ty * cx + tx);
-      const int k = min(prev_p ? g.npt : g.npx, n);
-      nlk_match_select<PSZ, CH, 2>(a2, wxy, n, k, px - wsz, py - wsz, surv, sel, lane);
-      nlk_match_epilogue<PSZ / 2>(g, t, px, py, prev_p, k, sel, grp, vmap, topk, tinfo, gcoords, marks, lane);
-      __builtin_amdgcn_wave_barrier();
-    }
+        for (int by = 0; by < BY; ++by)
+#pragma unroll
+          for (int bx = 0; bx < BX; ++bx)
+            if (j == by * BX + bx) {
+#pragma unroll
+              for (int m = 0; m < M; ++m) a2[m] = acc[by][bx][m];
+            }
+        const int tx = tx0 + j % BX, ty = ty0 + j / BX;
+        const int gx = gx0 + tx, gy = gy0 + ty;
+        const int px = gx * step, py = g.oy + gy * step;
+        const size_t t = (size_t)gy * g.ngx + gx;
+        const int prev_p = __builtin_amdgcn_readlane(rec_prev, ty * cx + tx);
+        const int k = min(prev_p ? g.npt : g.npx, n);
+        nlk_match_select<PSZ, CH, M>(a2, wxy, n, k, px - wsz, py - wsz, surv, sel, lane);
+        nlk_match_epilogue<PSZ / 2>(g, t, px, py, prev_p, k, sel, grp, vmap, topk, tinfo, gcoords, marks, lane);
+        __builtin_amdgcn_wave_barrier();
+      }
+    };
+    if (MB == 2 || n <= 128) run_block(std::integral_constant<int, 2>{});
+    else run_block(std::integral_constant<int, MB>{});
   }
 }
 

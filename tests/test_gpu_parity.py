@@ -412,7 +412,8 @@ def test_block_matching_equals_target_by_target(ctx, built, synth, monkeypatch):
     """k_bm_topk shares the squared differences inside blocks of 4 x 2 targets (nlk_match_block);
     NLK_MATCH_NOBLOCK=1 runs every target on its own (nlk_match_target). Same per-target summation
     order, so ALL records - every target's sorted k-NN list, group, counters, mark decisions - must be
-    identical, for the filter with and without a basic estimate, the smoother, and with NaN holes."""
+    identical, for spatial and temporal frames, with and without a basic estimate, the smoother, and
+    with NaN holes."""
     w, h, ch, sigma = 1000, 560, 3, 20.0
     n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, 21)
     o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
@@ -421,7 +422,8 @@ def test_block_matching_equals_target_by_target(ctx, built, synth, monkeypatch):
     holes = prev.copy()
     holes[100:140, 300:420] = np.nan
     holes[:, :2] = np.nan
-    calls = [(False, o1, prev, None, p1), (False, o1, holes, None, p1), (False, n1, prev, o1, p2),
+    calls = [(False, o0, None, None, p1),  # (spatial: 441 candidates, seven rounds per block)
+             (False, o1, prev, None, p1), (False, o1, holes, None, p1), (False, n1, prev, o1, p2),
              (True, o1, prev, None, p3), (True, o1, holes, None, p3)]
     for smo, cur, pv, basic, p in calls:
         monkeypatch.delenv("NLK_MATCH_NOBLOCK", raising=False)
