@@ -445,12 +445,16 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
   // differences between its targets (nlk_match_block, two or seven rounds of 64 candidates); any other
   // block - image border, a target without a valid previous patch in a temporal frame, windows of more
   // than 448 candidates - goes target by target.
+  if (!tl.block) {  // (comparison variant, and small grids: the targets dealt out to the wavefronts one by one)
+    for (int tt = wave; tt < cx * cy; tt += NLK_BM_WAVES) do_target(tt);
+    return;
+  }
   constexpr int BX = 4, BY = 2;
   const int nbx = (tl.tgx + BX - 1) / BX, nby = (tl.tgy + BY - 1) / BY;
   for (int blk = wave; blk < nbx * nby; blk += NLK_BM_WAVES) {
     const int bty = blk / nbx, tx0 = (blk - bty * nbx) * BX, ty0 = bty * BY;
     if (tx0 >= cx || ty0 >= cy) continue;
-    bool regular = tl.block && tx0 + BX <= cx && ty0 + BY <= cy && g.npt > 1 && g.npx > 1;
+    bool regular = tx0 + BX <= cx && ty0 + BY <= cy && g.npt > 1 && g.npx > 1;
     int nprev = 0;
     if (regular)
       for (int j = 0; j < BX * BY; ++j)

@@ -32,7 +32,11 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
     // 4 x 1 targets per wavefront measured best for the temporal radius (profiles/README.md);
     // with a wide halo the tile would leave LDS room for ~1 wavefront per SIMD: 2 x 1 then.
     // NLK_GTX/NLK_GTY override for experiments
-    tl.tgx = getenv("NLK_GTX") ? atoi(getenv("NLK_GTX")) : (tl.wmax > 6 ? 2 : 4);
+    // (a small grid is latency bound: fewer targets per wavefront while the tiles would not fill the
+    // ~2560 wavefronts the chip holds)
+    auto tiles_with = [&](int t) { return (size_t)((g.ngx + t - 1) / t) * g.ngy; };
+    const int tgx_fill = tiles_with(4) >= 2560 ? 4 : (tiles_with(2) >= 2560 ? 2 : 1);
+    tl.tgx = getenv("NLK_GTX") ? atoi(getenv("NLK_GTX")) : min(tgx_fill, tl.wmax > 6 ? 2 : 4);
     tl.tgy = getenv("NLK_GTY") ? atoi(getenv("NLK_GTY")) : 1;
     tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
     tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
@@ -56,7 +60,7 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
       if (pass == 0) {
         size_t need = ntiles * (CH + 1) * tl.plane, nflag = ntiles;
         if (split) {
-          const int tgx2 = getenv("NLK_GTX") ? atoi(getenv("NLK_GTX")) : (g.wsz_x > 6 ? 2 : 4);
+          const int tgx2 = getenv("NLK_GTX") ? atoi(getenv("NLK_GTX")) : min(tgx_fill, g.wsz_x > 6 ? 2 : 4);
           const int rw2 = (tgx2 - 1) * g.step + 2 * g.wsz_x + g.psz, rh2 = (tl.tgy - 1) * g.step + 2 * g.wsz_x + g.psz;
           const size_t nt2 = (size_t)((g.ngx + tgx2 - 1) / tgx2) * tl.nty;
           need += nt2 * (CH + 1) * ((size_t)(rw2 + 32) * rh2 + 32);
