@@ -29,13 +29,14 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
     // groups of a temporal frame that reach further fall back to HBM atomics
     tl.wmax = (g.smoother || g.have_prev) ? g.wsz_t : g.wsz_x;
     if (pass == 1) tl.wmax = g.wsz_x;
-    // 4 x 1 targets per wavefront measured best for the temporal radius (profiles/README.md);
-    // with a wide halo the tile would leave LDS room for ~1 wavefront per SIMD: 2 x 1 then.
-    // NLK_GTX/NLK_GTY override for experiments
-    // (a small grid is latency bound: fewer targets per wavefront while the tiles would not fill the
-    // ~2560 wavefronts the chip holds)
+    // Targets per wavefront (NLK_GTX / NLK_GTY override for experiments), measured (profiles/README.md):
+    // 3 x 1 on a 1080p grid (group 1.040 ms; 4 x 1 1.049, 2 x 1 1.068: a 3-target row needs 28 floats of
+    // row stride like a 2-target one, 11 KB of LDS instead of 13), 2 x 1 on smaller grids (more, shorter
+    // workgroups fill the chip better: 720p 0.499 vs 0.508 ms, 640 x 480 0.194 vs 0.221), one target while
+    // the tiles would not even fill the ~2560 wavefronts the chip holds (256 x 256). With a wide halo the
+    // tile would leave LDS room for ~1 wavefront per SIMD: 2 x 1 at most then.
     auto tiles_with = [&](int t) { return (size_t)((g.ngx + t - 1) / t) * g.ngy; };
-    const int tgx_fill = tiles_with(4) >= 2560 ? 4 : (tiles_with(2) >= 2560 ? 2 : 1);
+    const int tgx_fill = tiles_with(3) >= 30000 ? 3 : (tiles_with(2) >= 2560 ? 2 : 1);
     tl.tgx = getenv("NLK_GTX") ? atoi(getenv("NLK_GTX")) : min(tgx_fill, tl.wmax > 6 ? 2 : 4);
     tl.tgy = getenv("NLK_GTY") ? atoi(getenv("NLK_GTY")) : 1;
     tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
