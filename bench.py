@@ -269,6 +269,34 @@ def bench_sequence(args, pkg, synth, ctx, torch, rank, world, dev):
     print(json.dumps(res))
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a
+    child process (the ranks are its children). This parent never touches the GPU (no torch import, no
+    exec of a process that initialised HIP); it forwards rank 0's single JSON line and returns the
+    launcher's exit status, so a failed rank is a non-zero exit."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    for l in r.stdout.splitlines():
+        if not l.startswith("{") and l.strip():
+            print(l, file=sys.stderr)                   # anything else a rank printed is not the line
+    if r.returncode == 0 and len(lines) != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 1
+    for l in lines:
+        print(l)
+    return r.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -287,6 +315,11 @@ def main():
                     help="run the N > 1 strip machinery even at N = 1 (measures its fixed overhead)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: start the N ranks as CHILD processes before this
+        # process makes any GPU call (it never does), forward rank 0's line, exit with their status
+        raise SystemExit(launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
 
@@ -294,12 +327,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus}` "
+                         f"(launches its own ranks) or with torch.distributed.run --nproc-per-node {args.gpus}")
+    one_gpu = os.environ.get("NLK_BENCH_ONE_GPU") == "1"
+    if world > 1 and not one_gpu and torch.cuda.device_count() < world:   # device_count() does not initialise HIP
+        raise SystemExit(f"--gpus {world} but {torch.cuda.device_count()} HIP device(s) visible "
+                         "(NLK_BENCH_ONE_GPU=1 puts every rank on device 0 over gloo: plumbing check, not a measurement)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # NLK_BENCH_ONE_GPU=1 (development aid): every rank on device 0 with the gloo backend and host
     # staging, to drive the whole N > 1 code path on a one-GPU box; its numbers mean nothing
-    one_gpu = os.environ.get("NLK_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local = 0
     torch.cuda.set_device(local)
@@ -397,9 +434,8 @@ def main():
         one_step()
     barrier()
     dt = time.perf_counter() - t0
-    # Per-kernel times: a second, untimed loop with HIP events around every kernel. Profiling puts a
-    # frame call back into the single-stream order (in the timed loop above the two bands of a frame
-    # overlap on two streams, where a kernel's start-to-end time says nothing about its cost).
+    # Per-kernel times: a second, untimed loop of the same steps with HIP events around every kernel
+    # on the context's stream (the timed loop above runs the same single-stream order, unprofiled).
     ctx.set_profiling(True)
     for _ in range(args.steps):
         one_step()
@@ -497,8 +533,8 @@ def main():
                           "mask_order": "serial-exact" if world == 1 else
                           "serial-exact (mark words all-gathered, mask replayed on every rank)"},
                "kernels_ms": {k_: round(v, 4) for k_, v in tm.items()},
-               "kernels_ms_note": "second loop of the same steps in the single-stream order (HIP events around every "
-                                  "kernel); ms_per_step is the timed loop, where the bands of a frame overlap",
+               "kernels_ms_note": "second loop of the same steps with HIP events around every kernel on the "
+                                  "context's stream; ms_per_step is the timed (unprofiled) loop",
                "roofline": roof}
         if phase_ms is not None:
             res["strip_phase_ms"] = phase_ms
@@ -511,8 +547,14 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle as O
             o1_h, prev_h = t_n1.cpu().numpy(), t_prev.cpu().numpy()
-            ref, cb = cpu_baseline(O, o1_h, prev_h, sigma, p)
-            res["cpu_baseline"] = cb
+            if world == 1:   # the CPU baseline is timed at N = 1 only; N > 1 keeps the parity leg below
+                ref, cb = cpu_baseline(O, o1_h, prev_h, sigma, p)
+                res["cpu_baseline"] = cb
+            else:
+                cb = None
+                if args.workload == "C3":   # (every other workload takes the serial order below)
+                    po = O.Params(*[getattr(p, k) for k, _ in p._fields_])
+                    ref = O.filter_frame(o1_h, prev_h, None, sigma, po, nthreads=min(os.cpu_count() or 1, 100))
             # quality reference = the serial (OpenMP off) order, which is the order the GPU path
             # reproduces; the threaded run above perturbs the processed-mask like the reference's
             # own OpenMP build does. C3 never skips (step > temporal radius): any order is the same.
@@ -527,7 +569,8 @@ def main():
             res["psnr_reference_order"] = order
             import numpy as np
             res["max_abs_vs_cpu"] = round(float(np.abs(out - ref).max()), 6)
-            res["speedup_vs_cpu"] = round(value / cb["value"], 1)
+            if cb is not None:
+                res["speedup_vs_cpu"] = round(value / cb["value"], 1)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -22,12 +22,55 @@ def _bench(*args):
 
 def test_bench_refuses_to_run_without_a_gpu_or_with_a_wrong_world():
     import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    # a rank whose world does not match --gpus (a launcher started with the wrong --nproc-per-node)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
-                       cwd=ROOT, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")})
+                       cwd=ROOT, env=dict(env, WORLD_SIZE="4", RANK="0"))
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
     if not torch.cuda.is_available():
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], capture_output=True, text=True, cwd=ROOT)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], capture_output=True, text=True, cwd=ROOT, env=env)
         assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
+
+
+def test_bench_launches_its_own_ranks_and_reports_their_failure():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (children of a
+    torch.distributed.run child; the parent never touches the GPU). Without a GPU both ranks refuse to
+    run: the parent must then exit non-zero and print no JSON line."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the GPU variant is test_bench_two_and_eight_ranks_on_one_gpu")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, cwd=ROOT, env=dict(env, NLK_BENCH_ONE_GPU="1"), timeout=300)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "no CPU fallback" in r.stderr          # the ranks started and said why they stopped
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_two_and_eight_ranks_on_one_gpu(n):
+    """The driver's `python bench.py --gpus N` on a one-GPU box: every rank on device 0 over gloo
+    (NLK_BENCH_ONE_GPU=1) runs the whole N > 1 branch - strip plan, halo exchange, mark-word all-gather,
+    whole-grid replay, accumulator halos, summed transform counts, own-row assembly, phase times."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
+                        "--phase-times"], capture_output=True, text=True, cwd=ROOT, env=dict(env, NLK_BENCH_ONE_GPU="1"),
+                       timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == n and d["steps"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["parallelism"] == f"row strips x{n}" and d["config"]["workload"].startswith("C2: 1920x1080x3")
+    assert len(d["strip_phase_ms"]) == n and all("group" in ph and "exchange_acc" in ph for ph in d["strip_phase_ms"])
+    assert "cpu_baseline" not in d                 # timed at N = 1 only
+    # the single-GPU line's parity fields (a sample may flip at the reference's absolute aggr > 1e-6
+    # threshold in the default atomic-order mode, so max-abs is reported, the PSNR bar asserted)
+    assert abs(d["psnr_delta_db"]) <= 0.02 and d["max_abs_vs_cpu"] >= 0
+    assert 0 < d["roofline"]["frac"] < 1
 
 
 @pytest.mark.gpu
