@@ -97,7 +97,9 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [(CH+1)][plane]
   constexpr int PSZ = 8, step = 4;
   const int lane = threadIdx.x;
-  const int tile_id = nlk_xcd_tile(blockIdx.x, tl.ntx * tl.nty);
+  // (tiles in launch order: the XCD-band order of nlk_xcd_tile left whole XCDs idle at the end of a launch -
+  // the bands differ in skipped targets - and measured 2 % slower, profiles/README.md round 3)
+  const int tile_id = blockIdx.x;
   if (tile_id >= tl.ntx * tl.nty) return;
   const int tile_x = tile_id % tl.ntx, tile_y = tile_id / tl.ntx;
   const int gx0 = tile_x * tl.tgx, gy0 = tile_y * tl.tgy;
@@ -217,103 +219,122 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     // target has previous-frame patches - 8 candidates of the image AND their 8
     // previous-frame patches (slot lo = 4*(c>>1) + 2*isprev + (c&1), so that both
     // coefficients of a candidate end up in the same lane: registers j and j+2).
+    //
+    // Sums are taken of d = coefficient - x0 (x0 = coefficient of the first candidate's image
+    // patch, which every MFMA chain starts from as its C operand: NX0 = -x0, no instruction):
+    //   S0/S1 image (all candidates), S2/S3 previous frame (valid ones), S4 squared
+    //   image-previous difference, S5 previous frame over the group members.
+    // Slots that must not count - candidates past the k-th, and in the filter a candidate without
+    // a valid previous patch (the Kalman branch uses no image statistics, reference: :859-904) -
+    // read the FIRST candidate's image patch instead: their d is zero up to the rounding of the
+    // chain (a few ulp of x0, against sums of ~k * sigma), so the sums need no masks. What still
+    // needs one: the group mean (members only) and, in the smoother, the transition term of a
+    // candidate whose image patch counts while its previous patch does not (reference: :1659-1667).
     float part_sum = 0.f;
-    // sums of d = coefficient - x0 (x0 = coefficient of the first candidate):
-    // S0/S1 image (all candidates), S2/S3 previous frame (valid ones), S4 squared
-    // image-previous difference, S5 previous frame over the group members
-    float S[6][4], x0[4];
+    float S[6][4];
+    nlk_f4 NX0[4];
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
       for (int q = 0; q < 4; ++q) S[a][q] = 0.f;
+    // per lane: offset (floats) of candidate (lane + 64 m)'s patch inside an image plane,
+    // bit 31 = "has a valid previous patch"
+    uint32_t oreg[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) x0[q] = 0.f;
-    // two copies of the loop (with / without previous-frame patches).
-    // Load schedule: the rows of step it+1 are requested right after those of step it
-    // were folded and the address of step it+2 is prepared, so every request has a
-    // whole step to land. All loads are unconditional (a slot without a patch reads a
-    // valid one and is masked out): a load under a run-time branch would turn every
-    // wait into a wait for all loads in flight.
-    auto pass_a = [&](auto has_prev) {
-      constexpr bool HP = decltype(has_prev)::value;
+    for (int m = 0; m < 2; ++m)
+      oreg[m] = (uint32_t)(nlk_y(qreg[m]) * g.w + nlk_x(qreg[m])) | ((uint32_t)((vbits[m] >> lane) & 1ull) << 31);
+    const uint32_t o_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)oreg[0]) & 0x7fffffffu;
+    // MODE 0: no previous-frame patches (Wiener branch; 16 candidates per step), 1: filter with
+    // previous-frame patches (Kalman branch), 2: smoother with previous-frame patches.
+    // Schedule: the rows of step it+1 are requested right after those of step it were folded (into the
+    // same registers) and the offset of step it+2 is prepared, so every request has a whole step to land.
+    // All loads are unconditional: a load under a run-time branch would turn every wait into a wait for
+    // all loads in flight.
+    auto pass_a = [&](auto mode_tag) {
+      constexpr int MODE = decltype(mode_tag)::value;
+      constexpr bool HP = MODE != 0;
       constexpr int CB = HP ? 8 : 16;  // candidates per step
       const int nb = (k + CB - 1) / CB;
-      const int njobs = CH * nb;
-      if (njobs == 0) return;
+      if (nb == 0) return;
       const int slot_c = HP ? 2 * (lo >> 2) + (lo & 1) : lo;
       const bool slot_prev = HP && ((lo >> 1) & 1);
-      // rows of slot lo of step bb of channel cc; a candidate without a valid previous
-      // patch (NaNs) reads the image instead: finite, and masked out of the sums
-      auto slot_ptr = [&](int bb, int cc) -> const float* {
+      const uint32_t live_need = MODE == 1 ? 0x80000000u : (slot_prev ? 0x80000000u : 0u);
+      // slot lo's patch in step bb: offset into an image plane, and whether it is the previous frame's
+      auto slot_off = [&](int bb, bool& prevsel) -> int {
         const int ci = CB * bb + slot_c, cl = min(ci, k - 1);
-        const uint32_t qc = nlk_bperm_u(cl < 64 ? qreg[0] : qreg[1], cl & 63);
-        const int o = nlk_y(qc) * g.w + nlk_x(qc);
-        const bool usep = slot_prev && ci < k && (((ci < 64 ? vbits[0] : vbits[1]) >> (ci & 63)) & 1ull);
-        return img + (usep ? prev_off : (ptrdiff_t)0) + cc * npix + o;
+        const uint32_t oc = nlk_bperm_u(cl < 64 ? oreg[0] : oreg[1], cl & 63);
+        const bool live = ci < k && (oc & live_need) == live_need;
+        prevsel = live && slot_prev;
+        return live ? (int)(oc & 0x7fffffffu) : (int)o_first;
       };
-      auto next_job = [&](int bb, int cc, int& ob, int& oc) {
-        ob = bb + 1; oc = cc;
-        if (ob == nb) { ob = 0; oc = cc + 1; }
-        if (oc == CH) { ob = bb; oc = cc; }  // (past the end: a harmless reload)
+      // rows g4 and 7-g4 of the patch at `off` of channel cc
+      auto rows_read = [&](int off, bool prevsel, int cc, float (&R)[16]) {
+        nlk_rows_load(img + (prevsel ? prev_off : (ptrdiff_t)0) + (size_t)cc * npix + off, g.w, g4, R);
       };
       float R[16], F[4][4];
-      int b = 0, ch = 0, b1, ch1;
-      nlk_rows_load(slot_ptr(0, 0), g.w, g4, R);
-      next_job(b, ch, b1, ch1);
-      const float* pnext = slot_ptr(b1, ch1);
-      for (int it = 0; it < njobs; ++it) {
-        int b2, ch2;
-        next_job(b1, ch1, b2, ch2);
+      bool p0sel, pnsel;
+      const int o_step0 = slot_off(0, p0sel);
+      rows_read(o_step0, p0sel, 0, R);
+      int onext = slot_off(1, pnsel);
+      for (int ch = 0; ch < CH; ++ch)
+      for (int b = 0; b < nb; ++b) {
         nlk_fold(R, F);
-        nlk_rows_load(pnext, g.w, g4, R);
-        pnext = slot_ptr(b2, ch2);
+        __builtin_amdgcn_sched_barrier(0);  // (the reload below reuses R: no second register set, no copies)
+        // the next step's rows; after a channel's last step the next channel's first (after the very
+        // last step: a harmless reload)
+        const bool wrap = b + 1 == nb;
+        rows_read(wrap ? o_step0 : onext, wrap ? p0sel : pnsel, wrap ? min(ch + 1, CH - 1) : ch, R);
+        onext = slot_off(wrap ? 1 : b + 2, pnsel);
         __builtin_amdgcn_sched_barrier(0);
         nlk_f4 C[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) C[q] = nlk_f4{-x0[q], -x0[q], -x0[q], -x0[q]};
-        nlk_mfma_fwd<false>(F, dA, C);
         if (b == 0) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            x0[q] = nlk_bperm(C[q][0], lo);
+          for (int q = 0; q < 4; ++q) C[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
+          nlk_mfma_fwd<false>(F, dA, C);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) C[q][j] -= x0[q];
+          for (int q = 0; q < 4; ++q) {
+            const float x0 = nlk_bperm(C[q][0], lo);
+            NX0[q] = nlk_f4{-x0, -x0, -x0, -x0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) C[q][j] -= x0;
           }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) C[q] = NX0[q];
+          nlk_mfma_fwd<false>(F, dA, C);
         }
         if (HP) {
-          const uint64_t vw = b < 8 ? vbits[0] : vbits[1];
-          const uint64_t gw = b < 8 ? gbits[0] : gbits[1];
-          const int sh = 8 * (b & 7) + 2 * g4;
-          const uint32_t vnib = (uint32_t)(vw >> sh) & 3u, gnib = (uint32_t)(gw >> sh) & 3u;
+          // bit j of the lane group's pair of candidates: group membership (filter) / valid previous patch (smoother)
+          const uint64_t mw = MODE == 1 ? (b < 8 ? gbits[0] : gbits[1]) : (b < 8 ? vbits[0] : vbits[1]);
+          const uint32_t mbyte = (uint32_t)(mw >> (8 * (b & 7))) & 0xffu;
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            const float km = (8 * b + 2 * g4 + j) < k ? 1.f : 0.f;
-            const float vm = (vnib >> j) & 1u ? 1.f : 0.f;
-            const float gm = (gnib >> j) & 1u ? 1.f : 0.f;
+            const float mk = (float)((mbyte >> (2 * g4 + j)) & 1u);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const float di = C[q][j], mdi = km * di;
-              S[0][q] += mdi;
-              S[1][q] = fmaf(mdi, di, S[1][q]);
-              const float d = C[q][j + 2], md = vm * d;
-              S[2][q] += md;
-              S[3][q] = fmaf(md, d, S[3][q]);
+              const float di = C[q][j], d = C[q][j + 2];
+              if (MODE == 2) {
+                S[0][q] += di;
+                S[1][q] = fmaf(di, di, S[1][q]);
+              }
+              S[2][q] += d;
+              S[3][q] = fmaf(d, d, S[3][q]);
               const float df = di - d;  // reference: :769-783, smoother :1659-1667
-              S[4][q] = fmaf(vm * df, df, S[4][q]);
-              if (!SMO) S[5][q] = fmaf(gm, d, S[5][q]);
+              if (MODE == 2) S[4][q] = fmaf(mk * df, df, S[4][q]);
+              else {
+                S[4][q] = fmaf(df, df, S[4][q]);
+                S[5][q] = fmaf(mk, d, S[5][q]);
+              }
             }
           }
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float km = (16 * b + 4 * g4 + j) < k ? 1.f : 0.f;
+          for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const float md = km * C[q][j];
-              S[0][q] += md;
-              S[1][q] = fmaf(md, C[q][j], S[1][q]);
+              S[0][q] += C[q][j];
+              S[1][q] = fmaf(C[q][j], C[q][j], S[1][q]);
             }
-          }
         }
         if (b == nb - 1) {
           // The channel is complete: candidates are spread over the four lane groups. Each of the
@@ -326,7 +347,8 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
 #pragma unroll
           for (int a = 0; a < 6; ++a) {
             T[a] = 0.f;
-            if (a < (HP ? (SMO ? 5 : 6) : 2)) {
+            const bool used = MODE == 0 ? a < 2 : (MODE == 1 ? a >= 2 : a < 5);
+            if (used) {
               const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(S[a][0]), __float_as_uint(S[a][2]), false, false);
               const auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(S[a][1]), __float_as_uint(S[a][3]), false, false);
               const float X = __uint_as_float(x[0]) + __uint_as_float(x[1]);
@@ -337,29 +359,29 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
           }
           // ---- gain of coefficient lo of quadrant g4 (reference: :799-811, :859-904; smoother :1683-1776)
           {
-            const float x0q = g4 == 0 ? x0[0] : (g4 == 1 ? x0[1] : (g4 == 2 ? x0[2] : x0[3]));
-            const float mean1 = x0q + T[0] * in1;
-            const float v1 = (T[1] - T[0] * T[0] * in1) * in1;  // image variance
+            const float nx0q = g4 == 0 ? NX0[0][0] : (g4 == 1 ? NX0[1][0] : (g4 == 2 ? NX0[2][0] : NX0[3][0]));
             const float v0 = (T[3] - T[2] * T[2] * in0) * in0;  // previous-frame variance
             const float v01n = T[4] * in0;
             float a, term, m;
-            if (SMO) {
+            if (MODE == 2) {
+              const float v1 = (T[1] - T[0] * T[0] * in1) * in1;  // image variance
               a = v1 * __builtin_amdgcn_rcpf(v1 + g.beta_t * v01n);
               const float pv = v0 - g.beta_t * v01n;
               term = (1 - a * a) * v1 + a * a * (pv > 0.f ? pv : 0.f);
               m = 0.f;
-            } else if (HP) {
+            } else if (MODE == 1) {
               const float d = v01n - (g.have_basic ? 0.f : s2);
               const float v = v0 + (0.f > d ? 0.f : d);
               a = v * __builtin_amdgcn_rcpf(v + g.beta_t * s2);
               term = (1 - a * a) * v + a * a * s2;
-              m = x0q + T[5] * ing;
+              m = T[5] * ing - nx0q;
             } else {
+              const float v1 = (T[1] - T[0] * T[0] * in1) * in1;
               const float d = v1 - (g.have_basic ? 0.f : s2);
               const float v = 0.f > d ? 0.f : d;
               a = v * __builtin_amdgcn_rcpf(v + g.beta_x * s2);
               term = a * v;
-              m = mean1;
+              m = T[0] * in1 - nx0q;
             }
             part_sum += term;
             // parked in LDS for pass B: [channel][gain | (1-a)*mean][quadrant][coefficient]
@@ -371,14 +393,12 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
           for (int a = 0; a < 6; ++a)
 #pragma unroll
             for (int q = 0; q < 4; ++q) S[a][q] = 0.f;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) x0[q] = 0.f;
         }
-        b = b1; ch = ch1; b1 = b2; ch1 = ch2;
       }
     };
-    if (np0 > 0) pass_a(std::true_type{});
-    else pass_a(std::false_type{});
+    if (np0 == 0) pass_a(std::integral_constant<int, 0>{});
+    else if (!SMO) pass_a(std::integral_constant<int, 1>{});
+    else pass_a(std::integral_constant<int, 2>{});
 
     // ---------------- pass B: shrink, invert and aggregate the group members, 4 per step
     // (slot lo = 4*channel + member; slots without a member / channel read a valid patch

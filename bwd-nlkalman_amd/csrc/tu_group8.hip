@@ -38,7 +38,9 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
     auto tiles_with = [&](int t) { return (size_t)((g.ngx + t - 1) / t) * g.ngy; };
     const int tgx_fill = tiles_with(3) >= 30000 ? 3 : (tiles_with(2) >= 2560 ? 2 : 1);
     tl.tgx = getenv("NLK_GTX") ? atoi(getenv("NLK_GTX")) : min(tgx_fill, tl.wmax > 6 ? 2 : 4);
-    tl.tgy = getenv("NLK_GTY") ? atoi(getenv("NLK_GTY")) : 1;
+    // (round 3, matrix-core kernel with the leaner pass A, 1080p: 3 x 2 targets 0.957 ms, 2 x 2 0.970, 3 x 1 0.976,
+    // 4 x 2 1.10, 2 x 3 1.05, 3 x 3 1.04 - two target rows share the tile's vertical halo: 40 % fewer flushed bytes)
+    tl.tgy = getenv("NLK_GTY") ? atoi(getenv("NLK_GTY")) : ((mfma && tgx_fill == 3 && tl.wmax <= 6) ? 2 : 1);
     tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
     tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
     const int rw_max = (tl.tgx - 1) * g.step + 2 * tl.wmax + g.psz;
@@ -87,7 +89,7 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
     HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
     const float* basis = (const float*)c->tabs.p;
-    hipLaunchKernelGGL(kern, dim3(nlk_xcd_grid(tl.ntx * tl.nty)), dim3(64), lds, c->rv.stream, img, cur, prev,
+    hipLaunchKernelGGL(kern, dim3(mfma ? tl.ntx * tl.nty : nlk_xcd_grid(tl.ntx * tl.nty)), dim3(64), lds, c->rv.stream, img, cur, prev,
                        (const uint8_t*)c->vmap.p, g, tl, (const uint32_t*)c->rv.topk,
                        (const NlkTarget*)c->rv.tinfo, (const uint32_t*)c->rv.gcoords,
                        active, basis, basis + PSZ * PSZ, acc);
