@@ -29,7 +29,9 @@
 #ifndef NLK_BM_BLOCK7
 #define NLK_BM_BLOCK7 1  // spatial windows (<= 448 candidates) in blocks too
 #endif
+#ifndef NLK_BM_THREADS
 #define NLK_BM_THREADS 256
+#endif
 #define NLK_BM_WAVES (NLK_BM_THREADS / 64)
 
 struct NlkTile {
