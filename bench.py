@@ -70,21 +70,29 @@ def kernel_sources_sha():
     return hsh.hexdigest()
 
 
-def measured_traffic(workload, kname):
-    """HBM-side bytes per launch from the committed PMC passes (profiles/r02_traffic.json, made by
-    tools/profile_round.sh + tools/make_traffic.py) - only while the kernel sources are still the ones
-    the table was measured on; otherwise (None, why)."""
-    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+def measured_traffic(workload, instance, largest_grid=False):
+    """HBM-side bytes per launch of kernel `instance` (full template name, e.g. "k_bm_topk<8, 3, 2>": the
+    instantiation this run timed) from the committed PMC passes (profiles/<tag>_traffic.json, made by
+    tools/profile_round.sh + tools/make_traffic.py; tag = NLK_TRAFFIC_TAG, default r03) - only while the
+    kernel sources are still the ones the table was measured on; otherwise (None, why)."""
+    tag = os.environ.get("NLK_TRAFFIC_TAG", "r03")
+    tpath = os.path.join(ROOT, "profiles", f"{tag}_traffic.json")
     if not os.path.exists(tpath):
-        return None, "no PMC table committed"
+        return None, f"no PMC table profiles/{tag}_traffic.json committed"
     tab = json.load(open(tpath))
     if tab.get("kernel_sources_sha256") != kernel_sources_sha():
-        return None, ("the kernel sources differ from the ones profiles/r02_traffic.json was measured on "
+        return None, (f"the kernel sources differ from the ones profiles/{tag}_traffic.json was measured on "
                       f"(git {tab.get('git_head', '?')[:10]}): re-run tools/profile_round.sh")
-    ent = tab.get("workloads", {}).get(workload, {}).get(kname)
+    ents = tab.get("workloads", {}).get(workload, {})
+    ent = ents.get(instance)
+    if ent is None and largest_grid:  # (a kernel family with one instance per launch shape: the full-size one)
+        fam = [e for k_, e in ents.items() if k_.startswith(instance)]
+        ent = max(fam, key=lambda e: e["traffic_bytes"]) if fam else None
     if not ent:
-        return None, f"no entry for {kname} at {workload}"
-    return ent["traffic_bytes"], f"FETCH_SIZE + WRITE_SIZE per launch, git {tab['git_head'][:10]} (fetch x2 bound: {ent['traffic_bytes_fetch_x2']:.4g})"
+        return None, f"no entry for {instance} at {workload}"
+    return ent["traffic_bytes"], (f"FETCH_SIZE + WRITE_SIZE per launch of {ent['instance']} ({ent['launch_shape']}, "
+                                  f"{ent['launches_per_pass']} launches), git {tab['git_head'][:10]} "
+                                  f"(fetch x2 bound: {ent['traffic_bytes_fetch_x2']:.4g})")
 
 
 def bench_flow(args, pkg, synth, ctx, torch, dist, rank, world, dev):
@@ -139,11 +147,9 @@ def bench_flow(args, pkg, synth, ctx, torch, dist, rank, world, dev):
     torch.cuda.synchronize()
     t_iter = (time.perf_counter() - t1) / reps / max(it1, 1)
     gbs = 88.0 * w * h / t_iter / 1e9
-    traffic = None  # HBM-side bytes per iteration from the committed PMC passes (profiles/r01_traffic.json)
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if world == 1 and os.path.exists(tpath):
-        tb = json.load(open(tpath))["kernels"].get("k_tv_block", {}).get("traffic_bytes")
-        traffic = tb / 4 if tb else None  # a launch = 4 iterations
+    # HBM-side bytes per iteration from the committed PMC passes of the same sources (a launch = 4 iterations)
+    traffic, traffic_note = (None, "single-GPU runs only") if world > 1 else measured_traffic("F1", "k_tv_block", largest_grid=True)
+    traffic = traffic / 4 if traffic else None
     res = {"metric": "Mpix/s per flow (tvl1flow, 1080p, default parameters)", "value": round(world * w * h / (dt / args.steps) / 1e6, 3),
            "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -154,7 +160,7 @@ def bench_flow(args, pkg, synth, ctx, torch, dist, rank, world, dev):
                       "iterations": iters},
            "roofline": {"kernel": "k_tv_block (full-size level, per iteration)", "bound": "hbm",
                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
                         "iteration_us": round(t_iter * 1e6, 2), "algorithmic_bytes_per_iteration": 88 * w * h,
                         "note": "measured on a one-level run (wall time / iterations; launches, redone "
                                 "batches and state read-backs included). Algorithmic bytes of the plain "
@@ -452,7 +458,14 @@ def main():
     else:
         act = rec["active"].astype(bool)
     act = act & (rec["nagg"] > 0)
-    ntr_local = float((rec["nsel"] * (1 + (rec["np0"] > 0)) + 2 * rec["nagg"])[act].sum())
+    # ALGORITHMIC work of the group kernel (SURVEY.md §8(d) terms, per processed target): forward transforms of the
+    # kept candidates (image, and previous frame when the target has valid previous patches), inverse transforms of
+    # the group members (their forward transforms ARE candidate transforms: the kernels redo them, the algorithm
+    # does not), statistics 16 flop per coefficient and candidate, gains 68 per coefficient, aggregation 2 per
+    # member pixel and plane. Summed from the last launch's records.
+    nsel_a, np0_a, nagg_a = (rec[k_][act].astype(np.float64) for k_ in ("nsel", "np0", "nagg"))
+    ntr_local = float((nsel_a * (1 + (np0_a > 0)) + nagg_a).sum())                     # patch transforms per channel
+    nother_local = float((nsel_a * ch * psz * psz * 16 + ch * psz * psz * 68 + nagg_a * psz * psz * (ch + 1) * 2).sum())
     phase_ms = None
     if striped and args.phase_times and args.workload != "C5":
         sf.timers, sf.phase_s = True, {}
@@ -466,9 +479,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0].item())
         tm["group_ms"], tm["match_ms"] = float(tt[1].item()), float(tt[2].item())   # slowest rank
-        ts = torch.tensor([ntr_local], dtype=torch.float64, device=dev)
+        ts = torch.tensor([ntr_local, nother_local], dtype=torch.float64, device=dev)
         dist.all_reduce(ts)
-        ntr_total = float(ts.item())
+        ntr_total, nother_total = float(ts[0].item()), float(ts[1].item())
         if phase_ms is not None:
             allp = [None] * world
             dist.all_gather_object(allp, phase_ms)
@@ -479,7 +492,7 @@ def main():
         dist.all_reduce(full)
         t_out = full
     else:
-        ntr_total = ntr_local
+        ntr_total, nother_total = ntr_local, nother_local
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -488,26 +501,26 @@ def main():
         # dominant kernel and its roofline; algorithmic bytes and flops: DESIGN.md §5.
         # The group kernel runs its DCTs on the f32 matrix cores and everything else on the
         # f32 vector ALU, which share one FP32 datapath on gfx950 (tools/ubench/mfma_valu.hip):
-        # it is priced against the dense f32 MFMA peak. Algorithmic flops per launch =
-        # 2 * psz^3 MACs per psz x psz patch transform (row-column matrix form) x the transforms the
-        # path needs: per processed target (nsel image + nsel previous-frame patches when it
-        # has any + 2 * nagg for the members' forward and inverse) x channels; the counts are
-        # read from the last launch's records (single GPU; strips: the 70 % of the C2 frame).
+        # it is priced against the dense f32 MFMA peak. Algorithmic flops per launch: see above
+        # (2 * psz^3 MACs per psz x psz patch transform in the row-column matrix form).
         k, ngrid = p.npatches_t, ngx * ngy
         alg_bytes = {"match": w * h * ch * 4 + ngrid * k * 4,
                      "group": 2 * w * h * ch * 4 + (ch + 1) * w * h * 4 + ngrid * k * 4}
         # (all ranks' transforms; per-GPU figures below divide by the world size and use the slowest
         # rank's kernel time)
-        group_flops = ntr_total * ch * 2 * 2 * psz ** 3
+        group_flops = ntr_total * ch * 2 * 2 * psz ** 3 + nother_total
         alg_flops = {"match": ngrid * (121 * 192 * 3), "group": group_flops}
         dom = "group" if tm["group_ms"] >= tm["match_ms"] else "match"
         dur = tm[dom + "_ms"] * 1e-3
         gbs = alg_bytes[dom] / world / dur / 1e9 if dur > 0 else 0.0
         tfl = alg_flops[dom] / world / dur / 1e12 if dur > 0 else 0.0
         kname = ("k_group8m" if psz == 8 and ch in (1, 3) else "k_groupp") if dom == "group" else "k_bm_topk"
+        # the instantiation the timed (temporal) frames launch: what the PMC table is looked up by
+        inst = ((f"k_group8m<{ch}, false>" if kname == "k_group8m" else f"k_groupp<{psz}, false>") if dom == "group"
+                else f"k_bm_topk<{psz}, {ch}, {((2 * p.search_sz_t + 1) ** 2 + 63) // 64}>")
         # HBM-side bytes per launch: PMC passes of the same sources (see measured_traffic)
-        traffic, traffic_note = (None, "single-GPU runs only") if world > 1 else measured_traffic(args.workload, kname)
-        roof = {"kernel": kname, "bound": "mfma",
+        traffic, traffic_note = (None, "single-GPU runs only") if world > 1 else measured_traffic(args.workload, inst)
+        roof = {"kernel": inst, "bound": "mfma",
                 "achieved": round(tfl, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                 "launch_ms": round(tm[dom + "_ms"], 4),

@@ -17,7 +17,7 @@ extern "C" {
 
 int nlk_dev_image_dct(nlk_ctx* c, float* img, int w, int h, int ch, int inverse) {
   if (!c || !img || w < 1 || h < 1 || ch < 1) return fail(c, NLK_EINVAL, "nlk_dev_image_dct: bad argument");
-  HIPCHK(c, hipSetDevice(c->device));
+  NLK_USE_DEVICE(c);
   const size_t n = (size_t)w * h * ch;
   int rc = reserve(c, c->ms, sizeof(float) * (n + (size_t)h * h + (size_t)w * w));
   if (rc) return rc;
@@ -38,7 +38,7 @@ int nlk_dev_copy_block(nlk_ctx* c, float* dst, int dw, const float* src, int sw,
   if (!c || !dst || !src || bw < 0 || bh < 0 || bw > dw || bw > sw || ch < 1)
     return fail(c, NLK_EINVAL, "nlk_dev_copy_block: bad argument");
   if (bw == 0 || bh == 0) return NLK_OK;
-  HIPCHK(c, hipSetDevice(c->device));
+  NLK_USE_DEVICE(c);
   hipLaunchKernelGGL(k_ms_copy_block, dim3((bw * ch + 255) / 256, bh), dim3(256), 0, c->stream, dst, dw, src, sw,
                      ch, bw, bh);
   HIPCHK(c, hipGetLastError());

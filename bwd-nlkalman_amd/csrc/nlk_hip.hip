@@ -180,6 +180,7 @@ int nlk_ctx_set_profiling(nlk_ctx* c, int on) {
 // averages over every frame call recorded since profiling was switched on
 int nlk_ctx_get_timings(nlk_ctx* c, struct nlk_timings* t) {
   if (!c || !t) return NLK_EINVAL;
+  NLK_USE_DEVICE(c);
   memset(t, 0, sizeof *t);
   if (!c->ev || c->nsets == 0) return NLK_OK;
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -224,41 +225,46 @@ void* nlk_ctx_get_stream(nlk_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int nlk_dev_alloc(nlk_ctx* c, void** d, size_t bytes) {
   if (!c || !d) return fail(c, NLK_EINVAL, "null argument");
-  HIPCHK(c, hipSetDevice(c->device));
+  NLK_USE_DEVICE(c);
   if (hipMalloc(d, bytes) != hipSuccess) return fail(c, NLK_ENOMEM, "hipMalloc(%zu) failed", bytes);
   return NLK_OK;
 }
 int nlk_dev_free(nlk_ctx* c, void* d) {
   if (!c) return NLK_EINVAL;
+  NLK_USE_DEVICE(c);
   HIPCHK(c, hipFree(d));
   return NLK_OK;
 }
 int nlk_h2d(nlk_ctx* c, void* d, const void* h, size_t n) {
   if (!c) return NLK_EINVAL;
+  NLK_USE_DEVICE(c);
   HIPCHK(c, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return NLK_OK;
 }
 int nlk_d2h(nlk_ctx* c, void* h, const void* d, size_t n) {
   if (!c) return NLK_EINVAL;
+  NLK_USE_DEVICE(c);
   HIPCHK(c, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return NLK_OK;
 }
 int nlk_d2d(nlk_ctx* c, void* dst, const void* src, size_t n) {
   if (!c) return NLK_EINVAL;
+  NLK_USE_DEVICE(c);
   HIPCHK(c, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, c->stream));
   return NLK_OK;
 }
 int nlk_dev_zero(nlk_ctx* c, void* d, size_t n) {
   if (!c || !d) return fail(c, NLK_EINVAL, "null argument");
+  NLK_USE_DEVICE(c);
   HIPCHK(c, hipMemsetAsync(d, 0, n, c->stream));
   return NLK_OK;
 }
 int nlk_dev_add(nlk_ctx* c, float* dst, const float* src, size_t n) {
   if (!c || !dst || !src) return fail(c, NLK_EINVAL, "null argument");
   if (n == 0) return NLK_OK;
-  HIPCHK(c, hipSetDevice(c->device));
+  NLK_USE_DEVICE(c);
   hipLaunchKernelGGL(k_add, dim3(1024), dim3(256), 0, c->stream, dst, src, n);
   HIPCHK(c, hipGetLastError());
   return NLK_OK;
@@ -276,17 +282,19 @@ int nlk_dev_copy_peer(nlk_ctx* dc, void* dst, nlk_ctx* sc, const void* src, size
 }
 int nlk_host_alloc(nlk_ctx* c, void** h, size_t n) {
   if (!c || !h) return NLK_EINVAL;
-  HIPCHK(c, hipSetDevice(c->device));
+  NLK_USE_DEVICE(c);
   HIPCHK(c, hipHostMalloc(h, n, hipHostMallocDefault));
   return NLK_OK;
 }
 int nlk_host_free(nlk_ctx* c, void* h) {
   if (!c) return NLK_EINVAL;
+  NLK_USE_DEVICE(c);
   if (h) HIPCHK(c, hipHostFree(h));
   return NLK_OK;
 }
 int nlk_sync(nlk_ctx* c) {
   if (!c) return NLK_EINVAL;
+  NLK_USE_DEVICE(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return NLK_OK;
 }
@@ -294,6 +302,7 @@ int nlk_sync(nlk_ctx* c) {
 int nlk_dev_rgb2opp(nlk_ctx* c, float* im, int w, int h, int ch) {
   int rc = check_images(c, im, im, w, h, ch);
   if (rc) return rc;
+  NLK_USE_DEVICE(c);
   if (ch != 3) return NLK_OK;
   hipLaunchKernelGGL(k_rgb2opp, dim3(2048), dim3(256), 0, c->stream, im, (size_t)w * h);
   HIPCHK(c, hipGetLastError());
@@ -303,6 +312,7 @@ int nlk_dev_rgb2opp(nlk_ctx* c, float* im, int w, int h, int ch) {
 int nlk_dev_opp2rgb(nlk_ctx* c, float* im, int w, int h, int ch) {
   int rc = check_images(c, im, im, w, h, ch);
   if (rc) return rc;
+  NLK_USE_DEVICE(c);
   if (ch != 3) return NLK_OK;
   hipLaunchKernelGGL(k_opp2rgb, dim3(2048), dim3(256), 0, c->stream, im, (size_t)w * h);
   HIPCHK(c, hipGetLastError());
@@ -313,6 +323,7 @@ int nlk_dev_warp_bicubic(nlk_ctx* c, float* imw, const float* im, const float* o
                          const float* msk, int w, int h, int ch) {
   int rc = check_images(c, imw, im, w, h, ch);
   if (rc) return rc;
+  NLK_USE_DEVICE(c);
   if (!of) return fail(c, NLK_EINVAL, "null flow");
   hipLaunchKernelGGL(k_warp_bicubic, dim3((w + 127) / 128, h), dim3(128), 0, c->stream, imw,
                      im, of, msk, w, h, ch);
@@ -359,7 +370,7 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   int rc = check_images(c, cur, cur, w, h, ch);
   if (rc) return rc;
   if (!P) return fail(c, NLK_EINVAL, "null parameters");
-  HIPCHK(c, hipSetDevice(c->device));
+  NLK_USE_DEVICE(c);
   NlkGeom& g = pl.g;
   g.w = w; g.h = h; g.ch = ch;
   g.psz = P->patch_sz;
@@ -600,7 +611,10 @@ static int group_rows(nlk_ctx* c, hipStream_t stream, float* acc, const uint8_t*
 static int frame_bands(const nlk_ctx* c, const NlkGeom& g) {
   if (c->profiling || c->deterministic || g.R == 0 || g.R > 3) return 1;  // (deterministic mode: one slab set, one sum order)
   const char* e = getenv("NLK_BANDS");
-  int nb = e ? atoi(e) : 1;
+  // default: one band where the replay is the row formulation (reach 1: 2 % of a frame); four where it
+  // is the diagonal one (reach 2 / 3, i.e. spatial frames of small patches: 0.28 ms of a 2.6 ms first
+  // frame at 1080p on one compute unit - with four bands 2.36 ms, with two 2.41, profiles/README.md round 3)
+  int nb = e ? atoi(e) : (g.R >= 2 ? 4 : 1);
   nb = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
   while (nb > 1 && g.ngy / nb < 4 * (g.R + 1) + 8) --nb;  // (thin bands: nothing to gain)
   return nb;
@@ -693,7 +707,7 @@ int nlk_dev_mask_commit(nlk_ctx* c, const void* marks, int ngx, int ngy, int rea
                         unsigned char* active) {
   if (!c || !marks || !active || ngx < 1 || ngy < 1 || reach < 0)
     return fail(c, NLK_EINVAL, "bad mask-commit arguments");
-  HIPCHK(c, hipSetDevice(c->device));
+  NLK_USE_DEVICE(c);
   int rc = commit_rows(c, c->stream, (const uint64_t*)marks, active, ngx, 0, ngy, reach);
   mark(c, 3);
   return rc;
@@ -702,6 +716,7 @@ int nlk_dev_mask_commit(nlk_ctx* c, const void* marks, int ngx, int ngy, int rea
 int nlk_dev_strip_group(nlk_ctx* c, float* acc, const unsigned char* active) {
   if (!c || !c->have_last) return fail(c, NLK_EINVAL, "nlk_dev_strip_match has not run");
   if (!acc || !active) return fail(c, NLK_EINVAL, "null accumulator / active flags");
+  NLK_USE_DEVICE(c);
   int rc = group_rows(c, c->stream, acc, active, 0, c->last.ngy, 0);
   mark(c, 4);
   return rc;
@@ -712,6 +727,7 @@ int nlk_dev_frame_normalize(nlk_ctx* c, float* out, const float* acc, const floa
   int rc = check_images(c, out, cur, w, h, ch);
   if (rc) return rc;
   if (!acc || y0 < 0 || y1 > h || y0 > y1) return fail(c, NLK_EINVAL, "bad normalise range");
+  NLK_USE_DEVICE(c);
   mark(c, 5);
   hipLaunchKernelGGL(k_normalize, dim3(2048), dim3(256), 0, c->stream, out, acc, cur, w, h, ch,
                      y0, y1);
@@ -727,6 +743,7 @@ static int run_frame(nlk_ctx* c, float* out, const float* cur, const float* prev
   if (rc) return rc;
   if (!P) return fail(c, NLK_EINVAL, "null parameters");
   if (P->patch_sz < 2) return fail(c, NLK_EUNSUP, "patch size %d not supported", P->patch_sz);
+  NLK_USE_DEVICE(c);
   const size_t accb = sizeof(float) * (size_t)w * h * (ch + 1);
   if ((rc = reserve(c, c->acc, accb))) return rc;
   const int step = P->patch_sz / 2;
@@ -763,6 +780,7 @@ int nlk_ctx_read_records(nlk_ctx* c, int* ngrid, int* kmax, int* gmax, unsigned 
                          int* nsel, int* np0, int* nagg, unsigned int* topk,
                          unsigned int* gcoords) {
   if (!c || !c->have_last) return fail(c, NLK_EINVAL, "no frame has been processed");
+  NLK_USE_DEVICE(c);
   const NlkGeom& g = c->last;
   const int n = g.ngx * g.ngy;
   if (ngrid) *ngrid = n;

@@ -85,6 +85,11 @@ static inline int fail(nlk_ctx* c, int code, const char* fmt, ...) {
                   hipGetErrorString(e_), __FILE__, __LINE__);                     \
   } while (0)
 
+// Every entry point that launches, allocates, copies or synchronises makes its context's device the
+// calling thread's current one first: several contexts (NLK_DEVICES, host/multidev.c) may be driven
+// from one thread in any order, and HIP launches / allocates on the CURRENT device, whatever the stream.
+#define NLK_USE_DEVICE(ctx) HIPCHK(ctx, hipSetDevice((ctx)->device))
+
 static inline int reserve(nlk_ctx* c, NlkBuf& b, size_t bytes) {
   if (bytes <= b.cap) return NLK_OK;
   if (b.p) HIPCHK(c, hipFree(b.p));

@@ -194,7 +194,7 @@ int nlk_tvl1_scales(int w, int h, int nscales, float zfactor) {  // reference: m
 
 int nlk_dev_gray(nlk_ctx* c, float* gray, const float* im, int w, int h, int ch) {
   if (!c || !gray || !im || w <= 0 || h <= 0 || ch <= 0) return fail(c, NLK_EINVAL, "nlk_dev_gray: bad argument");
-  HIPCHK(c, hipSetDevice(c->device));
+  NLK_USE_DEVICE(c);
   const int n = w * h;
   hipLaunchKernelGGL(k_tv_gray, dim3((n + 255) / 256), dim3(256), 0, c->stream, im, gray, n, ch);
   HIPCHK(c, hipGetLastError());
@@ -203,7 +203,7 @@ int nlk_dev_gray(nlk_ctx* c, float* gray, const float* im, int w, int h, int ch)
 
 int nlk_dev_occlusion_mask(nlk_ctx* c, float* mask, const float* flow, int w, int h, float th) {
   if (!c || !mask || !flow || w <= 0 || h <= 0) return fail(c, NLK_EINVAL, "nlk_dev_occlusion_mask: bad argument");
-  HIPCHK(c, hipSetDevice(c->device));
+  NLK_USE_DEVICE(c);
   hipLaunchKernelGGL(k_tv_occlusion, tv_grid(w, h), tv_block, 0, c->stream, flow, mask, w, h, th);
   HIPCHK(c, hipGetLastError());
   return NLK_OK;
@@ -216,7 +216,7 @@ int nlk_dev_tvl1_flow(nlk_ctx* c, float* flow, const float* I0, const float* I1,
   if (!(P->tau > 0) || !(P->lambda > 0) || !(P->theta > 0) || !(P->zfactor > 0 && P->zfactor < 1) ||
       P->nscales < 1 || P->nscales > 64 || P->fscale < 0 || P->nwarps < 1 || !(P->epsilon > 0))
     return fail(c, NLK_EINVAL, "nlk_dev_tvl1_flow: parameter out of range");
-  HIPCHK(c, hipSetDevice(c->device));
+  NLK_USE_DEVICE(c);
   const int ns = P->nscales;
   int W[64], H[64];
   W[0] = w; H[0] = h;

@@ -21,6 +21,7 @@
 #include "tvl1flow.h"
 
 static nlk_ctx *g_ctx = NULL;
+int nlk_multi_first_device(void); /* multidev.c */
 
 static struct { void *p; size_t cap; } g_slot[4]; /* device buffers of the frame calls */
 
@@ -40,8 +41,10 @@ static void die(const char *what, nlk_ctx *c) {
 
 static nlk_ctx *ctx(void) {
   if (!g_ctx) {
+    /* NLK_DEVICE, else the first index of NLK_DEVICES (a list of one device, or a call the list cannot split), else 0 */
     const char *dev = getenv("NLK_DEVICE");
-    if (nlk_ctx_create(&g_ctx, dev ? atoi(dev) : 0) != NLK_OK) die("cannot initialise the GPU", NULL);
+    const int first = nlk_multi_first_device();
+    if (nlk_ctx_create(&g_ctx, dev ? atoi(dev) : (first >= 0 ? first : 0)) != NLK_OK) die("cannot initialise the GPU", NULL);
     atexit(ctx_atexit);
   }
   return g_ctx;
@@ -148,15 +151,12 @@ static float *slot(nlk_ctx *c, int i, size_t bytes) {
 
 /* host/multidev.c: the same call split over the devices of NLK_DEVICES */
 int nlk_multi_devices(void);
-void nlk_multi_frame(int smoother, float *out, const float *cur, const float *prev, const float *basic, int w, int h,
-                     int ch, float sigma, const struct nlkalman_params *P);
+int nlk_multi_frame(int smoother, float *out, const float *cur, const float *prev, const float *basic, int w, int h,
+                    int ch, float sigma, const struct nlkalman_params *P);
 
 static void frame_call(int smoother, float *out, float *cur, float *prev, float *basic, int w,
                        int h, int ch, float sigma, const struct nlkalman_params *prms) {
-  if (nlk_multi_devices() > 1) {
-    nlk_multi_frame(smoother, out, cur, prev, basic, w, h, ch, sigma, prms);
-    return;
-  }
+  if (nlk_multi_devices() > 1 && nlk_multi_frame(smoother, out, cur, prev, basic, w, h, ch, sigma, prms)) return;
   nlk_ctx *c = ctx();
   const size_t bytes = (size_t)w * h * ch * sizeof(float);
   float *d_cur = slot(c, 0, bytes), *d_out = slot(c, 3, bytes);

@@ -882,7 +882,7 @@ np.savez(sys.argv[2], f0=f0, f1=f1, f2=f2, s0=s0)
 """
 
 
-@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0"])
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0", "0,1"])
 def test_c_api_split_over_devices(built, tmp_path, devices):
     """NLK_DEVICES: the drop-in C API (libnlkalman.so, host/multidev.c) cuts a frame call into row
     strips over the listed devices - match per strip, mark words to every device, whole-grid mask
@@ -891,6 +891,8 @@ def test_c_api_split_over_devices(built, tmp_path, devices):
     equal the single-device call up to the order of the accumulator's atomic adds."""
     import subprocess
     import sys
+    if devices == "0,1" and built.hip().nlk_device_count() < 2:
+        pytest.skip("two distinct devices: needs a multi-GPU box (every entry point selects its context's device)")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "run.py"
     script.write_text(_MULTIDEV_SCRIPT)
@@ -907,3 +909,35 @@ def test_c_api_split_over_devices(built, tmp_path, devices):
             outs[tag] = {k: z[k] for k in z.files}
     for k in ("f0", "f1", "f2", "s0"):
         cases.assert_close(outs["split"][k], outs["one"][k], f"NLK_DEVICES={devices}: {k}", maxabs=5e-4, rmse=5e-5, flips=8)
+
+
+def test_c_api_device_list_falls_back_to_one_device(built, tmp_path):
+    """NLK_DEVICES with a configuration that cannot be split (a group reaching more than 3 grid cells:
+    4 x 4 patches with the default spatial radius 10) or with one listed index must behave like the
+    single-device call, not exit (host/multidev.c)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "run4.py"
+    script.write_text('''
+import importlib, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+pkg = importlib.import_module("bwd-nlkalman_amd")
+synth = importlib.import_module("bwd-nlkalman_amd.synth")
+n0, _, _ = synth.noisy_pair(120, 96, 3, 20.0, 3)
+p = pkg.default_params(20.0, pkg.FLT1, patch_sz=4)
+np.save(sys.argv[2], pkg.filter_frame(pkg.rgb2opp(n0), None, None, 20.0, p))
+''')
+    outs = {}
+    for tag, env in (("one", {}), ("list2", {"NLK_DEVICES": "0,0"}), ("list1", {"NLK_DEVICES": "0"})):
+        e = {k: v for k, v in os.environ.items() if k != "NLK_DEVICES"}
+        e.update(env)
+        out = tmp_path / f"{tag}.npy"
+        r = subprocess.run([sys.executable, str(script), root, str(out)], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        if tag == "list2":
+            assert "not split" in r.stderr
+        outs[tag] = np.load(out)
+    for tag in ("list2", "list1"):
+        cases.assert_close(outs[tag], outs["one"], f"NLK_DEVICES fallback ({tag})", maxabs=5e-4, rmse=5e-5, flips=8)

@@ -22,12 +22,18 @@ calls = {
     "FLT2 temporal": lambda: ctx.filter_frame(o2, d1, o0, o1, w, h, ch, sigma, p2),
     "SMO1": lambda: ctx.smooth_frame(o3, o0, o2, None, w, h, ch, sigma, p3),
 }
+import time
 for name, fn in calls.items():
     fn(); ctx.sync()
+    t0 = time.perf_counter()   # wall time without the profiler (the banded two-stream pipeline runs only then)
+    for _ in range(reps):
+        fn()
+    ctx.sync()
+    wall = (time.perf_counter() - t0) / reps * 1e3
     ctx.set_profiling(True)
     for _ in range(reps):
         fn()
     ctx.sync()
     tm = ctx.timings()
     ctx.set_profiling(False)
-    print(f"{name:14s} " + "  ".join(f"{k[:-3]} {v:.3f}" for k, v in tm.items()))
+    print(f"{name:14s} " + "  ".join(f"{k[:-3]} {v:.3f}" for k, v in tm.items()) + f"  wall {wall:.3f}")
