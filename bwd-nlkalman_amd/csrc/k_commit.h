@@ -271,9 +271,9 @@ k_mask_commit_wave(const uint32_t* __restrict__ skewed, uint8_t* __restrict__ ac
 // 1..3: marks (i-1, j+1), (i, j+1), (i+1, j+1); bit b of word w = column 32 w + b. All 64 words of a row
 // are written (zeros past the grid), launched over 2048 columns.
 __global__ void __launch_bounds__(256)
-k_marks_planes1(const uint64_t* __restrict__ marks, uint32_t* __restrict__ planes, int ngx) {
+k_marks_planes1(const uint64_t* __restrict__ marks, uint32_t* __restrict__ planes, int ngx, int j0) {
   constexpr int R = 1, side = 3, centre = R * side + R;
-  const int j = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  const int j = j0 + blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;  // (rows j0 .. : a band of the grid)
   const uint32_t fwd = i < ngx ? (uint32_t)(marks[(size_t)j * ngx + i] >> (centre + 1)) : 0u;
   const int lane = threadIdx.x & 63, w0 = i >> 5;  // (i of lane 0 of the wavefront is a multiple of 64)
 #pragma unroll
@@ -289,7 +289,11 @@ k_marks_planes1(const uint64_t* __restrict__ marks, uint32_t* __restrict__ plane
 // flight that swap roles (no copies).
 #define NLK_CR_BATCH 16  // rows per batch: the next batch's planes load while this one is replayed
 __global__ void __launch_bounds__(64)
-k_mask_commit_rows1(const uint32_t* __restrict__ planes, uint32_t* __restrict__ actbits, int ngx, int ngy) {
+// Rows [first, first + nrows) of the grid; the only state a row hands to the next - `a`, the columns marked
+// from above - is kept per row in `astate` (row j's input at astate[j]), so that a grid replayed in bands
+// (one call per band, in order) continues where the band before stopped.
+k_mask_commit_rows1(const uint32_t* __restrict__ planes, uint32_t* __restrict__ actbits,
+                    uint32_t* __restrict__ astate, int ngx, int first, int nrows) {
   const int lane = threadIdx.x;
   // columns of this word that exist
   const int nb = ngx - 32 * lane;
@@ -303,7 +307,8 @@ k_mask_commit_rows1(const uint32_t* __restrict__ planes, uint32_t* __restrict__ 
   constexpr int PF = NLK_CR_BATCH;
   const uint32_t* pp = planes + lane;
   uint32_t* ap = actbits + lane;
-  uint32_t a = 0;  // marked from above
+  uint32_t* sp = astate + lane;
+  uint32_t a = first ? sp[(size_t)first * 64] : 0u;  // marked from above
   auto load_batch = [&](uint32_t (&D)[PF][4], int jb) {
     const uint32_t* q = pp + (size_t)jb * 256;
 #pragma unroll
@@ -313,8 +318,10 @@ k_mask_commit_rows1(const uint32_t* __restrict__ planes, uint32_t* __restrict__ 
   };
   auto run_batch = [&](const uint32_t (&D)[PF][4], int jb) {
     uint32_t* o = ap + (size_t)jb * 64;
+    uint32_t* so = sp + (size_t)(jb + 1) * 64;
 #pragma unroll
-    for (int r = 0; r < PF; ++r) {  // (rows past the grid in the last batch: decisions land in the padding)
+    for (int r = 0; r < PF; ++r) {  // (rows past the band in its last batch: decisions and states land in rows the
+                                    //  next band rewrites, or in the padding)
       const uint32_t g = D[r][0] & ~a;
       // carries, assuming no carry enters the word
       const uint32_t sw = g & ~(g << 1);
@@ -340,23 +347,24 @@ k_mask_commit_rows1(const uint32_t* __restrict__ planes, uint32_t* __restrict__ 
       // marks for the row below
       const uint32_t ml = x & D[r][1], md = x & D[r][2], mr = x & D[r][3];
       a = ((ml >> 1) | (from_next(ml) << 31)) | md | ((mr << 1) | (from_prev(mr) >> 31));
+      so[r * 64] = a;
     }
   };
   uint32_t P[PF][4], Q[PF][4];
-  load_batch(P, 0);
-  for (int j0 = 0; j0 < ngy; j0 += 2 * PF) {
-    load_batch(Q, j0 + PF);
-    run_batch(P, j0);
-    if (j0 + PF >= ngy) break;
-    load_batch(P, j0 + 2 * PF);
-    run_batch(Q, j0 + PF);
+  load_batch(P, first);
+  for (int j0 = 0; j0 < nrows; j0 += 2 * PF) {
+    load_batch(Q, first + j0 + PF);
+    run_batch(P, first + j0);
+    if (j0 + PF >= nrows) break;
+    load_batch(P, first + j0 + 2 * PF);
+    run_batch(Q, first + j0 + PF);
   }
 }
 
 // bits -> the byte per target the group kernels read
 __global__ void __launch_bounds__(256)
-k_active_bytes(const uint32_t* __restrict__ actbits, uint8_t* __restrict__ active, int ngx) {
-  const int j = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+k_active_bytes(const uint32_t* __restrict__ actbits, uint8_t* __restrict__ active, int ngx, int j0) {
+  const int j = j0 + blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
   if (i < ngx) active[(size_t)j * ngx + i] = (actbits[(size_t)j * 64 + (i >> 5)] >> (i & 31)) & 1u;
 }
 

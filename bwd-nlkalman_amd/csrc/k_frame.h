@@ -9,8 +9,9 @@
 __global__ void __launch_bounds__(256)
 k_layout(const float* __restrict__ cur, float* __restrict__ pl_cur, const float* __restrict__ prev,
          float* __restrict__ pl_prev, const float* __restrict__ basic, float* __restrict__ pl_basic,
-         uint8_t* __restrict__ rowok, float* __restrict__ acc_zero, int w, int h, int ch, int psz, int planar) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+         uint8_t* __restrict__ rowok, float* __restrict__ acc_zero, int w, int h, int ch, int psz, int planar,
+         int y0) {  // (rows y0 .. y0 + gridDim.y - 1: a frame that arrives from the host in row bands)
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = y0 + blockIdx.y;
   if (x >= w) return;
   const size_t npix = (size_t)w * h, i = (size_t)y * w + x;
   if (planar) {  // (one channel: planar == interleaved, the images are used in place)
@@ -38,8 +39,8 @@ k_layout(const float* __restrict__ cur, float* __restrict__ pl_cur, const float*
 // (reference: src/nlkalman.c:605-609, 725-730 — only channel 0 is tested).
 // Two separable passes over a byte map: rows (in k_layout) then columns.
 __global__ void k_nan_cols(const uint8_t* __restrict__ rowok, uint8_t* __restrict__ valid,
-                           int w, int h, int psz) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+                           int w, int h, int psz, int y0) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = y0 + blockIdx.y;
   if (x >= w) return;
   uint8_t ok = (y + psz <= h);
   if (ok)
@@ -48,8 +49,8 @@ __global__ void k_nan_cols(const uint8_t* __restrict__ rowok, uint8_t* __restric
 }
 // the same on four pixels per thread (w % 4 == 0: rows of 32-bit words of 0 / 1 bytes)
 __global__ void k_nan_cols4(const uint32_t* __restrict__ rowok, uint32_t* __restrict__ valid,
-                            int w4, int h, int psz) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+                            int w4, int h, int psz, int y0) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = y0 + blockIdx.y;
   if (x >= w4) return;
   uint32_t ok = (y + psz <= h) ? 0x01010101u : 0u;
   if (ok)

@@ -5,6 +5,7 @@
 // call performs no allocation (context/alloc time is on the
 // CLI critical path).
 #include <math.h>
+#include <time.h>
 
 #include "k_commit.h"
 #include "k_frame.h"
@@ -147,7 +148,7 @@ void nlk_ctx_destroy(nlk_ctx* c) {
   if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
   Buf* bufs[] = {&c->pl_cur, &c->pl_prev, &c->pl_basic, &c->rowok, &c->vmap, &c->topk,
                  &c->tinfo, &c->gcoords, &c->marks, &c->active, &c->acc, &c->tabs, &c->wide, &c->tv, &c->skew, &c->ms,
-                 &c->slab, &c->tflag};
+                 &c->slab, &c->tflag, &c->hw_cur, &c->hw_prev, &c->hw_basic, &c->hw_out};
   for (Buf* b : bufs)
     if (b->p) hipFree(b->p);
   if (c->tv_host) (void)hipHostFree(c->tv_host);
@@ -157,6 +158,11 @@ void nlk_ctx_destroy(nlk_ctx* c) {
   }
   for (hipEvent_t e : c->sync_ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto& row : c->band_ev)
+    for (hipEvent_t e : row)
+      if (e) (void)hipEventDestroy(e);
+  if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
+  if (c->dn_stream) (void)hipStreamDestroy(c->dn_stream);
   if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
   (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -363,10 +369,31 @@ static NlkGeom band_geom(const NlkGeom& g, int r0, int rows) {
   return b;
 }
 
+// layout of the pixel rows [y0, y1) (planar copies, row test of the validity map, accumulator rows cleared) and
+// the validity map's column test for the rows [v0, v1) (a row needs the row tests of the psz rows from it on)
+static int layout_rows(nlk_ctx* c, const float* cur, const float* prev, const float* basic, float* acc_zero, int w,
+                       int h, int ch, int psz, int y0, int y1, int v0, int v1) {
+  const bool planar = ch != 1;  // (one channel: planar == interleaved)
+  if (y1 > y0 && (planar || prev || acc_zero))
+    hipLaunchKernelGGL(k_layout, dim3((w + 255) / 256, y1 - y0), dim3(256), 0, c->stream, cur, (float*)c->pl_cur.p, prev,
+                       (float*)c->pl_prev.p, basic, (float*)c->pl_basic.p, (uint8_t*)c->rowok.p, acc_zero, w, h, ch, psz,
+                       planar ? 1 : 0, y0);
+  if (prev && v1 > v0) {
+    if (w % 4 == 0)
+      hipLaunchKernelGGL(k_nan_cols4, dim3((w / 4 + 255) / 256, v1 - v0), dim3(256), 0, c->stream,
+                         (const uint32_t*)c->rowok.p, (uint32_t*)c->vmap.p, w / 4, h, psz, v0);
+    else
+      hipLaunchKernelGGL(k_nan_cols, dim3((w + 255) / 256, v1 - v0), dim3(256), 0, c->stream, (const uint8_t*)c->rowok.p,
+                         (uint8_t*)c->vmap.p, w, h, psz, v0);
+  }
+  HIPCHK(c, hipGetLastError());
+  return NLK_OK;
+}
+
 // phase 0: checks, geometry, layout (planar copies + validity map), scratch. Runs on c->stream.
 static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* prev, const float* basic, int w,
                       int h, int ch, float sigma, const struct nlkalman_params* P, int oy, int ngy,
-                      int smoother, int nbands, float* acc_zero = nullptr) {
+                      int smoother, int nbands, float* acc_zero = nullptr, bool do_layout = true) {
   int rc = check_images(c, cur, cur, w, h, ch);
   if (rc) return rc;
   if (!P) return fail(c, NLK_EINVAL, "null parameters");
@@ -415,7 +442,7 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   // ---- layout: planar copies + the row test of the validity map (+ clearing the accumulator of a
   // whole-frame call) in one kernel, the column test in a second
   {
-    const bool planar = ch != 1;  // (one channel: planar == interleaved)
+    const bool planar = ch != 1;  // (one channel: planar == interleaved, the images are used in place)
     pl.img_cur = cur; pl.img_prev = prev; pl.img_basic = basic;
     if (planar) {
       if ((rc = reserve(c, c->pl_cur, sizeof(float) * (size_t)npix * ch))) return rc;
@@ -426,17 +453,10 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
       if (basic) pl.img_basic = (const float*)c->pl_basic.p;
     }
     if (prev && ((rc = reserve(c, c->rowok, npix)) || (rc = reserve(c, c->vmap, npix)))) return rc;
-    const dim3 grd((w + 255) / 256, h);
-    if (planar || prev || acc_zero)
-      hipLaunchKernelGGL(k_layout, grd, dim3(256), 0, c->stream, cur, (float*)c->pl_cur.p, prev, (float*)c->pl_prev.p,
-                         basic, (float*)c->pl_basic.p, (uint8_t*)c->rowok.p, acc_zero, w, h, ch, g.psz, planar ? 1 : 0);
-    if (prev && w % 4 == 0)
-      hipLaunchKernelGGL(k_nan_cols4, dim3((w / 4 + 255) / 256, h), dim3(256), 0, c->stream, (const uint32_t*)c->rowok.p,
-                         (uint32_t*)c->vmap.p, w / 4, h, g.psz);
-    else if (prev)
-      hipLaunchKernelGGL(k_nan_cols, grd, dim3(256), 0, c->stream, (const uint8_t*)c->rowok.p,
-                         (uint8_t*)c->vmap.p, w, h, g.psz);
-    HIPCHK(c, hipGetLastError());
+    if (do_layout) {
+      int rc2 = layout_rows(c, cur, prev, basic, acc_zero, w, h, ch, g.psz, 0, h, 0, h);
+      if (rc2) return rc2;
+    }
   }
   if ((rc = upload_tables(c, g.psz))) return rc;
   if ((rc = reserve(c, c->topk, sizeof(uint32_t) * (size_t)ngrid * g.kmax)) ||
@@ -519,24 +539,29 @@ static int match_rows(nlk_ctx* c, const NlkPlan& pl, hipStream_t stream, int r0,
 // phase 2: replay of the raster-order processed mask over the mark words of the grid rows
 // [first, first + rows) (`marks` / `active` = whole-grid arrays). Rows before `first` are context:
 // their decisions must be final in `active`.
+// `total` = rows of the whole grid when it is replayed band by band (first > 0 continues the band before).
 static int commit_rows(nlk_ctx* c, hipStream_t stream, const uint64_t* marks, uint8_t* active, int ngx, int first,
-                       int nrows, int R) {
+                       int nrows, int R, int total = 0) {
+  total = max(total, first + nrows);
   if (R == 0) {
     // a group cannot reach another grid target: nothing is ever skipped
     HIPCHK(c, hipMemsetAsync(active + (size_t)first * ngx, 1, (size_t)nrows * ngx, stream));
     return NLK_OK;
   }
-  if (R == 1 && first == 0 && ngx <= 2048 && !getenv("NLK_COMMIT_WAVE") && !getenv("NLK_COMMIT_LDS")) {
-    // reach 1: one grid row per step on bit planes (k_commit.h); both arrays padded to whole batches
-    const int rows_pad = (nrows + NLK_CR_BATCH - 1) / NLK_CR_BATCH * NLK_CR_BATCH + 2 * NLK_CR_BATCH;
-    int rc = reserve(c, c->skew, sizeof(uint32_t) * (size_t)rows_pad * 5 * 64);  // 4 planes + the decisions
+  if (R == 1 && ngx <= 2048 && !getenv("NLK_COMMIT_WAVE") && !getenv("NLK_COMMIT_LDS") && !getenv("NLK_COMMIT_BAND")) {
+    // reach 1: one grid row per step on bit planes (k_commit.h); the arrays cover the whole grid, padded to
+    // whole batches (a band's last batch may run into the rows of the next): 4 planes + decisions + row states
+    const int rows_pad = (total + NLK_CR_BATCH - 1) / NLK_CR_BATCH * NLK_CR_BATCH + 3 * NLK_CR_BATCH;
+    int rc = reserve(c, c->skew, sizeof(uint32_t) * (size_t)rows_pad * 6 * 64);
     if (rc) return rc;
     uint32_t* planes = (uint32_t*)c->skew.p;
     uint32_t* actbits = planes + (size_t)rows_pad * 4 * 64;
-    hipLaunchKernelGGL(k_marks_planes1, dim3(8, nrows), dim3(256), 0, stream, marks, planes, ngx);
-    hipLaunchKernelGGL(k_mask_commit_rows1, dim3(1), dim3(64), 0, stream, (const uint32_t*)planes, actbits, ngx, nrows);
+    uint32_t* astate = actbits + (size_t)rows_pad * 64;
+    hipLaunchKernelGGL(k_marks_planes1, dim3(8, nrows), dim3(256), 0, stream, marks, planes, ngx, first);
+    hipLaunchKernelGGL(k_mask_commit_rows1, dim3(1), dim3(64), 0, stream, (const uint32_t*)planes, actbits, astate, ngx,
+                       first, nrows);
     hipLaunchKernelGGL(k_active_bytes, dim3((ngx + 255) / 256, nrows), dim3(256), 0, stream, (const uint32_t*)actbits,
-                       active, ngx);
+                       active, ngx, first);
     HIPCHK(c, hipGetLastError());
     return NLK_OK;
   }
@@ -659,7 +684,7 @@ static int frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const floa
   for (int b = 0; b < nb; ++b) {
     hipStream_t s = st[b & 1];
     if (b > 0) HIPCHK(c, hipStreamWaitEvent(s, ev[1 + ((b - 1) & 1)], 0));
-    if ((rc = commit_rows(c, s, (const uint64_t*)c->marks.p, active, g.ngx, r0[b], r0[b + 1] - r0[b], g.R))) return rc;
+    if ((rc = commit_rows(c, s, (const uint64_t*)c->marks.p, active, g.ngx, r0[b], r0[b + 1] - r0[b], g.R, g.ngy))) return rc;
     HIPCHK(c, hipEventRecord(ev[1 + (b & 1)], s));
     if ((rc = group_rows(c, s, acc, active + (size_t)r0[b] * g.ngx, r0[b], r0[b + 1] - r0[b], b))) return rc;
   }
@@ -765,6 +790,139 @@ int nlk_dev_smooth_frame(nlk_ctx* c, float* smoo1, const float* filt1, const flo
                          const float* bsic1, int w, int h, int ch, float sigma,
                          const struct nlkalman_params* P) {
   return run_frame(c, smoo1, filt1, smoo0, bsic1, w, h, ch, sigma, P, 1);
+}
+
+// ---- the frame functions on HOST images (what the drop-in API of include/nlkalman.h hands over: pageable
+// memory, src/nlkalman.h:46-53). A 1080p RGB call moves 75 MB up and 25 MB down over PCIe, as long as its
+// kernels run; done one after the other that is 3.2 ms for 1.35 ms of kernels. Here the frame travels in
+// row bands: band b is laid out, matched, its mask rows replayed and its groups filtered while band b+1 is
+// still on the link (the upload calls return when the host pages are staged, so the host issues them back
+// to back and the kernels follow one band behind), and the rows no later band can add to are normalised
+// and sent back while the last bands are still being filtered. Results: the banded pipeline's
+// (frame_accumulate), i.e. the whole-frame call's decisions and sums.
+static int frame_host(nlk_ctx* c, float* out_h, const float* cur_h, const float* prev_h, const float* basic_h, int w,
+                      int h, int ch, float sigma, const struct nlkalman_params* P, int smoother) {
+  int rc = check_images(c, out_h, cur_h, w, h, ch);
+  if (rc) return rc;
+  if (!P) return fail(c, NLK_EINVAL, "null parameters");
+  NLK_USE_DEVICE(c);
+  const size_t npix = (size_t)w * h, bytes = sizeof(float) * npix * ch, rowb = sizeof(float) * (size_t)w * ch;
+  if ((rc = reserve(c, c->hw_cur, bytes)) || (rc = reserve(c, c->hw_out, bytes)) ||
+      (prev_h && (rc = reserve(c, c->hw_prev, bytes))) || (basic_h && (rc = reserve(c, c->hw_basic, bytes))) ||
+      (rc = reserve(c, c->acc, sizeof(float) * npix * (ch + 1))))
+    return rc;
+  float *d_cur = (float*)c->hw_cur.p, *d_out = (float*)c->hw_out.p;
+  float *d_prev = prev_h ? (float*)c->hw_prev.p : nullptr, *d_basic = basic_h ? (float*)c->hw_basic.p : nullptr;
+  const int psz = P->patch_sz, step = psz / 2;
+  const int ngy = (psz >= 2 && h >= psz) ? (h - psz) / step + 1 : 0;
+  const int wall = smoother ? P->search_sz_t : max(P->search_sz_x, P->search_sz_t);  // reach of any window / group
+  const int R = ((smoother || prev_h) ? P->search_sz_t : P->search_sz_x) / max(step, 1);
+  int nb = getenv("NLK_HOST_BANDS") ? atoi(getenv("NLK_HOST_BANDS")) : 5;  // (1080p: 2 bands 2.43 ms, 3 2.30, 4 2.25, 5 2.20, 6 2.22; one upload + call + download 2.9)
+  nb = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
+  while (nb > 1 && ngy / nb < 4 * (R + 1) + 8) --nb;
+  if (nb < 2 || R > 3 || c->deterministic || c->profiling || psz > 16 || w < psz) {
+    // small frames, masks replayed from the coordinate lists, deterministic slabs, per-kernel timing, and
+    // everything the frame call rejects: one upload, the whole-frame call, one download
+    HIPCHK(c, hipMemcpyAsync(d_cur, cur_h, bytes, hipMemcpyHostToDevice, c->stream));
+    if (prev_h) HIPCHK(c, hipMemcpyAsync(d_prev, prev_h, bytes, hipMemcpyHostToDevice, c->stream));
+    if (basic_h) HIPCHK(c, hipMemcpyAsync(d_basic, basic_h, bytes, hipMemcpyHostToDevice, c->stream));
+    if ((rc = run_frame(c, d_out, d_cur, d_prev, d_basic, w, h, ch, sigma, P, smoother))) return rc;
+    HIPCHK(c, hipMemcpyAsync(out_h, d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return NLK_OK;
+  }
+  if (!c->up_stream) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->dn_stream, hipStreamNonBlocking));
+    for (auto& row : c->band_ev)
+      for (hipEvent_t& e : row) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  NlkPlan pl;
+  float* acc = (float*)c->acc.p;
+  if ((rc = plan_frame(c, pl, d_cur, d_prev, d_basic, w, h, ch, sigma, P, 0, ngy, smoother, 8, nullptr, false))) return rc;
+  const NlkGeom& g = pl.g;
+  uint8_t* active = (uint8_t*)c->active.p;
+  // the streams start behind whatever the context's stream was doing (the device images are reused call to call)
+  HIPCHK(c, hipEventRecord(c->sync_ev[0], c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->up_stream, c->sync_ev[0], 0));
+  HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->sync_ev[0], 0));
+  // Bands alternate between two streams, so that the tail of a band's kernels (a quarter of a frame does not
+  // fill the chip to the end) overlaps the next band's: E_UP uploaded, E_LAY laid out, E_MASK mask rows
+  // replayed, E_GRP groups filtered, E_DONE rows normalised.
+  enum { E_UP, E_LAY, E_MASK, E_GRP, E_DONE };
+  hipStream_t st[2] = {c->stream, c->aux_stream};
+  int up0 = 0, v0 = 0, nz0 = 0, nz[9];
+  nz[0] = 0;
+  const bool trace = getenv("NLK_HOST_TRACE") != nullptr;
+  struct timespec ts0, ts1, ts2;
+  if (trace) clock_gettime(CLOCK_MONOTONIC, &ts0);
+  hipStream_t const home = c->stream;
+  for (int b = 0; b < nb; ++b) {
+    const int r0 = (int)((long)ngy * b / nb), r1 = (int)((long)ngy * (b + 1) / nb);
+    const bool last = b + 1 == nb;
+    hipStream_t s = st[b & 1];
+    // pixel rows band b reads (windows, patches) and writes (group members): up to up1
+    const int up1 = last ? h : min(h, (r1 - 1) * step + wall + psz);
+    const size_t off = (size_t)up0 * w * ch;
+    HIPCHK(c, hipMemcpyAsync(d_cur + off, cur_h + off, rowb * (up1 - up0), hipMemcpyHostToDevice, c->up_stream));
+    if (prev_h) HIPCHK(c, hipMemcpyAsync(d_prev + off, prev_h + off, rowb * (up1 - up0), hipMemcpyHostToDevice, c->up_stream));
+    if (basic_h) HIPCHK(c, hipMemcpyAsync(d_basic + off, basic_h + off, rowb * (up1 - up0), hipMemcpyHostToDevice, c->up_stream));
+    HIPCHK(c, hipEventRecord(c->band_ev[E_UP][b], c->up_stream));
+    HIPCHK(c, hipStreamWaitEvent(s, c->band_ev[E_UP][b], 0));
+    if (b > 0) HIPCHK(c, hipStreamWaitEvent(s, c->band_ev[E_LAY][b - 1], 0));  // (the column test reads the rows before)
+    const int v1 = last ? h : up1 - psz + 1;
+    c->stream = s;  // (the layout helpers launch on the context's stream)
+    rc = layout_rows(c, d_cur, d_prev, d_basic, acc, w, h, ch, psz, up0, up1, v0, v1);
+    c->stream = home;
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->band_ev[E_LAY][b], s));
+    if ((rc = match_rows(c, pl, s, r0, r1 - r0, b))) return rc;
+    if (b > 0) HIPCHK(c, hipStreamWaitEvent(s, c->band_ev[E_MASK][b - 1], 0));
+    if ((rc = commit_rows(c, s, (const uint64_t*)c->marks.p, active, g.ngx, r0, r1 - r0, g.R, g.ngy))) return rc;
+    HIPCHK(c, hipEventRecord(c->band_ev[E_MASK][b], s));
+    if ((rc = group_rows(c, s, acc, active + (size_t)r0 * g.ngx, r0, r1 - r0, b))) return rc;
+    HIPCHK(c, hipEventRecord(c->band_ev[E_GRP][b], s));
+    // rows no later band adds to: the groups of the targets from row r1 on start at r1 * step - wall at the earliest
+    nz[b + 1] = last ? h : max(nz0, min(h, r1 * step - wall));
+    if (nz[b + 1] > nz0) {
+      if (b > 0) HIPCHK(c, hipStreamWaitEvent(s, c->band_ev[E_GRP][b - 1], 0));
+      hipLaunchKernelGGL(k_normalize, dim3(1024), dim3(256), 0, s, d_out, (const float*)acc, (const float*)d_cur, w, h,
+                         ch, nz0, nz[b + 1]);
+      HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipEventRecord(c->band_ev[E_DONE][b], s));
+    up0 = up1; v0 = v1; nz0 = nz[b + 1];
+  }
+  if (trace) clock_gettime(CLOCK_MONOTONIC, &ts1);
+  // the rows go back band by band: every upload has been issued by now, the kernels of the first bands are done
+  for (int b = 0; b < nb; ++b) {
+    if (nz[b + 1] <= nz[b]) continue;
+    HIPCHK(c, hipStreamWaitEvent(c->dn_stream, c->band_ev[E_DONE][b], 0));
+    const size_t off = (size_t)nz[b] * w * ch;
+    HIPCHK(c, hipMemcpyAsync(out_h + off, d_out + off, rowb * (nz[b + 1] - nz[b]), hipMemcpyDeviceToHost, c->dn_stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->dn_stream));
+  HIPCHK(c, hipStreamSynchronize(c->aux_stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (trace) {
+    clock_gettime(CLOCK_MONOTONIC, &ts2);
+    fprintf(stderr, "nlk frame_host: %d bands, uploads + launches issued after %.3f ms, downloads done after %.3f ms\n", nb,
+            (ts1.tv_sec - ts0.tv_sec) * 1e3 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-6,
+            (ts2.tv_sec - ts0.tv_sec) * 1e3 + (ts2.tv_nsec - ts0.tv_nsec) * 1e-6);
+  }
+  return NLK_OK;
+}
+
+int nlk_filter_frame_host(nlk_ctx* c, float* deno1, const float* nisy1, const float* deno0, const float* bsic1, int w,
+                          int h, int ch, float sigma, const struct nlkalman_params* P) {
+  if (!c) return fail(nullptr, NLK_EINVAL, "null context");
+  return frame_host(c, deno1, nisy1, deno0, bsic1, w, h, ch, sigma, P, 0);
+}
+
+int nlk_smooth_frame_host(nlk_ctx* c, float* smoo1, const float* filt1, const float* smoo0, const float* bsic1, int w,
+                          int h, int ch, float sigma, const struct nlkalman_params* P) {
+  if (!c) return fail(nullptr, NLK_EINVAL, "null context");
+  return frame_host(c, smoo1, filt1, smoo0, bsic1, w, h, ch, sigma, P, 1);
 }
 
 // the tables upload_tables() sends to the device, for tests that pin them (tests/test_fftw_pin.py)

@@ -45,6 +45,11 @@ struct nlk_ctx {
   NlkBuf ms;                      // whole-image DCT: temporary image + the two basis matrices
   NlkBuf tv;                      // TV-L1 pyramids and work images
   NlkBuf slab, tflag;             // deterministic aggregation: per-tile accumulator slabs + "written" flags (k_gather.h)
+  // host-pointer frame calls (nlk_frame_host): device copies of the caller's images, the streams the row bands
+  // travel on and the events that order them against the kernels
+  NlkBuf hw_cur, hw_prev, hw_basic, hw_out;
+  hipStream_t up_stream = nullptr, dn_stream = nullptr;
+  hipEvent_t band_ev[5][8] = {};  // per band: uploaded / laid out / mask rows replayed / groups filtered / rows normalised
   bool deterministic = false;     // nlk_ctx_set_deterministic / NLK_DETERMINISTIC=1
   NlkTvMail* tv_host = nullptr;   // pinned: the solver state, posted by the kernels (k_tvl1.h)
   unsigned tv_seq = 0;

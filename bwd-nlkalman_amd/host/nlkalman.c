@@ -52,12 +52,25 @@ static nlk_ctx *ctx(void) {
 
 nlk_ctx *nlkalman_hip_context(void) { return ctx(); } /* for the CLIs */
 
-static float *upload(nlk_ctx *c, const float *h, size_t n) {
-  void *d = NULL;
+/* Device buffers of the image helpers, kept between calls like the frame calls' (hipMalloc / hipFree
+ * cost ~0.5 ms per call at 1080p). The API is not re-entrant, like the reference's (its FFTW plans are
+ * global, src/nlkalman.c:570-575). */
+static float *slot(nlk_ctx *c, int i, size_t bytes) {
+  if (g_slot[i].cap < bytes) {
+    if (g_slot[i].p) nlk_dev_free(c, g_slot[i].p);
+    g_slot[i].p = NULL;
+    g_slot[i].cap = 0;
+    if (nlk_dev_alloc(c, &g_slot[i].p, bytes)) die("device buffers", c);
+    g_slot[i].cap = bytes;
+  }
+  return (float *)g_slot[i].p;
+}
+
+static float *upload(nlk_ctx *c, int i, const float *h, size_t n) {
   if (!h) return NULL;
-  if (nlk_dev_alloc(c, &d, n * sizeof(float)) || nlk_h2d(c, d, h, n * sizeof(float)))
-    die("upload", c);
-  return (float *)d;
+  float *d = slot(c, i, n * sizeof(float));
+  if (nlk_h2d(c, d, h, n * sizeof(float))) die("upload", c);
+  return d;
 }
 
 /* reference: src/nlkalman.c:92-110 */
@@ -65,9 +78,8 @@ void rgb2opp(float *im, int w, int h, int ch) {
   if (ch != 3) return;
   nlk_ctx *c = ctx();
   const size_t n = (size_t)w * h * ch;
-  float *d = upload(c, im, n);
+  float *d = upload(c, 0, im, n);
   if (nlk_dev_rgb2opp(c, d, w, h, ch) || nlk_d2h(c, im, d, n * sizeof(float))) die("rgb2opp", c);
-  nlk_dev_free(c, d);
 }
 
 /* reference: src/nlkalman.c:112-130 */
@@ -75,25 +87,18 @@ void opp2rgb(float *im, int w, int h, int ch) {
   if (ch != 3) return;
   nlk_ctx *c = ctx();
   const size_t n = (size_t)w * h * ch;
-  float *d = upload(c, im, n);
+  float *d = upload(c, 0, im, n);
   if (nlk_dev_opp2rgb(c, d, w, h, ch) || nlk_d2h(c, im, d, n * sizeof(float))) die("opp2rgb", c);
-  nlk_dev_free(c, d);
 }
 
 /* reference: src/nlkalman.c:71-88 */
 void warp_bicubic(float *imw, float *im, float *of, float *msk, int w, int h, int ch) {
   nlk_ctx *c = ctx();
   const size_t n = (size_t)w * h;
-  float *d_im = upload(c, im, n * ch), *d_of = upload(c, of, n * 2), *d_msk = upload(c, msk, n);
-  void *d_out = NULL;
-  if (nlk_dev_alloc(c, &d_out, n * ch * sizeof(float))) die("warp_bicubic", c);
-  if (nlk_dev_warp_bicubic(c, (float *)d_out, d_im, d_of, d_msk, w, h, ch) ||
-      nlk_d2h(c, imw, d_out, n * ch * sizeof(float)))
+  float *d_im = upload(c, 0, im, n * ch), *d_of = upload(c, 1, of, n * 2), *d_msk = upload(c, 2, msk, n);
+  float *d_out = slot(c, 3, n * ch * sizeof(float));
+  if (nlk_dev_warp_bicubic(c, d_out, d_im, d_of, d_msk, w, h, ch) || nlk_d2h(c, imw, d_out, n * ch * sizeof(float)))
     die("warp_bicubic", c);
-  nlk_dev_free(c, d_im);
-  nlk_dev_free(c, d_of);
-  if (d_msk) nlk_dev_free(c, d_msk);
-  nlk_dev_free(c, d_out);
 }
 
 /* reference: src/nlkalman.c:426-487 — sigma-dependent defaults for fields < 0.
@@ -134,21 +139,6 @@ void nlkalman_default_params(struct nlkalman_params *p, float sigma, enum FILTER
   }
 }
 
-/* Device buffers of the frame calls, kept between calls (a sequence calls the API once or twice
- * per frame with the same sizes: hipMalloc / hipFree per call cost ~0.5 ms of a 3.5 ms call). The
- * API is not re-entrant, like the reference's (its FFTW plans are global, src/nlkalman.c:570-575). */
-
-static float *slot(nlk_ctx *c, int i, size_t bytes) {
-  if (g_slot[i].cap < bytes) {
-    if (g_slot[i].p) nlk_dev_free(c, g_slot[i].p);
-    g_slot[i].p = NULL;
-    g_slot[i].cap = 0;
-    if (nlk_dev_alloc(c, &g_slot[i].p, bytes)) die("frame buffers", c);
-    g_slot[i].cap = bytes;
-  }
-  return (float *)g_slot[i].p;
-}
-
 /* host/multidev.c: the same call split over the devices of NLK_DEVICES */
 int nlk_multi_devices(void);
 int nlk_multi_frame(int smoother, float *out, const float *cur, const float *prev, const float *basic, int w, int h,
@@ -157,18 +147,12 @@ int nlk_multi_frame(int smoother, float *out, const float *cur, const float *pre
 static void frame_call(int smoother, float *out, float *cur, float *prev, float *basic, int w,
                        int h, int ch, float sigma, const struct nlkalman_params *prms) {
   if (nlk_multi_devices() > 1 && nlk_multi_frame(smoother, out, cur, prev, basic, w, h, ch, sigma, prms)) return;
+  /* host images in, host image out: the frame crosses PCIe in row bands while the bands before it are being
+   * matched and filtered (nlk_filter_frame_host, csrc/nlk_hip.hip) */
   nlk_ctx *c = ctx();
-  const size_t bytes = (size_t)w * h * ch * sizeof(float);
-  float *d_cur = slot(c, 0, bytes), *d_out = slot(c, 3, bytes);
-  float *d_prev = prev ? slot(c, 1, bytes) : NULL, *d_basic = basic ? slot(c, 2, bytes) : NULL;
-  if (nlk_h2d(c, d_cur, cur, bytes) || (prev && nlk_h2d(c, d_prev, prev, bytes)) ||
-      (basic && nlk_h2d(c, d_basic, basic, bytes)))
-    die("upload", c);
-  const int rc = smoother
-                     ? nlk_dev_smooth_frame(c, d_out, d_cur, d_prev, d_basic, w, h, ch, sigma, prms)
-                     : nlk_dev_filter_frame(c, d_out, d_cur, d_prev, d_basic, w, h, ch, sigma, prms);
-  if (rc || nlk_d2h(c, out, d_out, bytes))
-    die(smoother ? "nlkalman_smooth_frame" : "nlkalman_filter_frame", c);
+  const int rc = smoother ? nlk_smooth_frame_host(c, out, cur, prev, basic, w, h, ch, sigma, prms)
+                          : nlk_filter_frame_host(c, out, cur, prev, basic, w, h, ch, sigma, prms);
+  if (rc) die(smoother ? "nlkalman_smooth_frame" : "nlkalman_filter_frame", c);
 }
 
 /* reference: src/nlkalman.c:518-951 */
@@ -195,11 +179,11 @@ void Dual_TVL1_optic_flow_multiscale(float *I0, float *I1, float *u1, float *u2,
   nlk_ctx *c = ctx();
   const size_t n = (size_t)nxx * nyy;
   struct nlk_tvl1_params P = {tau, lambda, theta, nscales, fscale, zfactor, warps, epsilon};
-  float *d0 = upload(c, I0, n), *d1 = upload(c, I1, n);
-  void *d_flow = NULL;
+  float *d0 = upload(c, 0, I0, n), *d1 = upload(c, 1, I1, n);
+  float *d_flow = slot(c, 2, 2 * n * sizeof(float));
   float *flow = (float *)malloc(2 * n * sizeof(float));
-  if (!flow || nlk_dev_alloc(c, &d_flow, 2 * n * sizeof(float))) die("Dual_TVL1_optic_flow_multiscale", c);
-  if (nlk_dev_tvl1_flow(c, (float *)d_flow, d0, d1, nxx, nyy, &P, NULL) ||
+  if (!flow) die("Dual_TVL1_optic_flow_multiscale", c);
+  if (nlk_dev_tvl1_flow(c, d_flow, d0, d1, nxx, nyy, &P, NULL) ||
       nlk_d2h(c, flow, d_flow, 2 * n * sizeof(float)))
     die("Dual_TVL1_optic_flow_multiscale", c);
   for (size_t i = 0; i < n; ++i) {
@@ -207,7 +191,4 @@ void Dual_TVL1_optic_flow_multiscale(float *I0, float *I1, float *u1, float *u2,
     u2[i] = flow[2 * i + 1];
   }
   free(flow);
-  nlk_dev_free(c, d0);
-  nlk_dev_free(c, d1);
-  nlk_dev_free(c, d_flow);
 }

@@ -114,6 +114,16 @@ int nlk_dev_smooth_frame(nlk_ctx *ctx, float *smoo1, const float *filt1,
                          const float *smoo0, const float *bsic1, int w, int h,
                          int ch, float sigma, const struct nlkalman_params *prms);
 
+/* the same two functions on HOST images (pageable memory, what src/nlkalman.h:46-53 hands over): the frame
+ * travels over PCIe in row bands while the bands before it are matched and filtered, and the finished rows
+ * travel back while the last bands are filtered. Synchronous: the output is complete on return. */
+int nlk_filter_frame_host(nlk_ctx *ctx, float *deno1, const float *nisy1, const float *deno0,
+                          const float *bsic1, int w, int h, int ch, float sigma,
+                          const struct nlkalman_params *prms);
+int nlk_smooth_frame_host(nlk_ctx *ctx, float *smoo1, const float *filt1, const float *smoo0,
+                          const float *bsic1, int w, int h, int ch, float sigma,
+                          const struct nlkalman_params *prms);
+
 /* ---- optical flow between two frames: the dual TV-L1 method the
  * pipelines run before every filter call (scripts/nlkalman-seq.sh:57-66). Images are
  * single-channel float (w*h); `flow` receives w*h interleaved (u, v) pairs, the layout

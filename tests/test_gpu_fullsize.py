@@ -83,3 +83,32 @@ def test_deterministic_mode_against_serial_oracle_1080p(built, O, synth):
     _check_records(rec, tr, "deterministic 1080p")
     g, n_edge = _excuse_threshold_pixels(g, r, tr, "deterministic 1080p", 64)
     cases.assert_close(g, r, "deterministic 1080p", flips=0)
+
+
+def test_host_pointer_calls_pipeline_the_frame_in_row_bands(ctx, built, synth, monkeypatch):
+    """The drop-in API (host pointers, libnlkalman.so -> nlk_filter_frame_host) moves a frame over PCIe in
+    row bands while the bands before are matched and filtered, and returns finished rows while the last
+    bands are filtered. Same decisions as the whole-frame device call, so: equal up to the order of the
+    accumulator's atomic adds, for every kind of call of the flt1 -> flt2 -> smo1 chain at 1080p (incl. a
+    previous frame with a NaN ring and an occlusion hole: validity map built band by band), and for 2 and
+    8 bands."""
+    w, h, ch, sigma = 1920, 1080, 3, 20.0
+    n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, 1)
+    o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+    p1, p2, ps = (built.default_params(sigma, m) for m in (built.FLT1, built.FLT2, built.SMO1))
+    d0, _ = _dev_frame(ctx, False, o0, None, None, sigma, p1)
+    hole = d0.copy()
+    hole[:1], hole[-2:], hole[:, :1], hole[:, -2:] = np.nan, np.nan, np.nan, np.nan   # the warp's NaN ring
+    hole[500:540, 900:1000] = np.nan
+    d1, _ = _dev_frame(ctx, False, o1, hole, None, sigma, p1)
+    d2, _ = _dev_frame(ctx, False, o1, hole, d1, sigma, p2)
+    ds, _ = _dev_frame(ctx, True, d0, d2, None, sigma, ps)
+    for bands in (None, "2", "8"):
+        if bands:
+            monkeypatch.setenv("NLK_HOST_BANDS", bands)
+        tag = f"host bands {bands or 'default'}"
+        cases.assert_close(built.filter_frame(o0, None, None, sigma, p1), d0, f"{tag}: flt1 spatial", flips=40)
+        cases.assert_close(built.filter_frame(o1, hole, None, sigma, p1), d1, f"{tag}: flt1 temporal", flips=40)
+        if bands is None:
+            cases.assert_close(built.filter_frame(o1, hole, d1, sigma, p2), d2, f"{tag}: flt2", flips=40)
+            cases.assert_close(built.smooth_frame(d0, d2, None, sigma, ps), ds, f"{tag}: smo1", flips=40)
