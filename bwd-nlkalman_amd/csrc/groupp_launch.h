@@ -28,7 +28,7 @@ static int nlk_groupp_launch_t(nlk_ctx* c, const NlkGeom& g, const float* img, c
     tl.nty = g.ngy;
     const int rw_max = 2 * tl.wmax + g.psz;
     tl.rh_max = rw_max;
-    // one aggregation access = PSZ rows x NBK blocks of PB pixels (lane = PSZ * block + row): the row
+    // one aggregation access = PSZ rows x NBK blocks of PB pixels (lane = NBK * row + block): the row
     // stride with the fewest bank collisions among those addresses (two halves of 32 lanes)
     int best = 1 << 30;
     tl.rwp = rw_max;
@@ -37,7 +37,7 @@ static int nlk_groupp_launch_t(nlk_ctx* c, const NlkGeom& g, const float* img, c
       for (int half = 0; half < 2; ++half) {
         int cnt[32] = {0}, mx = 0;
         for (int l = 32 * half; l < 32 * half + 32 && l < PSZ * K::NBK; ++l) {
-          const int v = ++cnt[((l % PSZ) * r + K::PB * (l / PSZ)) & 31];
+          const int v = ++cnt[((l / K::NBK) * r + K::PB * (l % K::NBK)) & 31];
           mx = v > mx ? v : mx;
         }
         cost += mx;

@@ -211,13 +211,18 @@ k_groupp(const float* __restrict__ img,   // matching / statistics image (planar
   float* const tsc = scratch + sl * TS;
 #define NLK_PP_FWD(p) do { nlk_pp_dct_fwd<PSZ>(p, basis); nlk_pp_transpose<PSZ>(p, tsc, u, on); nlk_pp_dct_fwd<PSZ>(p, basis); } while (0)
 #define NLK_PP_INV(p) do { nlk_pp_dct_inv<PSZ>(p, basis); nlk_pp_transpose<PSZ>(p, tsc, u, on); nlk_pp_dct_inv<PSZ>(p, basis); } while (0)
-  // aggregation role: row u, pixels PB*slot .. PB*slot + PB-1 of ONE member (slots 0 .. NBK-1)
-  const bool agg_on = slot < NBK;
+  // aggregation role (pass B; independent of the transform role): lane = NBK * row + block adds pixels
+  // PB*block .. PB*block + PB-1 of row `au` of ONE member. Row-major over the lanes: the 32 lanes of a
+  // half-wavefront then read 8 staged rows (pitch PP = 12 floats at 12 x 12: banks 12 au + 3 ablk, all
+  // different) - with lane = PSZ * block + row, rows au and au + 8 met on one bank (round 2's 19 %
+  // conflict cycles, profiles/README.md round 3)
+  const int au = lane / NBK, ablk = lane - NBK * au;
+  const bool agg_on = lane < PSZ * NBK;
   float wv[PB];
 #pragma unroll
   for (int e = 0; e < PB; ++e) {
-    const int x = PB * (agg_on ? slot : 0) + e;
-    wv[e] = x < PSZ ? window[u * PSZ + x] : 0.f;
+    const int x = PB * (agg_on ? ablk : 0) + e;
+    wv[e] = (agg_on && x < PSZ) ? window[au * PSZ + x] : 0.f;
   }
   const size_t npix = (size_t)g.w * g.h;
   const float* src = g.have_basic ? cur : img;  // patches that get filtered
@@ -320,8 +325,11 @@ k_groupp(const float* __restrict__ img,   // matching / statistics image (planar
           const bool v = valid && ((vw >> (cl & 63)) & 1ull);
           vm = v ? 1.f : 0.f;
           const int org = cand_org(cl);
-          pa = img_c + org;
-          pb = v ? img_c + prev_off + org : img_c + org0;  // (no valid previous patch: candidate 0's image = x0)
+          // no valid previous patch: the "previous" rows are candidate 0's image rows (= x0: exact zeros in the
+          // sums), and in the filter - whose Kalman branch uses no image statistics - the image rows too, so
+          // that the transition term is an exact zero as well and needs no mask
+          pa = (HP && !SMO && !v) ? img_c + org0 : img_c + org;
+          pb = v ? img_c + prev_off + org : img_c + org0;
         };
         // one step: the rows in (a, b) are transformed and accumulated while the next step's rows
         // travel into (na, nb); the two register sets swap roles from step to step
@@ -361,15 +369,17 @@ k_groupp(const float* __restrict__ img,   // matching / statistics image (planar
           if constexpr (HP) {
 #pragma unroll
             for (int r = 0; r < PSZ; ++r) {
-              const float da = a[r] - x0[r], db = b[r] - x0[r];
+              const float db = b[r] - x0[r];
               if constexpr (IMG) {
+                const float da = a[r] - x0[r];
                 S[0][r] += da;
                 S[1][r] = fmaf(da, da, S[1][r]);
               }
               S[P0][r] += db;
               S[P0 + 1][r] = fmaf(db, db, S[P0 + 1][r]);
-              const float df = db - da;  // reference: :769-783, smoother :1659-1667
-              S[P0 + 2][r] = fmaf(vm * df, df, S[P0 + 2][r]);
+              const float df = b[r] - a[r];  // reference: :769-783, smoother :1659-1667
+              if constexpr (SMO) S[P0 + 2][r] = fmaf(vm * df, df, S[P0 + 2][r]);
+              else S[P0 + 2][r] = fmaf(df, df, S[P0 + 2][r]);
             }
           } else {
 #pragma unroll
@@ -470,36 +480,36 @@ k_groupp(const float* __restrict__ img,   // matching / statistics image (planar
       const int qx = nlk_x(q), qy = nlk_y(q);
       const int lx = qx - rx0, ly = qy - ry0;
       if (agg_on) {
-        const float* sp = scratch + (s * PSZ + u) * PP + PB * slot;
+        const float* sp = scratch + (s * PSZ + au) * PP + PB * ablk;
         float v[PB];
 #pragma unroll
         for (int e = 0; e < PB; ++e) v[e] = sp[e];  // (reads of the row's padding where PB*slot + e >= PSZ: weight 0)
         if (lx >= 0 && ly >= 0 && lx + PSZ <= rw && ly + PSZ <= rh) {
-          float* dst = vplane + (ly + u) * rwp + lx + PB * slot;
+          float* dst = vplane + (ly + au) * rwp + lx + PB * ablk;
           float o[PB];
 #pragma unroll
-          for (int e = 0; e < PB; ++e) o[e] = PB * slot + e < PSZ ? dst[e] : 0.f;
+          for (int e = 0; e < PB; ++e) o[e] = PB * ablk + e < PSZ ? dst[e] : 0.f;
 #pragma unroll
           for (int e = 0; e < PB; ++e)
-            if (PB * slot + e < PSZ) dst[e] = fmaf(ww[e], v[e], o[e]);
+            if (PB * ablk + e < PSZ) dst[e] = fmaf(ww[e], v[e], o[e]);
           if (c == 0) {
-            float* dw = wplane + (ly + u) * rwp + lx + PB * slot;
+            float* dw = wplane + (ly + au) * rwp + lx + PB * ablk;
 #pragma unroll
-            for (int e = 0; e < PB; ++e) o[e] = PB * slot + e < PSZ ? dw[e] : 0.f;
+            for (int e = 0; e < PB; ++e) o[e] = PB * ablk + e < PSZ ? dw[e] : 0.f;
 #pragma unroll
             for (int e = 0; e < PB; ++e)
-              if (PB * slot + e < PSZ) dw[e] = o[e] + ww[e];
+              if (PB * ablk + e < PSZ) dw[e] = o[e] + ww[e];
           }
         } else {
-          float* dst = acc + (size_t)c * npix + (size_t)(qy + u) * g.w + qx + PB * slot;
+          float* dst = acc + (size_t)c * npix + (size_t)(qy + au) * g.w + qx + PB * ablk;
 #pragma unroll
           for (int e = 0; e < PB; ++e)
-            if (PB * slot + e < PSZ) unsafeAtomicAdd(dst + e, ww[e] * v[e]);
+            if (PB * ablk + e < PSZ) unsafeAtomicAdd(dst + e, ww[e] * v[e]);
           if (c == 0) {
-            float* dw = acc + (size_t)CH * npix + (size_t)(qy + u) * g.w + qx + PB * slot;
+            float* dw = acc + (size_t)CH * npix + (size_t)(qy + au) * g.w + qx + PB * ablk;
 #pragma unroll
             for (int e = 0; e < PB; ++e)
-              if (PB * slot + e < PSZ) unsafeAtomicAdd(dw + e, ww[e]);
+              if (PB * ablk + e < PSZ) unsafeAtomicAdd(dw + e, ww[e]);
           }
         }
       }

@@ -1,26 +1,28 @@
 #!/bin/bash
 # End-of-round evidence run (gpurun): bench lines, rocprofv3 kernel statistics and PMC passes
-# (separate --pmc runs, kernel-trace only, program directly after `--`) for the C2 and C3 workloads.
+# (separate --pmc runs, kernel-trace only, program directly after `--`) for the C2, C3 and F1 workloads.
 #   tools/profile_round.sh <tag>      -> gpurun_out/<tag>/ ; then tools/make_traffic.py <tag>
+# Every command runs under `timeout` (a profiler that does not come back must not eat the GPU budget).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for W in C2 C3 C1; do python3 $ROOT/bench.py --workload $W > $OUT/bench_$W.json 2> $OUT/bench_$W.err; done
-python3 $ROOT/bench.py --workload C5 --no-cpu > $OUT/bench_C5.json 2> $OUT/bench_C5.err
-python3 $ROOT/bench.py --workload F1 > $OUT/bench_F1.json 2> $OUT/bench_F1.err
-python3 $ROOT/bench.py --workload S1 --steps 10 --warmup 2 > $OUT/bench_S1.json 2> $OUT/bench_S1.err
-NLK_DETERMINISTIC=1 python3 $ROOT/bench.py --no-cpu > $OUT/bench_C2_deterministic.json 2>/dev/null
-NLK_DETERMINISTIC=1 python3 $ROOT/bench.py --no-cpu --workload C3 > $OUT/bench_C3_deterministic.json 2>/dev/null
-NLK_GROUP_PACKED=1 python3 $ROOT/bench.py --no-cpu > $OUT/bench_C2_packed.json 2>/dev/null
-NLK_GROUP12_ROWS=1 python3 $ROOT/bench.py --no-cpu --workload C3 > $OUT/bench_C3_rows.json 2>/dev/null
-NLK_MATCH_NOBLOCK=1 python3 $ROOT/bench.py --no-cpu > $OUT/bench_C2_noblock.json 2>/dev/null
-NLK_MATCH_NOBLOCK=1 python3 $ROOT/bench.py --no-cpu --workload C3 > $OUT/bench_C3_noblock.json 2>/dev/null
-NLK_COMMIT_WAVE=1 python3 $ROOT/bench.py --no-cpu > $OUT/bench_C2_commit_wave.json 2>/dev/null
+T="timeout 300"
+for W in C2 C3 C1; do $T python3 $ROOT/bench.py --workload $W > $OUT/bench_$W.json 2> $OUT/bench_$W.err; done
+$T python3 $ROOT/bench.py --workload C5 --no-cpu > $OUT/bench_C5.json 2> $OUT/bench_C5.err
+$T python3 $ROOT/bench.py --workload F1 > $OUT/bench_F1.json 2> $OUT/bench_F1.err
+$T python3 $ROOT/bench.py --workload S1 --steps 10 --warmup 2 > $OUT/bench_S1.json 2> $OUT/bench_S1.err
+NLK_DETERMINISTIC=1 $T python3 $ROOT/bench.py --no-cpu > $OUT/bench_C2_deterministic.json 2>/dev/null
+NLK_DETERMINISTIC=1 $T python3 $ROOT/bench.py --no-cpu --workload C3 > $OUT/bench_C3_deterministic.json 2>/dev/null
+# the N > 1 code path of bench.py on the one GPU of this box (every rank on device 0 over gloo): plumbing, NOT a measurement
+NLK_BENCH_ONE_GPU=1 timeout 600 python3 $ROOT/bench.py --gpus 2 --steps 5 --warmup 2 --phase-times > $OUT/bench_C2_2ranks_onegpu.json 2> $OUT/bench_C2_2ranks_onegpu.err
+NLK_BENCH_ONE_GPU=1 timeout 900 python3 $ROOT/bench.py --gpus 8 --steps 5 --warmup 2 --phase-times > $OUT/bench_C2_8ranks_onegpu.json 2> $OUT/bench_C2_8ranks_onegpu.err
+$T python3 $ROOT/tools/mode_times.py > $OUT/mode_times_1080p.txt 2>&1
+NLK_HOST_TRACE=1 $T python3 $ROOT/tools/api_wall.py > $OUT/api_wall.txt 2>&1
 for W in C2 C3; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -o s -- python3 $ROOT/bench.py --no-cpu --workload $W > $OUT/bench_${W}_under_rocprof.json 2>/dev/null
+  $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -o s -- python3 $ROOT/bench.py --no-cpu --workload $W > $OUT/bench_${W}_under_rocprof.json 2>/dev/null
   i=0
   for SET in \
    "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" \
@@ -28,10 +30,16 @@ for W in C2 C3; do
    "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 GRBM_GUI_ACTIVE" \
    "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum"; do
     i=$((i+1))
-    rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/pmc_$W/p$i -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --workload $W > /dev/null 2>&1
+    $T rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/pmc_$W/p$i -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --workload $W > /dev/null 2>&1
   done
   python3 $ROOT/tools/pmc_summary.py $OUT/pmc_$W > $OUT/pmc_${W}_summary.txt 2>&1
 done
+i=0
+for SET in "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  $T rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/pmc_F1/p$i -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --workload F1 > /dev/null 2>&1
+done
+python3 $ROOT/tools/pmc_summary.py $OUT/pmc_F1 > $OUT/pmc_F1_summary.txt 2>&1
 find $OUT -name "*_kernel_stats.csv" | head
 find $OUT -name "*.csv" -size +6M -delete
 find $OUT -name "*.db" -delete
