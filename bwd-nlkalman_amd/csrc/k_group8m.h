@@ -35,6 +35,16 @@
 
 typedef float nlk_f4 __attribute__((ext_vector_type(4)));
 
+// tiles per chunk of the XCD-aware tile order (see the kernel); the grid is nlk_g8m_grid(ntx, nty) workgroups
+#ifndef NLK_G8_CW
+#define NLK_G8_CW 16
+#define NLK_G8_CH 4
+#endif
+static inline int nlk_g8m_grid(int ntx, int nty) {
+  const int nch = ((ntx + NLK_G8_CW - 1) / NLK_G8_CW) * ((nty + NLK_G8_CH - 1) / NLK_G8_CH);
+  return ((nch + 7) / 8) * 8 * NLK_G8_CW * NLK_G8_CH;
+}
+
 __device__ __forceinline__ float nlk_bperm(float v, int src_lane) {
   return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
 }
@@ -97,11 +107,21 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [(CH+1)][plane]
   constexpr int PSZ = 8, step = 4;
   const int lane = threadIdx.x;
-  // (tiles in launch order: the XCD-band order of nlk_xcd_tile left whole XCDs idle at the end of a launch -
-  // the bands differ in skipped targets - and measured 2 % slower, profiles/README.md round 3)
-  const int tile_id = blockIdx.x;
-  if (tile_id >= tl.ntx * tl.nty) return;
-  const int tile_x = tile_id % tl.ntx, tile_y = tile_id / tl.ntx;
+  // Tile order. Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, nlk_common.h); tiles that
+  // share halo rows should meet in one XCD's L2, but one contiguous band of the frame per XCD (nlk_xcd_tile)
+  // leaves whole XCDs idle at the end of a launch - the bands differ in skipped targets (2 % of the kernel) -
+  // and plain launch order spreads every neighbourhood over all eight L2s (8x the fetched bytes). So: chunks
+  // of NLK_G8_CW x NLK_G8_CH tiles, dealt round-robin to the XCDs, each worked through by one XCD.
+  int tile_x, tile_y;
+  {
+    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+    const int nchx = (tl.ntx + NLK_G8_CW - 1) / NLK_G8_CW;
+    const int chunk = (i / (NLK_G8_CW * NLK_G8_CH)) * 8 + xcd, within = i % (NLK_G8_CW * NLK_G8_CH);
+    tile_x = (chunk % nchx) * NLK_G8_CW + within % NLK_G8_CW;
+    tile_y = (chunk / nchx) * NLK_G8_CH + within / NLK_G8_CW;
+    if (tile_x >= tl.ntx || tile_y >= tl.nty) return;
+  }
+  const int tile_id = tile_y * tl.ntx + tile_x;
   const int gx0 = tile_x * tl.tgx, gy0 = tile_y * tl.tgy;
   const int cx = min(tl.tgx, g.ngx - gx0), cy = min(tl.tgy, g.ngy - gy0);
   const int rx0 = max(gx0 * step - tl.wmax, 0);

@@ -89,7 +89,7 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
     HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
     const float* basis = (const float*)c->tabs.p;
-    hipLaunchKernelGGL(kern, dim3(mfma ? tl.ntx * tl.nty : nlk_xcd_grid(tl.ntx * tl.nty)), dim3(64), lds, c->rv.stream, img, cur, prev,
+    hipLaunchKernelGGL(kern, dim3(mfma ? nlk_g8m_grid(tl.ntx, tl.nty) : nlk_xcd_grid(tl.ntx * tl.nty)), dim3(64), lds, c->rv.stream, img, cur, prev,
                        (const uint8_t*)c->vmap.p, g, tl, (const uint32_t*)c->rv.topk,
                        (const NlkTarget*)c->rv.tinfo, (const uint32_t*)c->rv.gcoords,
                        active, basis, basis + PSZ * PSZ, acc);
