@@ -36,6 +36,11 @@
 typedef float nlk_f4 __attribute__((ext_vector_type(4)));
 
 // tiles per chunk of the XCD-aware tile order (see the kernel); the grid is nlk_g8m_grid(ntx, nty) workgroups
+// floats per channel of the gain stash ([gain | (1-gain)*mean][quadrant][16 coefficients] = 128, + 8: pass B reads
+// 16 bytes per lane at channel * stride + 4 * lane group, and with a stride of 128 = 0 (mod 64 banks) two channels
+// of every 16-lane group met on one bank: round 2's 19 % SQ_LDS_BANK_CONFLICT, now 0. Not + 16: 12.9 KB instead of
+// 12.7 KB per workgroup costs a workgroup per CU - LDS is handed out in 1280-byte pieces - and 3.7 % of the time)
+#define NLK_G8_SST 136
 #ifndef NLK_G8_CW
 #define NLK_G8_CW 16
 #define NLK_G8_CH 4
@@ -153,11 +158,11 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   bool any_target = false;  // (deterministic mode: a tile without work writes no slab)
   for (int i = lane; i < (CH + 1) * plane / 4; i += 64)  // (plane is a multiple of 16)
     reinterpret_cast<nlk_f4*>(smem)[i] = nlk_f4{0.f, 0.f, 0.f, 0.f};
-  // [CH+2][2][4][16]: gains / means between the passes. Pass B treats the weight plane as one more
+  // [CH+2][NLK_G8_SST]: gains / means between the passes ([2][4][16] floats per channel + padding). Pass B treats the weight plane as one more
   // channel (gain 0, mean = DCT of a constant-1 patch: 8 at the DC coefficient) and the unused slots
   // of a 1-channel frame as another (all zero), so that its shrinkage is one fma without selects
   float* stash = smem + (CH + 1) * plane;
-  for (int i = lane; i < 2 * 128; i += 64) stash[CH * 128 + i] = (i == 64) ? 8.f : 0.f;
+  for (int i = lane; i < 2 * NLK_G8_SST; i += 64) stash[CH * NLK_G8_SST + i] = (i == 64) ? 8.f : 0.f;
   __syncthreads();
 
   const int lo = lane & 15, g4 = lane >> 4;
@@ -406,8 +411,8 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
             part_sum += term;
             // parked in LDS for pass B: [channel][gain | (1-a)*mean][quadrant][coefficient]
             // (filter: a*PG + (1-a)*M, reference: :879, :902)
-            stash[((ch * 2 + 0) * 4 + g4) * 16 + lo] = a;
-            stash[((ch * 2 + 1) * 4 + g4) * 16 + lo] = (1 - a) * m;
+            stash[ch * NLK_G8_SST + g4 * 16 + lo] = a;
+            stash[ch * NLK_G8_SST + 64 + g4 * 16 + lo] = (1 - a) * m;
           }
 #pragma unroll
           for (int a = 0; a < 6; ++a)
@@ -445,8 +450,8 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) ww[kk] = wgt * win[kk];
     const int bst = min(bch, CH + 1);  // stash channel of slot lo: image channel, weights, or nothing
-    const float* st_g = stash + (bst * 2 + 0) * 64 + 4 * g4;  // + 16*q: gains of coefficients 4*g4 .. 4*g4+3
-    const float* st_m = stash + (bst * 2 + 1) * 64 + 4 * g4;
+    const float* st_g = stash + bst * NLK_G8_SST + 4 * g4;  // + 16*q: gains of coefficients 4*g4 .. 4*g4+3
+    const float* st_m = stash + bst * NLK_G8_SST + 64 + 4 * g4;
     for (int n0 = 0; n0 < nagg; n0 += 4) {
       nlk_f4 Y[4], Z[4];
       nlk_fold(R, F);

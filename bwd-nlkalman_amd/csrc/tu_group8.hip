@@ -55,7 +55,7 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
       tl.rwp = rw_max | 1;
       tl.plane = tl.rwp * tl.rh_max;
     }
-    const size_t lds = sizeof(float) * ((size_t)(CH + 1) * tl.plane + (mfma ? (CH + 2) * 128 : 0));
+    const size_t lds = sizeof(float) * ((size_t)(CH + 1) * tl.plane + (mfma ? (CH + 2) * NLK_G8_SST : 0));
     if (lds > 160 * 1024) return fail(c, NLK_EUNSUP, "aggregation tile needs %zu bytes of LDS", lds);
     const size_t ntiles = (size_t)tl.ntx * tl.nty;
     if (c->deterministic) {
