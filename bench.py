@@ -413,9 +413,9 @@ def main():
             return ctx.strip_match(marks.data_ptr(), cur.data_ptr(), prev.data_ptr(), None, w,
                                    cur.shape[0], ch, sigma, p, oy, ngy_)
 
-        def match_rows(marks, cur, prev, oy, ngy_, r0, rows):
-            return ctx.strip_match_rows(marks.data_ptr(), cur.data_ptr(), prev.data_ptr(), None, w,
-                                        cur.shape[0], ch, sigma, p, oy, ngy_, r0, rows)
+        def match_rows(marks, cur, prev, oy, ngy_, r0, rows, lay):
+            return ctx.strip_match_part(marks.data_ptr(), cur.data_ptr(), prev.data_ptr(), None, w,
+                                        cur.shape[0], ch, sigma, p, oy, ngy_, r0, rows, lay)
 
         def commit(marks_full, ngx_, ngy_, reach, active_full):
             ctx.mask_commit(marks_full.data_ptr(), ngx_, ngy_, reach, active_full.data_ptr())

@@ -30,7 +30,7 @@ HIP_SYMBOLS = [
     "nlk_dev_strip_match", "nlk_dev_strip_match_rows", "nlk_dev_mask_commit", "nlk_dev_strip_group",
     "nlk_tvl1_default_params", "nlk_tvl1_scales", "nlk_dev_tvl1_flow", "nlk_dev_gray",
     "nlk_dev_occlusion_mask", "nlk_dev_image_dct", "nlk_dev_copy_block", "nlk_host_tables", "nlk_ctx_set_deterministic", "nlk_dev_zero", "nlk_dev_add", "nlk_dev_copy_peer",
-    "nlk_filter_frame_host", "nlk_smooth_frame_host",
+    "nlk_filter_frame_host", "nlk_smooth_frame_host", "nlk_dev_strip_match_part",
 ]
 API_SYMBOLS = [
     "rgb2opp", "opp2rgb", "warp_bicubic", "nlkalman_default_params",
@@ -118,6 +118,8 @@ def hip():
         L.nlk_dev_strip_match.argtypes = [vp, fp, fp, fp, i, i, i, f, C.POINTER(Params), i, i, i,
                                           vp, C.POINTER(i)]
         L.nlk_dev_strip_match_rows.argtypes = [vp, fp, fp, fp, i, i, i, f, C.POINTER(Params), i, i, i, i, i,
+                                               vp, C.POINTER(i)]
+        L.nlk_dev_strip_match_part.argtypes = [vp, fp, fp, fp, i, i, i, f, C.POINTER(Params), i, i, i, i, i, i, i, i, i,
                                                vp, C.POINTER(i)]
         L.nlk_dev_mask_commit.argtypes = [vp, vp, i, i, i, vp]
         L.nlk_dev_strip_group.argtypes = [vp, fp, vp]
@@ -373,6 +375,15 @@ class Context:
         self._chk(self.L.nlk_dev_strip_match_rows(self.h, d_cur, d_prev, d_basic, w, h, ch, float(sigma),
                                                   C.byref(params), oy, ngy, int(smoother), r0, rows, d_marks,
                                                   C.byref(r)))
+        return r.value
+
+    def strip_match_part(self, d_marks, d_cur, d_prev, d_basic, w, h, ch, sigma, params, oy, ngy, r0, rows, lay,
+                         smoother=False):
+        """strip_match_rows that lays out only the pixel rows lay = (lay0, lay1, v0, v1) (include/nlk_hip.h)."""
+        r = C.c_int()
+        self._chk(self.L.nlk_dev_strip_match_part(self.h, d_cur, d_prev, d_basic, w, h, ch, float(sigma),
+                                                  C.byref(params), oy, ngy, int(smoother), r0, rows,
+                                                  int(lay[0]), int(lay[1]), int(lay[2]), int(lay[3]), d_marks, C.byref(r)))
         return r.value
 
     def mask_commit(self, d_marks, ngx, ngy, reach, d_active):

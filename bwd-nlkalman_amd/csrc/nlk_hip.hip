@@ -700,15 +700,22 @@ int nlk_dev_frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const flo
 }
 
 // ---- the same three phases as separate entry points (exact masks across GPUs)
-// rows [r0, r0 + rows) of the strip's target rows (a whole strip: r0 = 0, rows = ngy). Every call lays
-// the strip out again (planar copies, validity map), so a caller may match the rows that do not depend
-// on a halo still in flight first and the others once it has arrived.
-int nlk_dev_strip_match_rows(nlk_ctx* c, const float* cur, const float* prev, const float* basic, int w,
+// rows [r0, r0 + rows) of the strip's target rows (a whole strip: r0 = 0, rows = ngy). _part lays out the pixel
+// rows [lay0, lay1) only (planar copies, row test of the validity map) and finishes the validity map of the rows
+// [v0, v1): a caller matches the rows that do not depend on a halo still in flight first - laying out its own rows -
+// and lays out the halo rows and matches the seam rows once they have arrived (nothing reads rows in flight, nothing
+// is laid out twice). _rows lays the whole strip out again on every call.
+int nlk_dev_strip_match_part(nlk_ctx* c, const float* cur, const float* prev, const float* basic, int w,
                              int h, int ch, float sigma, const struct nlkalman_params* P, int oy,
-                             int ngy, int smoother, int r0, int rows, void* marks_out, int* reach) {
+                             int ngy, int smoother, int r0, int rows, int lay0, int lay1, int v0, int v1,
+                             void* marks_out, int* reach) {
+  if (lay0 < 0 || lay1 > h || lay0 > lay1 || v0 < 0 || v1 > h || v0 > v1)
+    return fail(c, NLK_EINVAL, "layout rows [%d, %d) / validity rows [%d, %d) outside the %d-row strip", lay0, lay1, v0, v1, h);
   NlkPlan pl;
-  int rc = plan_frame(c, pl, cur, prev, basic, w, h, ch, sigma, P, oy, ngy, smoother, 1);
+  int rc = plan_frame(c, pl, cur, prev, basic, w, h, ch, sigma, P, oy, ngy, smoother, 1, nullptr, false);
   if (rc) return rc;
+  if ((rc = layout_rows(c, cur, prev, basic, nullptr, w, h, ch, pl.g.psz, lay0, lay1, v0, v1))) return rc;
+  mark(c, 1);
   if (r0 < 0 || rows < 0 || r0 + rows > pl.g.ngy) return fail(c, NLK_EINVAL, "rows [%d, %d) outside the strip's %d target rows", r0, r0 + rows, pl.g.ngy);
   if (rows > 0 && (rc = match_rows(c, pl, c->stream, r0, rows, 0))) return rc;
   mark(c, 2);
@@ -720,6 +727,13 @@ int nlk_dev_strip_match_rows(nlk_ctx* c, const float* cur, const float* prev, co
     HIPCHK(c, hipMemcpyAsync((uint64_t*)marks_out + (size_t)r0 * c->last.ngx, (const uint64_t*)c->marks.p + (size_t)r0 * c->last.ngx,
                              sizeof(uint64_t) * (size_t)c->last.ngx * rows, hipMemcpyDeviceToDevice, c->stream));
   return NLK_OK;
+}
+
+int nlk_dev_strip_match_rows(nlk_ctx* c, const float* cur, const float* prev, const float* basic, int w,
+                             int h, int ch, float sigma, const struct nlkalman_params* P, int oy,
+                             int ngy, int smoother, int r0, int rows, void* marks_out, int* reach) {
+  return nlk_dev_strip_match_part(c, cur, prev, basic, w, h, ch, sigma, P, oy, ngy, smoother, r0, rows, 0, h, 0, h,
+                                  marks_out, reach);
 }
 
 int nlk_dev_strip_match(nlk_ctx* c, const float* cur, const float* prev, const float* basic, int w,

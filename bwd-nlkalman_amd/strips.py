@@ -63,12 +63,17 @@ class StripFrame:
                  phases=None, stage_host=False):
         """phases = (match, commit, group[, match_rows]) callbacks selects the exact mode:
         match(marks[int64, ngy_l*ngx], cur, prev, oy, ngy_l) -> reach R;
-        match_rows(marks, cur, prev, oy, ngy_l, r0, rows) -> R: the same for the target rows [r0, r0+rows)
-        only (optional: overlaps the matching of the interior rows with the previous-frame halo exchange);
+        match_rows(marks, cur, prev, oy, ngy_l, r0, rows, lay) -> R: the same for the target rows [r0, r0+rows)
+        only, after laying out the pixel rows lay = (lay0, lay1, v0, v1) of the strip (include/nlk_hip.h:
+        nlk_dev_strip_match_part; backends without a layout step ignore it). Optional: overlaps the matching of
+        the interior rows with the previous-frame halo exchange - the own rows are laid out and the targets that
+        read nothing else are matched while the halo rows travel, the halo rows are laid out and the seam targets
+        matched after their arrival: nothing reads rows in flight, nothing is laid out twice;
         commit(marks_full[int64], ngx, ngy, R, active_full[uint8]);
         group(acc, active_slice[uint8], ...) (state of the last match)."""
         self.rank, self.world, self.w, self.h, self.ch = rank, world, w, h, ch
         self.step_px = psz // 2
+        self.psz = psz
         self.plan = strip_plan(h, psz, halo, world)
         p = self.plan[rank]
         self.p = p
@@ -218,14 +223,20 @@ class StripFrame:
             if match_rows is not None and i1 > i0 and (self.up is not None or self.dn is not None):
                 # the target rows that see only this rank's own rows of the previous frame are matched while
                 # the halo rows travel; the seam rows (and a fresh layout of the strip) follow their arrival
-                reach = match_rows(self.marks_pad[:n_l], self.cur, self.prev, oy, ngy_l, i0, i1 - i0)
+                o0, o1, hl, ps = l(p["own0"]), l(p["own1"]), self.hl, self.psz
+                # own rows (a validity-map row needs the row tests of the psz rows from it on: the last psz - 1
+                # own rows wait for the halo below, the first ones are complete unless a halo lies above)
+                reach = match_rows(self.marks_pad[:n_l], self.cur, self.prev, oy, ngy_l, i0, i1 - i0,
+                                   (o0, o1, o0, o1 if o1 == hl else o1 - ps + 1))
                 t0 = self._tick("match_interior", t0)
                 self._wait(posted)
                 t0 = self._tick("exchange_prev", t0)
-                if i0 > 0:
-                    match_rows(self.marks_pad[:n_l], self.cur, self.prev, oy, ngy_l, 0, i0)
-                if i1 < ngy_l:
-                    match_rows(self.marks_pad[:n_l], self.cur, self.prev, oy, ngy_l, i1, ngy_l - i1)
+                # halo rows above (+ the seam targets there), then below
+                if o0 > 0 or i0 > 0:
+                    match_rows(self.marks_pad[:n_l], self.cur, self.prev, oy, ngy_l, 0, i0, (0, o0, 0, o0))
+                if o1 < hl or i1 < ngy_l:
+                    match_rows(self.marks_pad[:n_l], self.cur, self.prev, oy, ngy_l, i1, ngy_l - i1,
+                               (o1, hl, max(o1 - ps + 1, o0) if o1 < hl else hl, hl))
                 t0 = self._tick("match_seams", t0)
             else:
                 self._wait(posted)

@@ -195,6 +195,15 @@ int nlk_dev_strip_match_rows(nlk_ctx *ctx, const float *cur, const float *prev,
                              const float *basic, int w, int h, int ch, float sigma,
                              const struct nlkalman_params *prms, int oy, int ngy,
                              int smoother, int r0, int rows, void *marks_out, int *reach);
+/* the same, laying out only the pixel rows [lay0, lay1) of the strip (planar copies, validity row test) and
+ * finishing the validity map of the rows [v0, v1) (row y needs the row tests of rows y .. y + patch - 1): first the
+ * own rows and the targets that read nothing else, then - once the previous frame's halo rows have arrived - those
+ * rows and the seam targets. Nothing is read while in flight, nothing is laid out twice. */
+int nlk_dev_strip_match_part(nlk_ctx *ctx, const float *cur, const float *prev,
+                             const float *basic, int w, int h, int ch, float sigma,
+                             const struct nlkalman_params *prms, int oy, int ngy,
+                             int smoother, int r0, int rows, int lay0, int lay1, int v0, int v1,
+                             void *marks_out, int *reach);
 int nlk_dev_mask_commit(nlk_ctx *ctx, const void *marks, int ngx, int ngy, int reach,
                         unsigned char *active);
 int nlk_dev_strip_group(nlk_ctx *ctx, float *acc, const unsigned char *active);

@@ -295,9 +295,9 @@ def _two_rank_worker(rank, world, port, q):
         return ctx.strip_match(marks.data_ptr(), cur.data_ptr(), prev.data_ptr(), None, w, cur.shape[0],
                                ch, sigma, p, oy, ngy)
 
-    def match_rows(marks, cur, prev, oy, ngy, r0, rows):
-        return ctx.strip_match_rows(marks.data_ptr(), cur.data_ptr(), prev.data_ptr(), None, w, cur.shape[0],
-                                    ch, sigma, p, oy, ngy, r0, rows)
+    def match_rows(marks, cur, prev, oy, ngy, r0, rows, lay):
+        return ctx.strip_match_part(marks.data_ptr(), cur.data_ptr(), prev.data_ptr(), None, w, cur.shape[0],
+                                    ch, sigma, p, oy, ngy, r0, rows, lay)
 
     def commit(marks_full, ngx, ngy, reach, active_full):
         ctx.mask_commit(marks_full.data_ptr(), ngx, ngy, reach, active_full.data_ptr())
@@ -310,8 +310,13 @@ def _two_rank_worker(rank, world, port, q):
         sf = strips.StripFrame(rank, world, w, h, ch, p.patch_sz, max(p.search_sz_x, p.search_sz_t), dev,
                                accumulate, normalize, phases=phases, stage_host=True)
         sf.load(t_n1, t_prev)
-        sf.step()
-        sf.step()
+        for _ in range(2):
+            # (the halo rows of the previous frame hold garbage until the exchange delivers them: a seam target
+            # matched too early, or a layout that reads them in flight, would show)
+            pp = sf.p
+            sf.prev[:sf._l(pp["own0"])] = float("nan")
+            sf.prev[sf._l(pp["own1"]):] = float("nan")
+            sf.step()
         y0, y1, rows = sf.own_rows()
         full = torch.zeros((h, w, ch))
         full[y0:y1] = rows.cpu()

@@ -65,7 +65,7 @@ def _phases(O, p, state):
         O.strip_group(acc.numpy(), active.numpy(), state["cur"], state["prev"], None, SIGMA, p,
                       state["oy"], state["ngy"])
 
-    def match_rows(marks, cur, prev, oy, ngy, r0, rows):
+    def match_rows(marks, cur, prev, oy, ngy, r0, rows, lay=None):
         # (the interior rows are matched while the halo is in flight: `prev` is read at call time, so a
         # seam row matched too early would see the stale halo and the result would differ from the serial run)
         step = p.patch_sz // 2
