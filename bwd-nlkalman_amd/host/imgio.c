@@ -252,8 +252,8 @@ static float *read_tiff(const char *path, const unsigned char *b, size_t n, int 
   if (!sane_size(W, H, spp)) return fail(path, "unreasonable TIFF size");
   if (!rps || rps > H) rps = H;
   if (bps != 8 && bps != 16 && bps != 32 && bps != 64) return fail(path, "unsupported bits per sample");
-  if (pred == 3) return fail(path, "floating-point predictor (3) not supported");
-  if (pred != 1 && pred != 2) return fail(path, "unknown TIFF predictor");
+  if (pred != 1 && pred != 2 && pred != 3) return fail(path, "unknown TIFF predictor");
+  if (pred == 3 && (fmt != 3 || (bps != 32 && bps != 64))) return fail(path, "floating-point predictor on non-float samples");
   if (tiled && (TW > (1u << 20) || TL > (1u << 20))) return fail(path, "unreasonable tile size");
   const int bytes = (int)bps / 8;
   const uint64_t planes = planar == 2 ? spp : 1, cpp = planar == 2 ? 1 : spp; /* comps per pixel in a chunk */
@@ -281,6 +281,23 @@ static float *read_tiff(const char *path, const unsigned char *b, size_t n, int 
         else { free(out); free(raw); return fail(path, "unsupported TIFF compression"); }
         if (got == (size_t)-1) { free(out); free(raw); return fail(path, "corrupt LZW stream"); }
         if (got < want) { free(out); free(raw); return fail(path, "short strip / tile"); }
+        if (pred == 3) {
+          /* floating-point predictor (Adobe TIFF technical note 3; libtiff fpAcc, which the reference reads such
+           * files through, lib/iio/iio.c:1463-1661): every row is stored as byte planes - the most significant
+           * bytes of all its samples first - differenced byte-wise with a stride of one pixel's samples */
+          const size_t ns = (size_t)cw * cpp, rb = ns * bytes;
+          unsigned char *tmp = malloc(rb ? rb : 1);
+          if (!tmp) { free(out); free(raw); return fail(path, "out of memory"); }
+          for (uint64_t r = 0; r < rows_in; ++r) {
+            unsigned char *row = raw + r * rb;
+            for (size_t i = cpp; i < rb; ++i) row[i] = (unsigned char)(row[i] + row[i - cpp]);
+            memcpy(tmp, row, rb);
+            for (size_t j = 0; j < ns; ++j)
+              for (int k = 0; k < bytes; ++k) /* k = significance, 0 = least */
+                row[j * bytes + (t.le ? k : bytes - 1 - k)] = tmp[(size_t)(bytes - 1 - k) * ns + j];
+          }
+          free(tmp);
+        }
         if (pred == 2 && bytes <= 4 && fmt != 3) /* horizontal differencing */
           for (uint64_t r = 0; r < rows_in; ++r)
             for (uint64_t x = cpp; x < cw * cpp; ++x) {

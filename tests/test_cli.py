@@ -228,7 +228,7 @@ def test_two_frame_pipeline_files(tools, O, tmp_path, name):
 
 def test_hostile_image_files_are_rejected(tools, tmp_path):
     """LZW codes beyond the next free entry, stale-table cycles, short
-    uncompressed strips, the floating-point predictor and absurd header sizes must end in an
+    uncompressed strips, the floating-point predictor on integer samples and absurd header sizes must end in an
     error message, never in a crash or a hang."""
     import struct
     from PIL import Image
@@ -267,11 +267,21 @@ def test_hostile_image_files_are_rejected(tools, tmp_path):
     open(tmp_path / "bad3.tif", "wb").write(ur)
     r = run("nlk-imgconv", tmp_path / "bad3.tif", tmp_path / "o.pfm")
     assert r.returncode != 0 and "short strip" in r.stderr
-    # (4) floating-point predictor
+    # (4) floating-point predictor (3): decoded since round 3 (what libtiff writes when the tag is set must read back
+    # exactly); on integer samples it is refused
     Image.fromarray(g).save(tmp_path / "f.tif", compression="tiff_lzw", tiffinfo={317: 3})
     r = run("nlk-imgconv", tmp_path / "f.tif", tmp_path / "o.pfm")
     fr = open(tmp_path / "f.tif", "rb").read()
     if 317 in entries(fr) and struct.unpack("<H", fr[entries(fr)[317] + 8:entries(fr)[317] + 10])[0] == 3:
+        assert r.returncode == 0, r.stderr
+        pf = open(tmp_path / "o.pfm", "rb").read()
+        back = np.frombuffer(pf[len(pf) - g.size * 4:], "<f4").reshape(g.shape)   # (rows top to bottom, like the reference's writer)
+        assert np.array_equal(back, g)
+        fe = entries(fr)
+        bad = bytearray(fr)
+        bad[fe[339] + 8:fe[339] + 10] = struct.pack("<H", 1)          # SampleFormat = unsigned integer
+        open(tmp_path / "bad4.tif", "wb").write(bad)
+        r = run("nlk-imgconv", tmp_path / "bad4.tif", tmp_path / "o.pfm")
         assert r.returncode != 0 and "predictor" in r.stderr
     # (5) absurd sizes in the header
     ur = bytearray(open(tmp_path / "u.tif", "rb").read())

@@ -280,9 +280,21 @@ def test_gpu_filter_tool_reads_and_writes_reference_files(iio, built, tmp_path):
 
 # ------------------------------------------------------------ round 2: tiles, LZW writer, hostile files
 
-def _tiled_tiff(path, a, tw, tl, comp="raw", planar=False, big=False):
+def _fp_predict(t):
+    """Adobe TIFF technical note 3 (predictor 3) on a block [rows, cols, comps] of float32: every row as byte planes,
+    most significant bytes first, then differenced byte-wise with a stride of `comps`."""
+    rows, cols, comps = t.shape
+    be = t.astype(">f4").view(np.uint8).reshape(rows, cols * comps, 4)
+    planes = np.ascontiguousarray(be.transpose(0, 2, 1)).reshape(rows, 4 * cols * comps)
+    out = planes.copy()
+    out[:, comps:] = planes[:, comps:] - planes[:, :-comps]
+    return out.tobytes()
+
+
+def _tiled_tiff(path, a, tw, tl, comp="raw", planar=False, big=False, fp_predictor=False):
     """A tiled TIFF assembled by hand from the TIFF 6.0 specification (section 15): tiles of
-    tw x tl pixels, edge tiles padded, float32 samples; `comp` raw or deflate."""
+    tw x tl pixels, edge tiles padded, float32 samples; `comp` raw or deflate; optionally with the
+    floating-point predictor (3)."""
     import struct
     import zlib
     h, w, ch = a.shape
@@ -295,11 +307,12 @@ def _tiled_tiff(path, a, tw, tl, comp="raw", planar=False, big=False):
                 blk = a[ty * tl:(ty + 1) * tl, tx * tw:(tx + 1) * tw]
                 blk = blk[..., pl:pl + 1] if planar else blk
                 t[:blk.shape[0], :blk.shape[1]] = blk
-                raw = t.tobytes()
+                raw = _fp_predict(t) if fp_predictor else t.tobytes()
                 tiles.append(zlib.compress(raw) if comp == "deflate" else raw)
     ents = [(256, 4, [w]), (257, 4, [h]), (258, 3, [32] * ch), (259, 3, [8 if comp == "deflate" else 1]),
-            (262, 3, [2 if ch >= 3 else 1]), (277, 3, [ch]), (284, 3, [2 if planar else 1]),
-            (322, 4, [tw]), (323, 4, [tl]), (324, 16 if big else 4, None), (325, 16 if big else 4, [len(t) for t in tiles]),
+            (262, 3, [2 if ch >= 3 else 1]), (277, 3, [ch]), (284, 3, [2 if planar else 1])] + \
+           ([(317, 3, [3])] if fp_predictor else []) + \
+           [(322, 4, [tw]), (323, 4, [tl]), (324, 16 if big else 4, None), (325, 16 if big else 4, [len(t) for t in tiles]),
             (339, 3, [3] * ch)]
     tsz = {3: 2, 4: 4, 16: 8}
     fsz, esz, hdr = (8, 20, 16) if big else (4, 12, 8)
@@ -340,6 +353,19 @@ def test_tiled_tiff_is_read_like_the_reference_library_reads_it(iio, conv, tmp_p
     assert np.array_equal(ref, a)                      # the hand-made file is a valid tiled TIFF
     conv(tmp_path / "t.tif", tmp_path / "t.pfm")
     assert np.array_equal(iio.read(tmp_path / "t.pfm"), a)
+
+
+@pytest.mark.parametrize("planar", [False, True])
+def test_floating_point_predictor_tiff(iio, conv, tmp_path, planar):
+    """TIFF predictor 3 (byte planes + byte-wise differencing; what e.g. GDAL and ImageMagick write for
+    float images with Deflate): libtiff undoes it for the reference's reader (lib/iio/iio.c:1463-1661),
+    host/imgio.c does it itself. The hand-made file must read back exactly through both."""
+    a = np.random.default_rng(9).normal(100, 50, (37, 52, 3)).astype(np.float32)
+    a[3, 5] = np.nan
+    _tiled_tiff(tmp_path / "p3.tif", a, 32, 16, "deflate", planar, False, fp_predictor=True)
+    assert np.array_equal(iio.read(tmp_path / "p3.tif"), a, equal_nan=True)   # libtiff agrees the file is valid
+    conv(tmp_path / "p3.tif", tmp_path / "p3.pfm")
+    assert np.array_equal(iio.read(tmp_path / "p3.pfm"), a, equal_nan=True)
 
 
 @pytest.mark.parametrize("name", ["float_big_rgb", "bytes_rgb", "nan_holes", "float_gray"])
