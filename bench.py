@@ -551,6 +551,10 @@ def main():
                "roofline": roof}
         if phase_ms is not None:
             res["strip_phase_ms"] = phase_ms
+        if one_gpu and world > 1:
+            res["not_a_measurement"] = (f"NLK_BENCH_ONE_GPU=1: all {world} ranks share device 0 and exchange through host "
+                                        "memory over gloo - a record of the N > 1 code path running end to end, "
+                                        "its times mean nothing")
         if args.workload == "C5":
             res["config"]["workload"] = (f"C5: {w}x{h}x{ch} sigma={sigma:g}: flt1 temporal -> flt2 -> smo1 "
                                          f"(3 frame calls per step), frames resident")
