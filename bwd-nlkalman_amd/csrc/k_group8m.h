@@ -98,6 +98,19 @@ __device__ __forceinline__ void nlk_mfma_fwd(const float (&F)[4][4], const float
                   : __builtin_amdgcn_mfma_f32_16x16x4f32(F[q][s], dA[q][s], C[q], 0, 0, 0);
 }
 
+// sum over the 64 lanes, in every lane, without LDS: two butterfly steps inside the quads and two mirror steps
+// inside the rows of 16 lanes (DPP), then the two row-swap instructions (tools/ubench/permlane_swap.hip)
+__device__ __forceinline__ float nlk_wave_sum_dpp(float v) {
+  v += nlk_dpp<NLK_DPP_XOR1>(v);
+  v += nlk_dpp<NLK_DPP_XOR2>(v);
+  v += nlk_dpp<NLK_DPP_HMIRROR>(v);
+  v += nlk_dpp<0x140 /* row_mirror */>(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 template <int CH, bool SMO>
 __global__ void __launch_bounds__(64, 3)
 k_group8m(const float* __restrict__ img,   // matching / statistics image (planar)
@@ -234,9 +247,10 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     }
     const int np1 = k;
     const int ngrp = min(np0, g.ntagg);
-    const float in1 = np1 ? 1.f / (float)np1 : 0.f;
-    const float in0 = np0 ? 1.f / (float)np0 : 0.f;
-    const float ing = ngrp ? 1.f / (float)ngrp : 0.f;
+    // (1 / n for n <= 128 by v_rcp_f32: within 1 ulp, like the gains' reciprocals)
+    const float in1 = np1 ? __builtin_amdgcn_rcpf((float)np1) : 0.f;
+    const float in0 = np0 ? __builtin_amdgcn_rcpf((float)np0) : 0.f;
+    const float ing = ngrp ? __builtin_amdgcn_rcpf((float)ngrp) : 0.f;
     const bool passthrough = SMO && np0 == 0;  // reference: :1795-1804
 
     // ---------------- pass A: statistics over the k kept candidates, one channel at a
@@ -443,7 +457,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     }
     int offn = member_off(4);
     // the reference adds the same per-coefficient terms once per group member
-    float vp = nlk_wave_sum8(part_sum) * (float)nagg;
+    float vp = nlk_wave_sum_dpp(part_sum) * (float)nagg;
     if (passthrough) vp = 0.f;
     const float wgt = 1.f / (vp > 1e-6f ? vp : 1e-6f);
     float ww[4];
