@@ -112,3 +112,30 @@ def test_host_pointer_calls_pipeline_the_frame_in_row_bands(ctx, built, synth, m
         if bands is None:
             cases.assert_close(built.filter_frame(o1, hole, d1, sigma, p2), d2, f"{tag}: flt2", flips=40)
             cases.assert_close(built.smooth_frame(d0, d2, None, sigma, ps), ds, f"{tag}: smo1", flips=40)
+
+
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_host_pointer_pipeline_on_odd_sizes(ctx, built, synth, seed):
+    """Row bands of the host-pointer calls on frames whose sizes are nothing round: one or three channels,
+    8 x 8 and 12 x 12 patches (mask reach 1 and 0), a previous frame with NaN holes on band seams, a basic
+    estimate. Equal to the device call up to the order of the accumulator's atomic adds."""
+    rng = np.random.default_rng(seed)
+    w, h = int(rng.integers(500, 900)), int(rng.integers(420, 700))
+    ch = int(rng.choice([1, 3]))
+    psz = int(rng.choice([8, 12]))
+    sigma = float(rng.choice([20.0, 40.0]))
+    n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, seed)
+    o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+    p1 = built.default_params(sigma, built.FLT1, patch_sz=psz)
+    p2 = built.default_params(sigma, built.FLT2, patch_sz=psz)
+    d0, _ = _dev_frame(ctx, False, o0, None, None, sigma, p1)
+    hole = d0.copy()
+    for _ in range(12):   # (holes anywhere: some straddle the seams between two bands)
+        y, x = int(rng.integers(0, h - 20)), int(rng.integers(0, w - 30))
+        hole[y:y + int(rng.integers(1, 20)), x:x + int(rng.integers(1, 30))] = np.nan
+    d1, _ = _dev_frame(ctx, False, o1, hole, None, sigma, p1)
+    d2, _ = _dev_frame(ctx, False, o1, hole, d1, sigma, p2)
+    what = f"host pipeline {w}x{h}x{ch} psz {psz}"
+    cases.assert_close(built.filter_frame(o0, None, None, sigma, p1), d0, what + ": flt1 spatial", flips=40)
+    cases.assert_close(built.filter_frame(o1, hole, None, sigma, p1), d1, what + ": flt1 temporal", flips=40)
+    cases.assert_close(built.filter_frame(o1, hole, d1, sigma, p2), d2, what + ": flt2", flips=40)
