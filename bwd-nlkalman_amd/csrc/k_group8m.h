@@ -468,33 +468,35 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     const float* st_m = stash + bst * NLK_G8_SST + 64 + 4 * g4;
     for (int n0 = 0; n0 < nagg; n0 += 4) {
       nlk_f4 Y[4], Z[4];
+      if (SMO) {
+        // The smoother's update (1 - a) A + a B of a member's coefficients (A image, B previous frame,
+        // reference: :1775) is A + a (B - A), and every step from here to the frame is linear: the member's
+        // pixels are its image patch + IDCT(a . DCT(previous patch - image patch)), and the image patches,
+        // added with the members' weights, sum to image x weight plane. So only the SECOND term goes through
+        // the transforms - one forward transform of the pixel difference instead of two - and k_normalize adds
+        // the image back (nlk_ctx::acc_residual).
+#pragma unroll
+        for (int c = 0; c < 16; ++c) R[c] = Rp[c] - R[c];
+      }
       nlk_fold(R, F);
       nlk_rows_load(src + offn, g.w, g4, R);
 #pragma unroll
       for (int q = 0; q < 4; ++q) Y[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
       if (SMO) {
-        // (one folded operand set at a time: image member first, then its previous-frame patch)
-        nlk_f4 Yp[4];
-        __builtin_amdgcn_sched_barrier(0);
-        nlk_mfma_fwd<true>(F, dA, Y);
-        nlk_fold(Rp, F);
         nlk_rows_load(psrc + offn, g.w, g4, Rp);
         offn = member_off(n0 + 8);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Yp[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
-        nlk_mfma_fwd<true>(F, dA, Yp);
+        nlk_mfma_fwd<true>(F, dA, Y);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const nlk_f4 gq = *reinterpret_cast<const nlk_f4*>(st_g + 16 * q);
           const nlk_f4 mq = *reinterpret_cast<const nlk_f4*>(st_m + 16 * q);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            // (weight / unused slots: gain 1 in the stash's first half would need Yp = the constant;
-            // they carry gain 0 and their value in the mean half instead)
-            const float a = (passthrough && bch < CH) ? 0.f : gq[j];
-            Y[q][j] = bch < CH ? (1 - a) * Y[q][j] + a * Yp[q][j]  // reference: :1775
-                               : mq[j];
+            // (weight / unused slots carry gain 0 and their value - the constant's DCT - in the mean half; a
+            // pass-through target reads its own patch as "previous" - the difference is zero - and its gains
+            // come from the Wiener formula with beta_x = 0, i.e. may be 0 / 0: not used)
+            Y[q][j] = bch < CH ? (passthrough ? 0.f : gq[j] * Y[q][j]) : mq[j];
           }
         }
       } else {

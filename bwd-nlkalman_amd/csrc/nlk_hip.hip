@@ -64,6 +64,7 @@ int launch_group(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cu
   // row)), NLK_GENERIC_GROUP=1 (LDS-DCT kernel, which also takes the lists of more than 128 entries)
   const bool ch13 = g.ch == 1 || g.ch == 3;
   const bool lists_fit = g.kmax <= 128 && g.gstride <= 128;
+  c->acc_residual = false;  // (set by the launcher whose kernel accumulates residuals: nlk_launch_group8)
   if (getenv("NLK_GENERIC_GROUP") || !lists_fit) return nlk_launch_group_generic(c, g, img, cur, prev, acc, active);
   if (g.psz == 8 && ch13 && !getenv("NLK_GROUP_PACKED"))
     return nlk_launch_group8(c, g, img, cur, prev, acc, active);
@@ -769,7 +770,7 @@ int nlk_dev_frame_normalize(nlk_ctx* c, float* out, const float* acc, const floa
   NLK_USE_DEVICE(c);
   mark(c, 5);
   hipLaunchKernelGGL(k_normalize, dim3(2048), dim3(256), 0, c->stream, out, acc, cur, w, h, ch,
-                     y0, y1);
+                     y0, y1, c->acc_residual ? 1 : 0);
   HIPCHK(c, hipGetLastError());
   mark(c, 6);
   return NLK_OK;
@@ -901,7 +902,7 @@ static int frame_host(nlk_ctx* c, float* out_h, const float* cur_h, const float*
     if (nz[b + 1] > nz0) {
       if (b > 0) HIPCHK(c, hipStreamWaitEvent(s, c->band_ev[E_GRP][b - 1], 0));
       hipLaunchKernelGGL(k_normalize, dim3(1024), dim3(256), 0, s, d_out, (const float*)acc, (const float*)d_cur, w, h,
-                         ch, nz0, nz[b + 1]);
+                         ch, nz0, nz[b + 1], c->acc_residual ? 1 : 0);
       HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(c->band_ev[E_DONE][b], s));

@@ -51,6 +51,7 @@ struct nlk_ctx {
   hipStream_t up_stream = nullptr, dn_stream = nullptr;
   hipEvent_t band_ev[5][8] = {};  // per band: uploaded / laid out / mask rows replayed / groups filtered / rows normalised
   bool deterministic = false;     // nlk_ctx_set_deterministic / NLK_DETERMINISTIC=1
+  bool acc_residual = false;      // what the last group launch left in the accumulator's value planes (k_normalize)
   NlkTvMail* tv_host = nullptr;   // pinned: the solver state, posted by the kernels (k_tvl1.h)
   unsigned tv_seq = 0;
   int tabs_psz = 0;

@@ -86,6 +86,7 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
                  const uint32_t*, const NlkTarget*, const uint32_t*, const uint8_t*, const float*,
                  const float*, float*);
     kern = mfma ? k_group8m<CH, SMO> : k_group8<CH, SMO>;
+    if (mfma && SMO) c->acc_residual = true;  // (k_group8m's smoother accumulates member - image, k_normalize adds the image)
     HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
     const float* basis = (const float*)c->tabs.p;
