@@ -71,8 +71,13 @@ __global__ void k_normalize(float* __restrict__ out, const float* __restrict__ a
        i < (size_t)y1 * w; i += (size_t)gridDim.x * blockDim.x) {
     const float a = acc[(size_t)ch * npix + i];
     for (int c = 0; c < ch; ++c) {
-      const float in = cur_hwc[i * ch + c];
-      const float v = (a > 1e-6f) ? (residual ? in + acc[(size_t)c * npix + i] / a : acc[(size_t)c * npix + i] / a) : in;
+      float v;
+      if (a > 1e-6f) {  // (the input frame is read only where it is needed)
+        v = acc[(size_t)c * npix + i] / a;
+        if (residual) v += cur_hwc[i * ch + c];
+      } else {
+        v = cur_hwc[i * ch + c];
+      }
       out[i * ch + c] = v;
     }
   }
