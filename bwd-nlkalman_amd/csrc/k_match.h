@@ -41,6 +41,7 @@ struct NlkTile {
   int ksel_max;       // capacity of the per-wave survivor arrays
   int halo;           // search halo held in LDS (windows reaching further read HBM/L2)
   int block;          // 4 x 2-target blocks share their squared differences (0: NLK_MATCH_NOBLOCK, target by target)
+  int threads;        // k_bm_topk: threads per workgroup (256, or 512 for tiles of 8 x 8 targets)
 };
 
 __device__ inline uint64_t nlk_wave_or(uint64_t v) {
@@ -317,7 +318,7 @@ __device__ __forceinline__ void nlk_match_epilogue(const NlkGeom& g, size_t t, i
 }
 
 template <int PSZ, int CH, int MAXM>
-__global__ void __launch_bounds__(NLK_BM_THREADS, MAXM == 7 ? 3 : 1)  // (7 rounds in blocks: 168 registers, the LDS tile allows 3 wavefronts per SIMD)
+__global__ void __launch_bounds__(512, MAXM == 7 ? 3 : 2)  // (7 rounds in blocks: 168 registers, the LDS tile allows 3 wavefronts per SIMD)
 k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGeom g,
           NlkTile tl, uint32_t* __restrict__ topk, NlkTarget* __restrict__ tinfo,
           uint32_t* __restrict__ gcoords, uint64_t* __restrict__ marks,
@@ -325,6 +326,7 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: makes per-target addresses uniform
+  const int nwaves = (int)(blockDim.x >> 6);  // 4, or 8 for tiles of 8 x 8 targets (NlkTile::threads)
   const int tile_id = nlk_xcd_tile(blockIdx.x, tl.ntx * tl.nty);
   if (tile_id >= tl.ntx * tl.nty) return;
   const int tile_x = tile_id % tl.ntx, tile_y = tile_id / tl.ntx;
@@ -348,19 +350,19 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
   float* tile = smem;                                  // [CH][rh_max][rwp]
   // (the tile size is kept even so that the 64-bit survivor array is 8-byte aligned)
   uint64_t* surv_all = (uint64_t*)(tile + ((CH * plane + 1) & ~1));  // [waves][ksel_max]
-  uint32_t* sel_all = (uint32_t*)(surv_all + NLK_BM_WAVES * tl.ksel_max);
-  uint32_t* grp_all = sel_all + NLK_BM_WAVES * tl.ksel_max;  // [waves][gstride]
+  uint32_t* sel_all = (uint32_t*)(surv_all + nwaves * tl.ksel_max);
+  uint32_t* grp_all = sel_all + nwaves * tl.ksel_max;  // [waves][gstride]
 
   const size_t npix = (size_t)g.w * g.h;
   // stage the region: 8 rows per wavefront in flight (loads first, then the LDS
   // stores), so the HBM/L2 latency is paid once per batch, not once per row
   {
     const int nrows = CH * rh;  // rows of all channel planes; region width <= 128
-    for (int r0 = wave; r0 < nrows; r0 += NLK_BM_WAVES * 8) {
+    for (int r0 = wave; r0 < nrows; r0 += nwaves * 8) {
       float v0[8], v1[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int r = min(r0 + NLK_BM_WAVES * j, nrows - 1);
+        const int r = min(r0 + nwaves * j, nrows - 1);
         const int c = r / rh, y = r - c * rh;
         const float* src = img + c * npix + (size_t)(ry0 + y) * g.w + rx0;
         v0[j] = lane < rw ? src[lane] : 0.f;
@@ -368,7 +370,7 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int r = r0 + NLK_BM_WAVES * j;
+        const int r = r0 + nwaves * j;
         if (r < nrows) {
           const int c = r / rh, y = r - c * rh;
           float* dst = tile + c * plane + y * rwp;
@@ -448,12 +450,12 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
   // block - image border, a target without a valid previous patch in a temporal frame, windows of more
   // than 448 candidates - goes target by target.
   if (!tl.block) {  // (comparison variant, and small grids: the targets dealt out to the wavefronts one by one)
-    for (int tt = wave; tt < cx * cy; tt += NLK_BM_WAVES) do_target(tt);
+    for (int tt = wave; tt < cx * cy; tt += nwaves) do_target(tt);
     return;
   }
   constexpr int BX = 4, BY = 2;
   const int nbx = (tl.tgx + BX - 1) / BX, nby = (tl.tgy + BY - 1) / BY;
-  for (int blk = wave; blk < nbx * nby; blk += NLK_BM_WAVES) {
+  for (int blk = wave; blk < nbx * nby; blk += nwaves) {
     const int bty = blk / nbx, tx0 = (blk - bty * nbx) * BX, ty0 = bty * BY;
     if (tx0 >= cx || ty0 >= cy) continue;
     bool regular = tx0 + BX <= cx && ty0 + BY <= cy && g.npt > 1 && g.npx > 1;

@@ -478,6 +478,17 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   const bool small_grid = (size_t)((g.ngx + 7) / 8) * ((g.ngy + 3) / 4) < 1024;
   tl.tgx = getenv("NLK_MTX") ? atoi(getenv("NLK_MTX")) : (small_grid ? 4 : 8);
   tl.tgy = getenv("NLK_MTY") ? atoi(getenv("NLK_MTY")) : (small_grid ? 2 : 4);
+  // workgroups of 8 wavefronts on tiles of 8 x 8 targets where the patches are small enough for the tile to leave
+  // three workgroups per CU (8 x 8 patches with the temporal radius: 45 KB; NLK_MATCH_WG8=0/1 overrides)
+  tl.threads = NLK_BM_THREADS;
+  {
+    const char* e = getenv("NLK_MATCH_WG8");
+    const int halo0 = (g.smoother || g.have_prev) ? g.wsz_t : g.wsz_x;
+    // (1080p, match ms with 4 / 8 wavefronts: FLT1 temporal 0.305 / 0.294, FLT2 0.283 / 0.276, SMO1 0.399 / 0.380;
+    // with the spatial radius 10 the 8 x 8 tile is 62 KB: 0.95 / 1.22)
+    const bool wg8 = e ? atoi(e) != 0 : (g.psz <= 8 && halo0 <= 6);
+    if (wg8 && !small_grid && !getenv("NLK_MTY")) { tl.threads = 512; tl.tgy = 8; }
+  }
   tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
   tl.block = getenv("NLK_MATCH_NOBLOCK") ? 0 : (getenv("NLK_MATCH_BLOCK") ? 1 : !small_grid);
   // LDS holds the halo of the dominant window; its row stride = window width
@@ -492,7 +503,7 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   tl.rh_max = (tl.tgy - 1) * g.step + 2 * tl.halo + g.psz;
   tl.ksel_max = g.kmax;
   pl.lds = sizeof(float) * ((size_t)ch * tl.rwp * tl.rh_max + 1 +
-                            (size_t)NLK_BM_WAVES * (3 * tl.ksel_max + ntagg_alloc));
+                            (size_t)(tl.threads / 64) * (3 * tl.ksel_max + ntagg_alloc));
   if (pl.lds > 160 * 1024) pl.generic = true;  // (a k or window too large for the tile: the generic kernel)
   // targets of a temporal frame without a valid previous patch search the spatial window
   // (reference: :637); when that one is the wider, they are queued for a second launch

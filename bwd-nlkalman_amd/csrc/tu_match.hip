@@ -13,7 +13,7 @@ int launch_match_t(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // k_bm_wide: the queue length is only known on the device, so a fixed grid strides over it
   const int grid = wide ? 512 : nlk_xcd_grid(tl.ntx * tl.nty);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NLK_BM_THREADS), lds, c->rv.stream, img,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(wide ? NLK_BM_THREADS : tl.threads), lds, c->rv.stream, img,
                      (const uint8_t*)c->vmap.p, g, tl, c->rv.topk,
                      c->rv.tinfo, c->rv.gcoords, c->rv.marks,
                      c->rv.wide + 1, c->rv.wide);
