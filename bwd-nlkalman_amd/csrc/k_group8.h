@@ -42,6 +42,9 @@ constexpr float NLK_C8[8][8] = {
 
 struct NlkGTile {
   int tgx, tgy, ntx, nty;
+  // k_group8m: tile rows of tgy grid rows; the tile rows after them hold ONE grid row each, and the last `single`
+  // grid rows are worked through one target per workgroup, in the workgroups after `nmain` (end of the launch)
+  int nty_full, single, nmain;
   int rwp, rh_max;  // LDS accumulator region: row stride / rows
   int wmax;         // halo of the LDS tile around its targets (groups reaching further spill to HBM atomics)
   int plane;        // k_group8m / k_groupp: floats per accumulator plane (padded, see there)

@@ -130,18 +130,31 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   // leaves whole XCDs idle at the end of a launch - the bands differ in skipped targets (2 % of the kernel) -
   // and plain launch order spreads every neighbourhood over all eight L2s (8x the fetched bytes). So: chunks
   // of NLK_G8_CW x NLK_G8_CH tiles, dealt round-robin to the XCDs, each worked through by one XCD.
-  int tile_x, tile_y;
-  {
+  int tile_x, tile_y, gx0, gy0, cx, cy;
+  if ((int)blockIdx.x < tl.nmain) {
     const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
     const int nchx = (tl.ntx + NLK_G8_CW - 1) / NLK_G8_CW;
     const int chunk = (i / (NLK_G8_CW * NLK_G8_CH)) * 8 + xcd, within = i % (NLK_G8_CW * NLK_G8_CH);
     tile_x = (chunk % nchx) * NLK_G8_CW + within % NLK_G8_CW;
     tile_y = (chunk / nchx) * NLK_G8_CH + within / NLK_G8_CW;
     if (tile_x >= tl.ntx || tile_y >= tl.nty) return;
+    // The launch ends when its last tile does, and a tile of 3 x 2 targets takes 1/7 of a 1080p launch: the last
+    // tile rows hold one grid row instead of tgy, and the very last grid rows go one target per workgroup
+    // (tu_group8.hip; deterministic mode keeps the uniform tiles its gather kernel assumes).
+    const bool full = tile_y < tl.nty_full;
+    gx0 = tile_x * tl.tgx;
+    gy0 = full ? tile_y * tl.tgy : tl.nty_full * tl.tgy + (tile_y - tl.nty_full);
+    cx = min(tl.tgx, g.ngx - gx0);
+    cy = min(full ? tl.tgy : 1, g.ngy - tl.single - gy0);
+  } else {
+    // single targets: every XCD takes a contiguous run of them
+    const int j = blockIdx.x - tl.nmain, n = tl.single * g.ngx, per = (n + 7) >> 3;
+    const int idx = (j & 7) * per + (j >> 3);
+    if ((j >> 3) >= per || idx >= n) return;
+    tile_y = idx / g.ngx; tile_x = idx - tile_y * g.ngx;
+    gx0 = tile_x; gy0 = g.ngy - tl.single + tile_y; cx = 1; cy = 1;
   }
   const int tile_id = tile_y * tl.ntx + tile_x;
-  const int gx0 = tile_x * tl.tgx, gy0 = tile_y * tl.tgy;
-  const int cx = min(tl.tgx, g.ngx - gx0), cy = min(tl.tgy, g.ngy - gy0);
   const int rx0 = max(gx0 * step - tl.wmax, 0);
   const int rx1 = min((gx0 + cx - 1) * step + tl.wmax + PSZ, g.w);
   const int ry0 = max(g.oy + gy0 * step - tl.wmax, 0);

@@ -43,6 +43,23 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
     tl.tgy = getenv("NLK_GTY") ? atoi(getenv("NLK_GTY")) : ((mfma && tgx_fill == 3 && tl.wmax <= 6) ? 2 : 1);
     tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
     tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
+    tl.nty_full = tl.nty;
+    tl.single = 0;
+    if (mfma && tl.tgy > 1 && !c->deterministic) {
+      // The launch ends when its last tile does, and a 3 x 2 tile takes 1/7 of a 1080p launch (21600 tiles on 3072
+      // wavefront slots): the chip would drain for most of a tile's time. So the last ~0.8 slots' worth of tiles
+      // hold one grid row (3 x 1), and the last ~0.9 slots' worth of targets go one per workgroup
+      // (1080p: 16 + 6 of 269 grid rows; group 0.950 -> 0.900 ms. NLK_G8_TAIL / NLK_G8_SINGLE override)
+      int tail = getenv("NLK_G8_TAIL") ? atoi(getenv("NLK_G8_TAIL")) : (2560 + tl.ntx / 2) / tl.ntx;
+      int single = getenv("NLK_G8_SINGLE") ? atoi(getenv("NLK_G8_SINGLE")) : (2880 + g.ngx / 2) / g.ngx;
+      single = max(0, min(single, g.ngy / 8));
+      tail = max(0, min(tail, g.ngy / 4));
+      tl.single = single;
+      const int rows = g.ngy - tl.single;
+      tl.nty_full = (rows - tail) / tl.tgy;
+      tl.nty = tl.nty_full + (rows - tl.nty_full * tl.tgy);
+    }
+    tl.nmain = mfma ? nlk_g8m_grid(tl.ntx, tl.nty) : 0;
     const int rw_max = (tl.tgx - 1) * g.step + 2 * tl.wmax + g.psz;
     tl.rh_max = (tl.tgy - 1) * g.step + 2 * tl.wmax + g.psz;
     if (mfma) {
@@ -90,7 +107,7 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
     HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
     const float* basis = (const float*)c->tabs.p;
-    hipLaunchKernelGGL(kern, dim3(mfma ? nlk_g8m_grid(tl.ntx, tl.nty) : nlk_xcd_grid(tl.ntx * tl.nty)), dim3(64), lds, c->rv.stream, img, cur, prev,
+    hipLaunchKernelGGL(kern, dim3(mfma ? tl.nmain + ((tl.single * g.ngx + 7) / 8) * 8 : nlk_xcd_grid(tl.ntx * tl.nty)), dim3(64), lds, c->rv.stream, img, cur, prev,
                        (const uint8_t*)c->vmap.p, g, tl, (const uint32_t*)c->rv.topk,
                        (const NlkTarget*)c->rv.tinfo, (const uint32_t*)c->rv.gcoords,
                        active, basis, basis + PSZ * PSZ, acc);

@@ -85,6 +85,32 @@ def test_deterministic_mode_against_serial_oracle_1080p(built, O, synth):
     cases.assert_close(g, r, "deterministic 1080p", flips=0)
 
 
+@pytest.mark.parametrize("tail,single", [("0", "0"), ("7", "3"), ("1", "33"), ("60", "0")])
+def test_group_tiles_of_mixed_sizes_1080p(ctx, built, O, synth, monkeypatch, tail, single):
+    """`k_group8m` ends a 1080p launch on smaller tiles (3 x 1 targets, then single targets: tu_group8.hip).
+    Whatever the split of the grid rows between the three kinds - none, odd counts, clamped counts - every target
+    is filtered exactly once: FLT1 temporal and SMO1 equal the default split up to the order of the accumulator's
+    adds, and the default equals the serial oracle."""
+    w, h, ch, sigma = 1920, 1080, 3, 20.0
+    n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, 1)
+    o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+    p1, ps = built.default_params(sigma, built.FLT1), built.default_params(sigma, built.SMO1)
+    d0, _ = _dev_frame(ctx, False, o0, None, None, sigma, p1)
+    d1, rec = _dev_frame(ctx, False, o1, d0, None, sigma, p1)
+    ds, _ = _dev_frame(ctx, True, d0, d1, None, sigma, ps)
+    if tail == "0":   # (once: the default split against the oracle)
+        r, tr = O.filter_frame(o1, d0, None, sigma, _to_o(O, p1), trace=True)
+        _check_records(rec, tr, "flt1 temporal 1080p")
+        g, _ = _excuse_threshold_pixels(d1, r, tr, "flt1 temporal 1080p", 64)
+        cases.assert_close(g, r, "flt1 temporal 1080p")
+    monkeypatch.setenv("NLK_G8_TAIL", tail)
+    monkeypatch.setenv("NLK_G8_SINGLE", single)
+    e1, _ = _dev_frame(ctx, False, o1, d0, None, sigma, p1)
+    es, _ = _dev_frame(ctx, True, d0, d1, None, sigma, ps)
+    cases.assert_close(e1, d1, f"tail {tail} single {single}: flt1 temporal", flips=40)
+    cases.assert_close(es, ds, f"tail {tail} single {single}: smo1", flips=40)
+
+
 def test_host_pointer_calls_pipeline_the_frame_in_row_bands(ctx, built, synth, monkeypatch):
     """The drop-in API (host pointers, libnlkalman.so -> nlk_filter_frame_host) moves a frame over PCIe in
     row bands while the bands before are matched and filtered, and returns finished rows while the last
