@@ -798,7 +798,12 @@ static int run_frame(nlk_ctx* c, float* out, const float* cur, const float* prev
   const size_t accb = sizeof(float) * (size_t)w * h * (ch + 1);
   if ((rc = reserve(c, c->acc, accb))) return rc;
   const int step = P->patch_sz / 2;
-  if (h < P->patch_sz || w < P->patch_sz) return fail(c, NLK_EINVAL, "image smaller than a patch");
+  if (h < P->patch_sz || w < P->patch_sz) {
+    // no target fits (the reference's loops `px < w - psz + 1`, src/nlkalman.c:586-595, do not run): nothing is
+    // aggregated and every pixel keeps its input value (:939-942)
+    HIPCHK(c, hipMemcpyAsync(out, cur, sizeof(float) * (size_t)w * h * ch, hipMemcpyDeviceToDevice, c->stream));
+    return NLK_OK;
+  }
   const int ngy = (h - P->patch_sz) / step + 1;
   rc = frame_accumulate(c, (float*)c->acc.p, cur, prev, basic, w, h, ch, sigma, P, 0, ngy, smoother, true);
   if (rc) return rc;
@@ -846,7 +851,7 @@ static int frame_host(nlk_ctx* c, float* out_h, const float* cur_h, const float*
   int nb = getenv("NLK_HOST_BANDS") ? atoi(getenv("NLK_HOST_BANDS")) : 5;  // (1080p: 2 bands 2.43 ms, 3 2.30, 4 2.25, 5 2.20, 6 2.22; one upload + call + download 2.9)
   nb = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
   while (nb > 1 && ngy / nb < 4 * (R + 1) + 8) --nb;
-  if (nb < 2 || R > 3 || c->deterministic || c->profiling || psz > 16 || w < psz) {
+  if (nb < 2 || R > 3 || c->deterministic || c->profiling || psz > 16 || w < psz || h < psz) {
     // small frames, masks replayed from the coordinate lists, deterministic slabs, per-kernel timing, and
     // everything the frame call rejects: one upload, the whole-frame call, one download
     HIPCHK(c, hipMemcpyAsync(d_cur, cur_h, bytes, hipMemcpyHostToDevice, c->stream));

@@ -632,7 +632,9 @@ static void run_frame(float *out, const float *cur, const float *prev,
   nlko_window(f.W, f.psz);
   nlko_dct_basis(f.C, f.psz);
   memset(out, 0, sizeof(float) * (size_t)w * h * ch);
-  f.ngx = (w - f.psz) / f.step + 1;
+  /* the reference's loops `for (px = 0; px < w - psz + 1; px += step)` (:586, :595): no target at all in an
+   * image smaller than a patch, and the output is then the input (:939-942) */
+  f.ngx = w >= f.psz ? (w - f.psz) / f.step + 1 : 0;
   f.ngy = ngy;
 #ifdef _OPENMP
   if (nthreads < 1) nthreads = 1;
@@ -688,7 +690,7 @@ void nlko_filter_frame(float *deno1, const float *nisy1, const float *deno0,
                        const float *bsic1, int w, int h, int ch, float sigma,
                        const nlko_params *P, int nthreads, nlko_trace *tr) {
   run_frame(deno1, nisy1, deno0, bsic1, w, h, ch, sigma, P, nthreads, tr, 0, 0,
-            (h - P->patch_sz) / (P->patch_sz / 2) + 1, NULL);
+            h >= P->patch_sz ? (h - P->patch_sz) / (P->patch_sz / 2) + 1 : 0, NULL);
 }
 
 /* reference: src/nlkalman.c:1409-1865 */
@@ -696,7 +698,7 @@ void nlko_smooth_frame(float *smoo1, const float *filt1, const float *smoo0,
                        const float *bsic1, int w, int h, int ch, float sigma,
                        const nlko_params *P, int nthreads, nlko_trace *tr) {
   run_frame(smoo1, filt1, smoo0, bsic1, w, h, ch, sigma, P, nthreads, tr, 1, 0,
-            (h - P->patch_sz) / (P->patch_sz / 2) + 1, NULL);
+            h >= P->patch_sz ? (h - P->patch_sz) / (P->patch_sz / 2) + 1 : 0, NULL);
 }
 
 /* row-strip form (mirror of nlk_dev_frame_accumulate / _normalize in include/nlk_hip.h) */

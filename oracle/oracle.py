@@ -170,7 +170,7 @@ def dct2(planes, inverse=False):
 
 def grid_shape(w, h, psz):
     step = psz // 2
-    return (w - psz) // step + 1, (h - psz) // step + 1
+    return ((w - psz) // step + 1 if w >= psz else 0), ((h - psz) // step + 1 if h >= psz else 0)
 
 
 def _run(fn, cur, prev, basic, sigma, params, nthreads, trace):

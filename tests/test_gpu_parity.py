@@ -134,6 +134,25 @@ def test_edge_cases(ctx, built, O):
         cases.assert_close(g, r, f"psz{psz}")
 
 
+def test_image_smaller_than_a_patch_is_returned_unchanged(ctx, built, O):
+    """No target fits an image narrower or lower than a patch: the reference's loops `px < w - psz + 1`
+    (src/nlkalman.c:586-595, :1477-1486) do not run, nothing is aggregated and every pixel keeps its input value
+    (:939-942, :1853-1856). Device call, host-pointer call and oracle, filter and smoother."""
+    rng = np.random.default_rng(11)
+    for (w, h, ch), psz in [((5, 20, 3), 8), ((20, 7, 1), 8), ((7, 7, 3), 8), ((30, 11, 3), 12), ((3, 2, 1), 4)]:
+        im = rng.uniform(0, 255, (h, w, ch)).astype(np.float32)
+        prev = rng.uniform(0, 255, (h, w, ch)).astype(np.float32)
+        for mode, smo in ((built.FLT1, False), (built.FLT2, False), (built.SMO1, True)):
+            p = built.default_params(20.0, mode, patch_sz=psz)
+            bas = prev if mode == built.FLT2 else None
+            r = (O.smooth_frame if smo else O.filter_frame)(im, prev, bas, 20.0, _to_o(O, p))
+            assert np.array_equal(r, im)
+            g, _ = _dev_frame(ctx, smo, im, prev, bas, 20.0, p)
+            assert np.array_equal(g, im), (w, h, ch, psz, mode)
+            gh = (built.smooth_frame if smo else built.filter_frame)(im, prev, bas, 20.0, p)
+            assert np.array_equal(gh, im), (w, h, ch, psz, mode)
+
+
 def test_unsupported_parameters_fail_loudly(ctx, built):
     """What is left outside the kernels: patches above 16x16, and - across GPUs only - a marking
     group that reaches more than 3 grid cells (64-bit mark words)."""

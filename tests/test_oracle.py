@@ -278,3 +278,17 @@ def test_row_formulation_of_the_mask_replay(O):
             want = O.mask_commit(marks, ngx, ngy, 1)
             got = _rows_replay_words(marks, ngx, ngy)
             assert np.array_equal(got, want), (ngx, ngy, density, right)
+
+
+def test_image_smaller_than_a_patch_comes_back_unchanged(O):
+    """reference: src/nlkalman.c:586-595 (`px < w - psz + 1`: no target), :939-942 (unaggregated pixels keep the input)"""
+    rng = np.random.default_rng(2)
+    for (w, h, ch), psz in [((5, 20, 3), 8), ((20, 7, 1), 8), ((7, 7, 1), 8), ((11, 30, 3), 12)]:
+        im = rng.uniform(0, 255, (h, w, ch)).astype(np.float32)
+        prev = rng.uniform(0, 255, (h, w, ch)).astype(np.float32)
+        p = O.default_params(20.0, O.FLT1, patch_sz=psz)
+        assert np.array_equal(O.filter_frame(im, prev, None, 20.0, p), im)
+        assert np.array_equal(O.filter_frame(im, None, None, 20.0, p), im)
+        ps = O.default_params(20.0, O.SMO1, patch_sz=psz)
+        assert np.array_equal(O.smooth_frame(im, prev, None, 20.0, ps), im)
+        assert O.grid_shape(w, h, psz)[0] * O.grid_shape(w, h, psz)[1] == 0
