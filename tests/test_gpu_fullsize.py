@@ -111,6 +111,24 @@ def test_group_tiles_of_mixed_sizes_1080p(ctx, built, O, synth, monkeypatch, tai
     cases.assert_close(es, ds, f"tail {tail} single {single}: smo1", flips=40)
 
 
+def test_4k_patch8_temporal_against_serial_oracle(ctx, built, O, synth):
+    """3840x2160 RGB sigma 20 with the default 8x8 patches, FLT1 temporal, serial oracle: the patch grid of
+    959 x 539 targets (4x the 1080p one) through the 8-wavefront match tiles, the row replay of the mask and
+    `k_group8m` with its three kinds of tiles (3x2, the last 8 grid rows 3x1, the last 3 one target each).
+    Records exact, pixels within the tolerances of the 1080p tests."""
+    w, h, ch, sigma = 3840, 2160, 3, 20.0
+    n0, n1, c1 = synth.noisy_pair(w, h, ch, sigma, 3)
+    o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+    p = built.default_params(sigma, built.FLT1)
+    prev, _ = _dev_frame(ctx, False, o0, None, None, sigma, p)
+    g, rec = _dev_frame(ctx, False, o1, prev, None, sigma, p)
+    r, tr = O.filter_frame(o1, prev, None, sigma, _to_o(O, p), trace=True)
+    _check_records(rec, tr, "4K psz 8")
+    g, _ = _excuse_threshold_pixels(g, r, tr, "4K psz 8", 256)
+    cases.assert_close(g, r, "4K psz 8", flips=160)
+    assert abs(synth.psnr(built.opp2rgb(g), c1) - synth.psnr(O.opp2rgb(r), c1)) <= 0.02
+
+
 def test_host_pointer_calls_pipeline_the_frame_in_row_bands(ctx, built, synth, monkeypatch):
     """The drop-in API (host pointers, libnlkalman.so -> nlk_filter_frame_host) moves a frame over PCIe in
     row bands while the bands before are matched and filtered, and returns finished rows while the last
