@@ -65,6 +65,7 @@ int launch_group(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cu
   const bool ch13 = g.ch == 1 || g.ch == 3;
   const bool lists_fit = g.kmax <= 128 && g.gstride <= 128;
   c->acc_residual = false;  // (set by the launcher whose kernel accumulates residuals: nlk_launch_group8)
+  if (g.psz > 16) return nlk_launch_group_any(c, g, img, cur, prev, acc, active);  // (k_group_any.h: 17..32)
   if (getenv("NLK_GENERIC_GROUP") || !lists_fit) return nlk_launch_group_generic(c, g, img, cur, prev, acc, active);
   if (g.psz == 8 && ch13 && !getenv("NLK_GROUP_PACKED"))
     return nlk_launch_group8(c, g, img, cur, prev, acc, active);
@@ -402,7 +403,8 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   NlkGeom& g = pl.g;
   g.w = w; g.h = h; g.ch = ch;
   g.psz = P->patch_sz;
-  if (g.psz < 2 || g.psz > 16) return fail(c, NLK_EUNSUP, "patch size %d not supported", g.psz);
+  if (g.psz < 2 || g.psz > 32 || ch * g.psz * g.psz > 4096)
+    return fail(c, NLK_EUNSUP, "patch size %d with %d channels not supported (2..32, ch * psz^2 <= 4096)", g.psz, ch);
   g.step = g.psz / 2;
   g.p2 = g.psz * g.psz;
   g.E = g.p2 * ch;

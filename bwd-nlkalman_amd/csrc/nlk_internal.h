@@ -124,6 +124,9 @@ int nlk_launch_groupp_c(nlk_ctx* c, const NlkGeom& g, const float* img, const fl
 // tu_group_generic.hip: the LDS-DCT kernel (even patch sizes, candidate lists of any length)
 int nlk_launch_group_generic(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur,
                              const float* prev, float* acc, const uint8_t* active);
+// ... and the kernel for patch sizes 17..32 (k_group_any.h)
+int nlk_launch_group_any(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur, const float* prev,
+                         float* acc, const uint8_t* active);
 // tu_match.hip: block matching + selection (wide = the queued targets of a temporal frame)
 int nlk_launch_match(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds, const float* img,
                      int maxm, bool wide);

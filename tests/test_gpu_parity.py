@@ -153,13 +153,55 @@ def test_image_smaller_than_a_patch_is_returned_unchanged(ctx, built, O):
             assert np.array_equal(gh, im), (w, h, ch, psz, mode)
 
 
+@pytest.mark.parametrize("psz,ch,size", [(17, 1, (75, 61)), (20, 3, (90, 70)), (25, 3, (83, 77)), (32, 1, (100, 90)),
+                                         (32, 3, (96, 80)), (8, 2, (60, 50)), (12, 4, (70, 64)), (7, 2, (41, 37))])
+def test_large_patches_and_other_channel_counts(ctx, built, O, psz, ch, size):
+    """Patch sizes 17..32 (`k_bm_generic` + `k_group_any`) and channel counts other than 1 and 3 (`k_bm_generic` +
+    `k_groupp`) - the reference takes any: src/nlkalman.c:524-525, 555-560: FLT1 spatial, FLT1 temporal with a NaN hole in the previous
+    frame, FLT2 and the smoother against the serial oracle - records exact, pixels within tolerance."""
+    rng = np.random.default_rng(100 * psz + ch)
+    w, h = size
+    sigma = 20.0
+    clean = np.add.outer(np.linspace(30, 200, h), np.linspace(0, 40, w))[..., None] * np.ones(ch)
+    n0 = (clean + rng.normal(0, sigma, clean.shape)).astype(np.float32)
+    n1 = (clean + rng.normal(0, sigma, clean.shape)).astype(np.float32)
+    p1 = built.default_params(sigma, built.FLT1, patch_sz=psz)
+    p2 = built.default_params(sigma, built.FLT2, patch_sz=psz)
+    ps = built.default_params(sigma, built.SMO1, patch_sz=psz)
+    r0, t0 = O.filter_frame(n0, None, None, sigma, _to_o(O, p1), trace=True)
+    g0, rec0 = _dev_frame(ctx, False, n0, None, None, sigma, p1)
+    _check_records(rec0, t0, "spatial")
+    cases.assert_close(g0, r0, f"psz {psz} ch {ch}: flt1 spatial")
+    prev = r0.copy()
+    prev[h // 3:h // 3 + 5, w // 2:w // 2 + 9] = np.nan
+    r1, t1 = O.filter_frame(n1, prev, None, sigma, _to_o(O, p1), trace=True)
+    g1, rec1 = _dev_frame(ctx, False, n1, prev, None, sigma, p1)
+    _check_records(rec1, t1, "temporal")
+    cases.assert_close(g1, r1, f"psz {psz} ch {ch}: flt1 temporal")
+    r2, t2 = O.filter_frame(n1, prev, r1, sigma, _to_o(O, p2), trace=True)
+    g2, rec2 = _dev_frame(ctx, False, n1, prev, r1, sigma, p2)
+    _check_records(rec2, t2, "flt2")
+    cases.assert_close(g2, r2, f"psz {psz} ch {ch}: flt2")
+    rs, ts = O.smooth_frame(r0, prev, None, sigma, _to_o(O, ps), trace=True)
+    gs, recs = _dev_frame(ctx, True, r0, prev, None, sigma, ps)
+    _check_records(recs, ts, "smo")
+    cases.assert_close(gs, rs, f"psz {psz} ch {ch}: smo1")
+    # ... and through the drop-in API (host pointers)
+    cases.assert_close(built.filter_frame(n1, prev, None, sigma, p1), r1, f"psz {psz} ch {ch}: host call")
+
+
 def test_unsupported_parameters_fail_loudly(ctx, built):
-    """What is left outside the kernels: patches above 16x16, and - across GPUs only - a marking
-    group that reaches more than 3 grid cells (64-bit mark words)."""
+    """What is left outside the kernels: patches above 32x32 (or ch * psz^2 > 4096), and - across GPUs only - a
+    marking group that reaches more than 3 grid cells (64-bit mark words)."""
     im = np.zeros((40, 40, 1), np.float32)
     d, o = ctx.upload(im), ctx.alloc(im.nbytes)
     with pytest.raises(built.NlkError, match="not supported"):
-        ctx.filter_frame(o, d, None, None, 40, 40, 1, 20.0, built.default_params(20.0, 0, patch_sz=18))
+        ctx.filter_frame(o, d, None, None, 40, 40, 1, 20.0, built.default_params(20.0, 0, patch_sz=34))
+    im5 = np.zeros((40, 40, 5), np.float32)
+    d5, o5 = ctx.upload(im5), ctx.alloc(im5.nbytes)
+    with pytest.raises(built.NlkError, match="not supported"):
+        ctx.filter_frame(o5, d5, None, None, 40, 40, 5, 20.0, built.default_params(20.0, 0, patch_sz=30))
+    ctx.free(d5); ctx.free(o5)
     marks = ctx.upload(np.zeros(19 * 19, np.uint64))
     with pytest.raises(built.NlkError, match="reach"):
         ctx.strip_match(marks, d, None, None, 40, 40, 1, 20.0, built.default_params(20.0, 0, patch_sz=4, search_sz_x=10), 0, 19)
