@@ -319,7 +319,7 @@ def test_gpu_exact_strips_equal_whole_frame(ctx, built, O, synth, world):
     cases.assert_close(got, whole, f"exact strips x{world} vs whole frame", maxabs=5e-4, rmse=5e-5)
 
 
-def _two_rank_worker(rank, world, port, q):
+def _two_rank_worker(rank, world, port, q, backend="gloo"):
     import importlib
     import sys
     import torch
@@ -331,9 +331,13 @@ def _two_rank_worker(rank, world, port, q):
     pkg = importlib.import_module("bwd-nlkalman_amd")
     synth = importlib.import_module("bwd-nlkalman_amd.synth")
     strips = importlib.import_module("bwd-nlkalman_amd.strips")
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    w, h, ch, sigma = 320, 256, 3, 20.0
     dev = torch.device("cuda", 0)
+    if backend == "nccl":   # RCCL: the backend bench.py uses on a multi-GPU node
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    w, h, ch, sigma = 320, 256, 3, 20.0
     ctx = pkg.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, 5)
@@ -369,7 +373,7 @@ def _two_rank_worker(rank, world, port, q):
     for mode, phases in (("exact", (match, commit, group)), ("exact-overlap", (match, commit, group, match_rows)),
                          ("per-strip", None)):
         sf = strips.StripFrame(rank, world, w, h, ch, p.patch_sz, max(p.search_sz_x, p.search_sz_t), dev,
-                               accumulate, normalize, phases=phases, stage_host=True)
+                               accumulate, normalize, phases=phases, stage_host=backend != "nccl")
         sf.load(t_n1, t_prev)
         for _ in range(2):
             # (the halo rows of the previous frame hold garbage until the exchange delivers them: a seam target
@@ -379,10 +383,10 @@ def _two_rank_worker(rank, world, port, q):
             sf.prev[sf._l(pp["own1"]):] = float("nan")
             sf.step()
         y0, y1, rows = sf.own_rows()
-        full = torch.zeros((h, w, ch))
-        full[y0:y1] = rows.cpu()
+        full = torch.zeros((h, w, ch), device=dev if backend == "nccl" else "cpu")
+        full[y0:y1] = rows if backend == "nccl" else rows.cpu()
         dist.all_reduce(full)
-        res[mode] = full.numpy()
+        res[mode] = full.cpu().numpy()
     if rank == 0:
         q.put((res, t_whole.cpu().numpy()))
     dist.destroy_process_group()
@@ -412,6 +416,28 @@ def test_two_processes_drive_gpu_strips(built):
                        maxabs=5e-4, rmse=5e-5)
     d = np.abs(res["per-strip"] - whole)
     assert np.isfinite(res["per-strip"]).all() and (d > 1e-2).mean() < 0.2  # seam-order differences only
+
+
+def test_strip_driver_over_rccl_one_rank(built):
+    """The strip driver on the backend bench.py uses on a multi-GPU node ("nccl" = RCCL, device tensors, no host
+    staging): process-group creation on the device, the 64-bit mark words through `all_gather_into_tensor`, the
+    all-reduce of the assembled rows. One rank is all a one-GPU box can hold (RCCL refuses two ranks on one
+    device), so the neighbour sends have no peer here: those run over gloo in the two-process test above."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    pr = mpc.Process(target=_two_rank_worker, args=(0, 1, port, q, "nccl"))
+    pr.start()
+    res, whole = q.get(timeout=600)
+    pr.join(timeout=120)
+    assert pr.exitcode == 0
+    for mode in ("exact", "exact-overlap", "per-strip"):
+        cases.assert_close(res[mode], whole, f"RCCL, one rank, {mode}", maxabs=5e-4, rmse=5e-5)
 
 
 def test_full_size_1080p_against_oracle(ctx, built, O, synth):
