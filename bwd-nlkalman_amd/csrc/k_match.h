@@ -36,6 +36,7 @@
 
 struct NlkTile {
   int tgx, tgy;       // targets per tile
+  int bx;             // targets per block along x: 4, or 2 (k_bm_topk<.., 2>: 12 x 12 patches, 8 wavefronts on an 8 x 4 tile)
   int ntx, nty;       // tiles
   int rwp, rh_max;    // LDS region: padded row stride (floats) / rows
   int ksel_max;       // capacity of the per-wave survivor arrays
@@ -317,7 +318,7 @@ __device__ __forceinline__ void nlk_match_epilogue(const NlkGeom& g, size_t t, i
   }
 }
 
-template <int PSZ, int CH, int MAXM>
+template <int PSZ, int CH, int MAXM, int BX = 4>  // BX x 2 targets per block (2: twice the wavefronts on the same tile)
 __global__ void __launch_bounds__(512, MAXM == 7 ? 3 : 2)  // (7 rounds in blocks: 168 registers, the LDS tile allows 3 wavefronts per SIMD)
 k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGeom g,
           NlkTile tl, uint32_t* __restrict__ topk, NlkTarget* __restrict__ tinfo,
@@ -453,7 +454,7 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
     for (int tt = wave; tt < cx * cy; tt += nwaves) do_target(tt);
     return;
   }
-  constexpr int BX = 4, BY = 2;
+  constexpr int BY = 2;
   const int nbx = (tl.tgx + BX - 1) / BX, nby = (tl.tgy + BY - 1) / BY;
   for (int blk = wave; blk < nbx * nby; blk += nwaves) {
     const int bty = blk / nbx, tx0 = (blk - bty * nbx) * BX, ty0 = bty * BY;

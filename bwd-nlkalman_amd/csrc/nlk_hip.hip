@@ -490,6 +490,15 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
     // with the spatial radius 10 the 8 x 8 tile is 62 KB: 0.95 / 1.22)
     const bool wg8 = e ? atoi(e) != 0 : (g.psz <= 8 && halo0 <= 6);
     if (wg8 && !small_grid && !getenv("NLK_MTY")) { tl.threads = 512; tl.tgy = 8; }
+    // Patches of 10 x 10 and more: the 8 x 4 tile is 36 KB at 12 x 12 already, so the second four wavefronts come
+    // from blocks of 2 x 2 targets instead of 4 x 2 (a fifth more subtractions and multiplications, twice the
+    // wavefronts per CU: C3 match 0.864 -> 0.762 ms; NLK_MATCH_BX2=0/1 overrides)
+    tl.bx = 4;
+    const char* e2 = getenv("NLK_MATCH_BX2");
+    if ((e2 ? atoi(e2) != 0 : halo0 <= 6) && g.psz >= 10 && !small_grid && tl.tgx == 8 && tl.tgy == 4) {
+      tl.threads = 512;
+      tl.bx = 2;
+    }
   }
   tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
   tl.block = getenv("NLK_MATCH_NOBLOCK") ? 0 : (getenv("NLK_MATCH_BLOCK") ? 1 : !small_grid);

@@ -527,6 +527,34 @@ def test_block_matching_equals_target_by_target(ctx, built, synth, monkeypatch):
     monkeypatch.delenv("NLK_MATCH_NOBLOCK", raising=False)
 
 
+@pytest.mark.parametrize("psz,size", [(10, (1400, 900)), (12, (1600, 1000)), (16, (2000, 1300))])
+def test_blocks_of_2x2_targets_equal_target_by_target(ctx, built, synth, monkeypatch, psz, size):
+    """Patches of 10 x 10 and more put 8 wavefronts on an 8 x 4 tile, each with a block of 2 x 2 targets
+    (`k_bm_topk<.., 2>`). Blocks of 4 x 2 (NLK_MATCH_BX2=0) and no blocks at all (NLK_MATCH_NOBLOCK=1) must give the
+    same records, for temporal frames with NaN holes and for the smoother."""
+    w, h = size
+    ch, sigma = 3, 40.0
+    n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, 30 + psz)
+    o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+    p1 = built.default_params(sigma, built.FLT1, patch_sz=psz)
+    p3 = built.default_params(sigma, built.SMO1, patch_sz=psz)
+    prev, _ = _dev_frame(ctx, False, o0, None, None, sigma, p1)
+    holes = prev.copy()
+    holes[200:260, 500:640] = np.nan
+    holes[:, :3] = np.nan
+    for smo, cur, pv, p in [(False, o1, prev, p1), (False, o1, holes, p1), (True, o1, holes, p3)]:
+        recs = []
+        for env in ({}, {"NLK_MATCH_BX2": "0"}, {"NLK_MATCH_NOBLOCK": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            recs.append(_dev_frame(ctx, smo, cur, pv, None, sigma, p)[1])
+            for k in env:
+                monkeypatch.delenv(k)
+        for other in recs[1:]:
+            for f in ("active", "nsel", "np0", "nagg", "topk", "gcoords"):
+                assert np.array_equal(recs[0][f], other[f]), (psz, smo, f)
+
+
 @pytest.mark.parametrize("reach", [1, 2])
 def test_mask_replay_on_synthetic_mark_words(ctx, O, monkeypatch, reach):
     """The processed-mask replay alone, on mark words no image produces: dense marks, rows where every
