@@ -480,25 +480,21 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   const bool small_grid = (size_t)((g.ngx + 7) / 8) * ((g.ngy + 3) / 4) < 1024;
   tl.tgx = getenv("NLK_MTX") ? atoi(getenv("NLK_MTX")) : (small_grid ? 4 : 8);
   tl.tgy = getenv("NLK_MTY") ? atoi(getenv("NLK_MTY")) : (small_grid ? 2 : 4);
-  // workgroups of 8 wavefronts on tiles of 8 x 8 targets where the patches are small enough for the tile to leave
-  // three workgroups per CU (8 x 8 patches with the temporal radius: 45 KB; NLK_MATCH_WG8=0/1 overrides)
+  // 8 wavefronts per workgroup where the search radius is the temporal one (FLT1 / FLT2 temporal, SMO1), measured at
+  // 1080p, match ms with 8 x 8 patches: 8 x 4 tile, 4 wavefronts, blocks of 4 x 2 targets 0.305 (20 wavefronts per CU);
+  // 8 x 8 tile, 8 wavefronts, 4 x 2 blocks 0.294 (45 KB: three per CU = 24); 8 x 4 tile, 8 wavefronts with a block of
+  // 2 x 2 targets each, 64 registers 0.268 (30 KB: four per CU = 32, a fifth more subtractions and multiplications)
+  // - the default. 10 x 10 patches and more: the same 2 x 2 blocks (4K, 12 x 12: 0.864 -> 0.762, 16 x 16: 1.22 -> 0.91).
+  // With the spatial radius the tiles are too large for more than the four wavefronts (8 x 8 tile 62 KB: 0.95 -> 1.22).
+  // NLK_MATCH_BX2=0 keeps the 4 x 2 blocks, NLK_MATCH_WG8=1 the 8 x 8 tiles.
   tl.threads = NLK_BM_THREADS;
+  tl.bx = 4;
   {
-    const char* e = getenv("NLK_MATCH_WG8");
+    const char *e = getenv("NLK_MATCH_WG8"), *e2 = getenv("NLK_MATCH_BX2");
     const int halo0 = (g.smoother || g.have_prev) ? g.wsz_t : g.wsz_x;
-    // (1080p, match ms with 4 / 8 wavefronts: FLT1 temporal 0.305 / 0.294, FLT2 0.283 / 0.276, SMO1 0.399 / 0.380;
-    // with the spatial radius 10 the 8 x 8 tile is 62 KB: 0.95 / 1.22)
-    const bool wg8 = e ? atoi(e) != 0 : (g.psz <= 8 && halo0 <= 6);
-    if (wg8 && !small_grid && !getenv("NLK_MTY")) { tl.threads = 512; tl.tgy = 8; }
-    // Patches of 10 x 10 and more: the 8 x 4 tile is 36 KB at 12 x 12 already, so the second four wavefronts come
-    // from blocks of 2 x 2 targets instead of 4 x 2 (a fifth more subtractions and multiplications, twice the
-    // wavefronts per CU: C3 match 0.864 -> 0.762 ms; NLK_MATCH_BX2=0/1 overrides)
-    tl.bx = 4;
-    const char* e2 = getenv("NLK_MATCH_BX2");
-    if ((e2 ? atoi(e2) != 0 : halo0 <= 6) && g.psz >= 10 && !small_grid && tl.tgx == 8 && tl.tgy == 4) {
-      tl.threads = 512;
-      tl.bx = 2;
-    }
+    const bool tiles84 = !small_grid && !getenv("NLK_MTX") && !getenv("NLK_MTY");
+    if (e && atoi(e) != 0 && g.psz <= 8 && tiles84) { tl.threads = 512; tl.tgy = 8; }
+    else if ((e2 ? atoi(e2) != 0 : halo0 <= 6) && g.psz >= 8 && tiles84) { tl.threads = 512; tl.bx = 2; }
   }
   tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
   tl.block = getenv("NLK_MATCH_NOBLOCK") ? 0 : (getenv("NLK_MATCH_BLOCK") ? 1 : !small_grid);

@@ -527,9 +527,9 @@ def test_block_matching_equals_target_by_target(ctx, built, synth, monkeypatch):
     monkeypatch.delenv("NLK_MATCH_NOBLOCK", raising=False)
 
 
-@pytest.mark.parametrize("psz,size", [(10, (1400, 900)), (12, (1600, 1000)), (16, (2000, 1300))])
+@pytest.mark.parametrize("psz,size", [(8, (1000, 560)), (10, (1400, 900)), (12, (1600, 1000)), (16, (2000, 1300))])
 def test_blocks_of_2x2_targets_equal_target_by_target(ctx, built, synth, monkeypatch, psz, size):
-    """Patches of 10 x 10 and more put 8 wavefronts on an 8 x 4 tile, each with a block of 2 x 2 targets
+    """With the temporal search radius, patches of 8 x 8 and more put 8 wavefronts on an 8 x 4 tile, each with a block of 2 x 2 targets
     (`k_bm_topk<.., 2>`). Blocks of 4 x 2 (NLK_MATCH_BX2=0) and no blocks at all (NLK_MATCH_NOBLOCK=1) must give the
     same records, for temporal frames with NaN holes and for the smoother."""
     w, h = size
