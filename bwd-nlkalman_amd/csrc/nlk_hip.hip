@@ -494,7 +494,13 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
     const int halo0 = (g.smoother || g.have_prev) ? g.wsz_t : g.wsz_x;
     const bool tiles84 = !small_grid && !getenv("NLK_MTX") && !getenv("NLK_MTY");
     if (e && atoi(e) != 0 && g.psz <= 8 && tiles84) { tl.threads = 512; tl.tgy = 8; }
-    else if ((e2 ? atoi(e2) != 0 : halo0 <= 6) && g.psz >= 8 && tiles84) { tl.threads = 512; tl.bx = 2; }
+    else if ((e2 ? atoi(e2) != 0 : true) && tiles84 &&
+             ((halo0 <= 6 && g.psz >= 8) || (g.psz == 8 && (2 * halo0 + 1) * (2 * halo0 + 1) <= 448))) {
+      // (... and the seven-round blocks of a first frame, 441 candidates: 2 x 2 targets per block need 128 registers
+      // instead of 168 + spills, two 8-wavefront workgroups per CU instead of three of 4: match 0.947 -> 0.828)
+      tl.threads = 512;
+      tl.bx = 2;
+    }
   }
   tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
   tl.block = getenv("NLK_MATCH_NOBLOCK") ? 0 : (getenv("NLK_MATCH_BLOCK") ? 1 : !small_grid);

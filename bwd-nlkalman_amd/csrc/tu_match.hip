@@ -9,7 +9,7 @@ template <int PSZ, int CH, int MAXM>
 int launch_match_t(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds,
                    const float* img, bool wide) {
   auto kern = wide ? k_bm_wide<PSZ, CH, MAXM> : k_bm_topk<PSZ, CH, MAXM>;
-  if constexpr (PSZ >= 8 && MAXM == 2)
+  if constexpr (PSZ >= 8 && (MAXM == 2 || (MAXM == 7 && PSZ == 8)))
     if (!wide && tl.bx == 2) kern = k_bm_topk<PSZ, CH, MAXM, 2>;
   HIPCHK(c, hipFuncSetAttribute((const void*)kern,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
