@@ -106,8 +106,6 @@ k_group_any(const float* __restrict__ img,   // matching / statistics image (pla
     ej[r] = rem - ei[r] * psz;
     poff[r] = ec[r] * (int)npix + ei[r] * g.w + ej[r];
   }
-  const int gy = t / g.ngx, gx = t - gy * g.ngx;
-  (void)gx; (void)gy;
   const bool prev_p = info.flags & 1;
   const int k = info.nsel;
   const float s2 = g.sigma2;

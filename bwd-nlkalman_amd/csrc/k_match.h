@@ -131,14 +131,28 @@ __device__ __forceinline__ void nlk_match_select(const float (&acc)[M], const ui
   nlk_wave_lds_fence();
 
   // --- rank the k survivors among themselves (one 64-bit compare per pair)
-  for (int base = 0; base < k; base += 64) {
-    const int p = base + lane;
+  if (k <= 32) {
+    // two lanes per survivor: lane p counts the first half of the list, lane p + 32 the second
+    const int p = lane & 31, half = lane >> 5, kh = (k + 1) >> 1;
     const uint64_t mine = p < k ? surv[p] : ~0ull;
+    const int j0 = half ? kh : 0, j1 = half ? k : kh;
     int rank = 0;
-    for (int j = 0; j < k; ++j) rank += surv[j] < mine;
-    if (p < k) {
+    for (int j = 0; j < kh; ++j) rank += (j0 + j < j1) && surv[min(j0 + j, k - 1)] < mine;
+    rank += __shfl_xor(rank, 32, 64);
+    if (lane < k) {
       const uint32_t mi = (uint32_t)mine;
       sel[rank] = nlk_pack_xy(x0 + (int)(mi & 0xFFFFu), y0 + (int)(mi >> 16));
+    }
+  } else {
+    for (int base = 0; base < k; base += 64) {
+      const int p = base + lane;
+      const uint64_t mine = p < k ? surv[p] : ~0ull;
+      int rank = 0;
+      for (int j = 0; j < k; ++j) rank += surv[j] < mine;
+      if (p < k) {
+        const uint32_t mi = (uint32_t)mine;
+        sel[rank] = nlk_pack_xy(x0 + (int)(mi & 0xFFFFu), y0 + (int)(mi >> 16));
+      }
     }
   }
   nlk_wave_lds_fence();
