@@ -492,7 +492,7 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   {
     const char *e = getenv("NLK_MATCH_WG8"), *e2 = getenv("NLK_MATCH_BX2");
     const int halo0 = (g.smoother || g.have_prev) ? g.wsz_t : g.wsz_x;
-    const bool tiles84 = !small_grid && !getenv("NLK_MTX") && !getenv("NLK_MTY");
+    const bool tiles84 = tl.tgx == 8 && tl.tgy == 4 && (getenv("NLK_MATCH_BLOCK") || !small_grid);  // (the tiles of a full-size frame)
     if (e && atoi(e) != 0 && g.psz <= 8 && tiles84) { tl.threads = 512; tl.tgy = 8; }
     else if ((e2 ? atoi(e2) != 0 : true) && tiles84 &&
              ((halo0 <= 6 && g.psz >= 8) || (g.psz == 8 && (2 * halo0 + 1) * (2 * halo0 + 1) <= 448))) {

@@ -650,17 +650,20 @@ def test_smoother_full_size_1080p(ctx, built, O, synth):
     cases.assert_close(g, r, "smo 1080p", flips=40)
 
 
-@pytest.mark.parametrize("launch", ["auto", "large-grid"])
+@pytest.mark.parametrize("launch", ["auto", "large-grid", "large-grid-4x2"])
 def test_randomised_parameters_and_shapes(ctx, built, O, monkeypatch, launch):
     """120 seeded random configurations: odd image sizes, every supported patch
     size, clipped windows, k larger than the window, group sizes above k, NaN
     holes, second-iteration and smoother calls. Integer records exact, pixels
     within tolerance, for each of them. Small grids launch in a latency-bound shape
     (small tiles, one target at a time); "large-grid" forces the shapes of a full-size
-    frame - 8 x 4 match tiles in 4 x 2 blocks, 4 x 1 group tiles - onto the same images."""
-    if launch == "large-grid":
+    frame - 8 x 4 match tiles worked in blocks (2 x 2 targets on 8 wavefronts where a full-size frame would use them,
+    4 x 2 on 4 wavefronts otherwise; "large-grid-4x2": 4 x 2 everywhere), 4 x 1 group tiles - onto the same images."""
+    if launch != "auto":
         for k, v in (("NLK_MATCH_BLOCK", "1"), ("NLK_MTX", "8"), ("NLK_MTY", "4"), ("NLK_GTX", "4")):
             monkeypatch.setenv(k, v)
+        if launch == "large-grid-4x2":
+            monkeypatch.setenv("NLK_MATCH_BX2", "0")
     # (NLK_RANDOM_SEED / NLK_RANDOM_COUNT run other or longer sequences, e.g. as a soak test)
     rng = np.random.default_rng(int(os.environ.get("NLK_RANDOM_SEED", 2024)))
     want = int(os.environ.get("NLK_RANDOM_COUNT", 120))

@@ -1,0 +1,37 @@
+import os, sys, numpy as np, importlib
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo/oracle')
+ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
+for p in (ROOT, ROOT + '/tests', ROOT + '/oracle'):
+    sys.path.insert(0, p)
+import cases
+import oracle as O
+O.build()
+built = importlib.import_module('bwd-nlkalman_amd')
+tp = importlib.import_module('test_gpu_parity')
+ctx = built.Context(0)
+rng = np.random.default_rng(int(sys.argv[1]))
+for it in range(int(sys.argv[2])):
+    w, h = int(rng.integers(1700, 2300)), int(rng.integers(950, 1300))
+    ch = int(rng.choice([1, 3]))
+    smoother = rng.random() < 0.3
+    mode = built.SMO1 if smoother else int(rng.choice([built.FLT1, built.FLT2]))
+    sigma = float(rng.choice([10.0, 20.0, 40.0]))
+    over = dict(patch_sz=8, search_sz_t=int(rng.integers(2, 7)), npatches_t=int(rng.integers(2, 64)),
+                npatches_tagg=int(rng.integers(1, 45)), npatches_x=int(rng.integers(2, 64)))
+    p = built.default_params(sigma, mode, **over)
+    base = np.add.outer(np.linspace(20, 220, h), np.linspace(0, 30, w))[..., None] * np.ones(ch)
+    cur = (base + rng.normal(0, sigma, base.shape)).astype(np.float32)
+    prev = (base + rng.normal(0, sigma / 3, base.shape)).astype(np.float32)
+    for _ in range(6):
+        y0, x0 = int(rng.integers(0, h - 40)), int(rng.integers(0, w - 60))
+        prev[y0:y0 + int(rng.integers(1, 40)), x0:x0 + int(rng.integers(1, 60))] = np.nan
+    basic = (base + rng.normal(0, 3, base.shape)).astype(np.float32) if mode == built.FLT2 else None
+    fn = O.smooth_frame if smoother else O.filter_frame
+    r, tr = fn(cur, prev, basic, sigma, tp._to_o(O, p), trace=True)
+    g, rec = tp._dev_frame(ctx, smoother, cur, prev, basic, sigma, p)
+    what = f"#{it} {w}x{h}x{ch} mode{mode} {over} sigma{sigma}"
+    tp._check_records(rec, tr, what)
+    edge = np.abs(tr["aggr"] - 1e-6) <= 1e-10
+    g = np.where(edge[..., None], r, g)
+    cases.assert_close(g, r, what, flips=80)
+    print("ok", what, "active", float(tr["active"].mean()), flush=True)
