@@ -515,8 +515,16 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   }
   tl.rh_max = (tl.tgy - 1) * g.step + 2 * tl.halo + g.psz;
   tl.ksel_max = g.kmax;
-  pl.lds = sizeof(float) * ((size_t)ch * tl.rwp * tl.rh_max + 1 +
-                            (size_t)(tl.threads / 64) * (3 * tl.ksel_max + ntagg_alloc));
+  auto tile_lds = [&]() {
+    return sizeof(float) * ((size_t)ch * tl.rwp * tl.rh_max + 1 + (size_t)(tl.threads / 64) * (3 * tl.ksel_max + ntagg_alloc));
+  };
+  pl.lds = tile_lds();
+  if (pl.lds > 160 * 1024 && tl.threads > NLK_BM_THREADS && tl.tgy == 4) {
+    // (very long lists: the per-wavefront list space of 8 wavefronts does not fit beside the tile - 4 wavefronts, 4 x 2 blocks)
+    tl.threads = NLK_BM_THREADS;
+    tl.bx = 4;
+    pl.lds = tile_lds();
+  }
   if (pl.lds > 160 * 1024) pl.generic = true;  // (a k or window too large for the tile: the generic kernel)
   // targets of a temporal frame without a valid previous patch search the spatial window
   // (reference: :637); when that one is the wider, they are queued for a second launch
