@@ -45,12 +45,12 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
     tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
     tl.nty_full = tl.nty;
     tl.single = 0;
-    if (mfma && tl.tgy > 1 && !c->deterministic) {
+    if (mfma && (tl.tgy > 1 || tl.tgx > 1) && !c->deterministic) {
       // The launch ends when its last tile does, and a 3 x 2 tile takes 1/7 of a 1080p launch (21600 tiles on 3072
       // wavefront slots): the chip would drain for most of a tile's time. So the last ~0.8 slots' worth of tiles
       // hold one grid row (3 x 1), and the last ~0.9 slots' worth of targets go one per workgroup
       // (1080p: 16 + 6 of 269 grid rows; group 0.950 -> 0.900 ms. NLK_G8_TAIL / NLK_G8_SINGLE override)
-      int tail = getenv("NLK_G8_TAIL") ? atoi(getenv("NLK_G8_TAIL")) : (2560 + tl.ntx / 2) / tl.ntx;
+      int tail = tl.tgy == 1 ? 0 : (getenv("NLK_G8_TAIL") ? atoi(getenv("NLK_G8_TAIL")) : (2560 + tl.ntx / 2) / tl.ntx);
       int single = getenv("NLK_G8_SINGLE") ? atoi(getenv("NLK_G8_SINGLE")) : (2880 + g.ngx / 2) / g.ngx;
       single = max(0, min(single, g.ngy / 8));
       tail = max(0, min(tail, g.ngy / 4));

@@ -111,6 +111,32 @@ def test_group_tiles_of_mixed_sizes_1080p(ctx, built, O, synth, monkeypatch, tai
     cases.assert_close(es, ds, f"tail {tail} single {single}: smo1", flips=40)
 
 
+def test_single_target_tail_on_single_row_tiles_720p(ctx, built, O, synth, monkeypatch):
+    """Grids that use tiles of one grid row (2 x 1 targets: 720p, and every first frame) end their launch on single
+    targets too. FLT1 spatial + temporal at 1280x720 against the serial oracle, and against the same calls with the
+    tail switched off / enlarged."""
+    w, h, ch, sigma = 1280, 720, 3, 20.0
+    n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, 9)
+    o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+    p1 = built.default_params(sigma, built.FLT1)
+    d0, rec0 = _dev_frame(ctx, False, o0, None, None, sigma, p1)
+    d1, rec1 = _dev_frame(ctx, False, o1, d0, None, sigma, p1)
+    r0, tr0 = O.filter_frame(o0, None, None, sigma, _to_o(O, p1), trace=True)
+    _check_records(rec0, tr0, "720p spatial")
+    g0, _ = _excuse_threshold_pixels(d0, r0, tr0, "720p spatial", 64)
+    cases.assert_close(g0, r0, "720p spatial")
+    r1, tr1 = O.filter_frame(o1, d0, None, sigma, _to_o(O, p1), trace=True)
+    _check_records(rec1, tr1, "720p temporal")
+    g1, _ = _excuse_threshold_pixels(d1, r1, tr1, "720p temporal", 64)
+    cases.assert_close(g1, r1, "720p temporal")
+    for single in ("0", "5", "40"):
+        monkeypatch.setenv("NLK_G8_SINGLE", single)
+        e0, _ = _dev_frame(ctx, False, o0, None, None, sigma, p1)
+        e1, _ = _dev_frame(ctx, False, o1, d0, None, sigma, p1)
+        cases.assert_close(e0, d0, f"single {single}: spatial", flips=40)
+        cases.assert_close(e1, d1, f"single {single}: temporal", flips=40)
+
+
 def test_4k_patch8_temporal_against_serial_oracle(ctx, built, O, synth):
     """3840x2160 RGB sigma 20 with the default 8x8 patches, FLT1 temporal, serial oracle: the patch grid of
     959 x 539 targets (4x the 1080p one) through the 8-wavefront match tiles, the row replay of the mask and
