@@ -125,7 +125,10 @@ __device__ inline float nlk_cubic(const float v[4], float x) {
                       x * (3.0 * (v[1] - v[2]) + v[3] - v[0]))));
 }
 
-// reference: src/nlkalman.c:29-33, 43-88 — one thread per output pixel
+// reference: src/nlkalman.c:29-33, 43-88 — one thread per output pixel. The 16 taps are gathered first, all
+// channels of a tap together (CH = 3: one 12-byte load per tap instead of three 4-byte ones; CH = 0: any channel
+// count, tap by tap), then every channel is interpolated in the reference's order: columns with fy, then the row with fx.
+template <int CH>
 __global__ void k_warp_bicubic(float* __restrict__ imw, const float* __restrict__ im,
                                const float* __restrict__ of, const float* __restrict__ msk,
                                int w, int h, int ch) {
@@ -143,6 +146,33 @@ __global__ void k_warp_bicubic(float* __restrict__ imw, const float* __restrict_
   yw -= 1;
   const int ix = (int)floorf(xw), iy = (int)floorf(yw);
   const float fx = xw - ix, fy = yw - iy;
+  if (CH > 0) {
+    float t[4][4][CH > 0 ? CH : 1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int sx = ix + i, sy = iy + j;
+        const bool in = !(sx < 0 || sx >= w || sy < 0 || sy >= h);
+        const float* p = im + ((size_t)(in ? sx : 0) + (size_t)(in ? sy : 0) * w) * CH;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const float v = p[c];
+          t[i][j][c] = in ? v : __builtin_nanf("");
+        }
+      }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float col[4] = {t[i][0][c], t[i][1][c], t[i][2][c], t[i][3][c]};
+        v[i] = nlk_cubic(col, fy);
+      }
+      o[c] = nlk_cubic(v, fx);
+    }
+    return;
+  }
   for (int c = 0; c < ch; ++c) {
     float v[4];
     for (int i = 0; i < 4; ++i) {

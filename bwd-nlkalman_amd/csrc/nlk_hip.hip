@@ -333,7 +333,8 @@ int nlk_dev_warp_bicubic(nlk_ctx* c, float* imw, const float* im, const float* o
   if (rc) return rc;
   NLK_USE_DEVICE(c);
   if (!of) return fail(c, NLK_EINVAL, "null flow");
-  hipLaunchKernelGGL(k_warp_bicubic, dim3((w + 127) / 128, h), dim3(128), 0, c->stream, imw,
+  auto kern = ch == 3 ? k_warp_bicubic<3> : (ch == 1 ? k_warp_bicubic<1> : k_warp_bicubic<0>);
+  hipLaunchKernelGGL(kern, dim3((w + 127) / 128, h), dim3(128), 0, c->stream, imw,
                      im, of, msk, w, h, ch);
   HIPCHK(c, hipGetLastError());
   return NLK_OK;
