@@ -190,6 +190,24 @@ def test_large_patches_and_other_channel_counts(ctx, built, O, psz, ch, size):
     cases.assert_close(built.filter_frame(n1, prev, None, sigma, p1), r1, f"psz {psz} ch {ch}: host call")
 
 
+@pytest.mark.parametrize("ch", [1, 2, 3, 4])
+def test_warp_bicubic_any_channel_count(built, O, ch):
+    """`warp_bicubic` (src/nlkalman.c:29-88) through the drop-in API for 1..4 channels - `k_warp_bicubic<1>`, `<3>`
+    and the tap-by-tap kernel for the rest: flows that leave the image (NaN ring), an occlusion mask, bit-exact
+    against the oracle (same mixed float / double evaluation)."""
+    rng = np.random.default_rng(40 + ch)
+    h, w = 57, 83
+    im = rng.uniform(0, 255, (h, w, ch)).astype(np.float32)
+    im[10:12, 20:23] = np.nan
+    flow = rng.normal(0, 3, (h, w, 2)).astype(np.float32)
+    flow[:5] += 9.0
+    occ = (rng.random((h, w)) < 0.05).astype(np.float32)
+    for m in (None, occ):
+        r, g = O.warp_bicubic(im, flow, m), built.warp_bicubic(im, flow, m)
+        assert np.array_equal(np.isnan(r), np.isnan(g))
+        assert np.array_equal(np.nan_to_num(r), np.nan_to_num(g)), ch
+
+
 def test_unsupported_parameters_fail_loudly(ctx, built):
     """What is left outside the kernels: patches above 32x32 (or ch * psz^2 > 4096), and - across GPUs only - a
     marking group that reaches more than 3 grid cells (64-bit mark words)."""
