@@ -30,7 +30,7 @@ HIP_SYMBOLS = [
     "nlk_dev_strip_match", "nlk_dev_strip_match_rows", "nlk_dev_mask_commit", "nlk_dev_strip_group",
     "nlk_tvl1_default_params", "nlk_tvl1_scales", "nlk_dev_tvl1_flow", "nlk_dev_gray",
     "nlk_dev_occlusion_mask", "nlk_dev_image_dct", "nlk_dev_copy_block", "nlk_host_tables", "nlk_ctx_set_deterministic", "nlk_dev_zero", "nlk_dev_add", "nlk_dev_copy_peer",
-    "nlk_filter_frame_host", "nlk_smooth_frame_host", "nlk_dev_strip_match_part",
+    "nlk_filter_frame_host", "nlk_smooth_frame_host", "nlk_dev_strip_match_part", "nlk_ctx_reload_switches",
 ]
 API_SYMBOLS = [
     "rgb2opp", "opp2rgb", "warp_bicubic", "nlkalman_default_params",
@@ -135,6 +135,7 @@ def hip():
         L.nlk_dev_copy_block.argtypes = [vp, fp, i, fp, i, i, i, i]
         L.nlk_host_tables.argtypes = [i, vp, vp, vp]
         L.nlk_ctx_set_deterministic.argtypes = [vp, i]
+        L.nlk_ctx_reload_switches.argtypes = [vp]
         _hip = L
     return _hip
 
@@ -240,14 +241,21 @@ def warp_bicubic(im, flow, occ=None):
 
 
 def host_tables(psz):
-    """The DCT basis and aggregation window a frame call uploads for this patch size, and the
-    compile-time 12x12 basis of the register kernel (nlk_host_tables; no device needed)."""
+    """The DCT basis and aggregation window a frame call uploads for this patch size, and the 12x12
+    matrix the 12-point flow graph of k_dct12.h applies (nlk_host_tables; no device needed)."""
     b, w, b12 = (np.zeros((psz, psz), np.float32), np.zeros((psz, psz), np.float32),
                  np.zeros((12, 12), np.float32))
     rc = hip().nlk_host_tables(psz, b.ctypes.data, w.ctypes.data, b12.ctypes.data)
     if rc:
         raise NlkError(hip().nlk_last_error(None).decode())
     return b, w, b12
+
+
+def reload_switches():
+    """Re-read the NLK_* environment switches for every live context of this process (they are read once,
+    at context creation: include/nlk_hip.h). Only the tests need this."""
+    if _hip is not None:
+        _hip.nlk_ctx_reload_switches(None)
 
 
 # ------------------------------------------------------- device-resident C-ABI

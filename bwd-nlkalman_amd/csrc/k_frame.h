@@ -61,25 +61,15 @@ __global__ void k_nan_cols4(const uint32_t* __restrict__ rowok, uint32_t* __rest
 // out = acc_c / acc_w where acc_w > 1e-6 else the input frame
 // (reference: src/nlkalman.c:939-942, 1853-1856; the double literal 1e-6 there
 // compares like 1e-6f against a float weight)
-// `residual`: the value planes hold the weighted sum of (member pixel - image pixel) only (the smoother on the
-// matrix cores, k_group8m.h): the image comes back here, out = image + acc_c / acc_w
 __global__ void k_normalize(float* __restrict__ out, const float* __restrict__ acc,
                             const float* __restrict__ cur_hwc, int w, int h, int ch,
-                            int y0, int y1, int residual) {
+                            int y0, int y1) {
   const size_t npix = (size_t)w * h;
   for (size_t i = (size_t)y0 * w + blockIdx.x * blockDim.x + threadIdx.x;
        i < (size_t)y1 * w; i += (size_t)gridDim.x * blockDim.x) {
     const float a = acc[(size_t)ch * npix + i];
-    for (int c = 0; c < ch; ++c) {
-      float v;
-      if (a > 1e-6f) {  // (the input frame is read only where it is needed)
-        v = acc[(size_t)c * npix + i] / a;
-        if (residual) v += cur_hwc[i * ch + c];
-      } else {
-        v = cur_hwc[i * ch + c];
-      }
-      out[i * ch + c] = v;
-    }
+    for (int c = 0; c < ch; ++c)  // (the input frame is read only where it is needed)
+      out[i * ch + c] = a > 1e-6f ? acc[(size_t)c * npix + i] / a : cur_hwc[i * ch + c];
   }
 }
 

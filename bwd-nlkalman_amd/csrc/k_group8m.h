@@ -86,6 +86,13 @@ __device__ __forceinline__ void nlk_fold(const float (&R)[16], float (&F)[4][4])
   }
 }
 
+// the 16 folded values and an offset through one empty asm statement: whatever is computed from `o` afterwards
+// (the addresses of the next loads) cannot be issued before F exists
+#define NLK_PIN_FOLD(F, o)                                                                                        \
+  asm volatile("" : "+v"(F[0][0]), "+v"(F[0][1]), "+v"(F[0][2]), "+v"(F[0][3]), "+v"(F[1][0]), "+v"(F[1][1]),    \
+               "+v"(F[1][2]), "+v"(F[1][3]), "+v"(F[2][0]), "+v"(F[2][1]), "+v"(F[2][2]), "+v"(F[2][3]),          \
+               "+v"(F[3][0]), "+v"(F[3][1]), "+v"(F[3][2]), "+v"(F[3][3]), "+v"(o))
+
 // C_q += X^T D_q^T (patches along the rows) or D_q X (swapped: coefficients along the rows)
 template <bool SWAP>
 __device__ __forceinline__ void nlk_mfma_fwd(const float (&F)[4][4], const float (&dA)[4][4],
@@ -111,8 +118,11 @@ __device__ __forceinline__ float nlk_wave_sum_dpp(float v) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+#ifndef NLK_G8_WPS
+#define NLK_G8_WPS 3  // wavefronts per SIMD the register budget is cut for (experiments: -DNLK_G8_WPS=2)
+#endif
 template <int CH, bool SMO>
-__global__ void __launch_bounds__(64, 3)
+__global__ void __launch_bounds__(64, NLK_G8_WPS)
 k_group8m(const float* __restrict__ img,   // matching / statistics image (planar)
           const float* __restrict__ cur,   // image whose patches are filtered
           const float* __restrict__ prev,  // previous output or nullptr
@@ -331,11 +341,17 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       for (int ch = 0; ch < CH; ++ch)
       for (int b = 0; b < nb; ++b) {
         nlk_fold(R, F);
-        __builtin_amdgcn_sched_barrier(0);  // (the reload below reuses R: no second register set, no copies)
         // the next step's rows; after a channel's last step the next channel's first (after the very
         // last step: a harmless reload)
         const bool wrap = b + 1 == nb;
-        rows_read(wrap ? o_step0 : onext, wrap ? p0sel : pnsel, wrap ? min(ch + 1, CH - 1) : ch, R);
+        int o_load = wrap ? o_step0 : onext;
+        // The reload below reuses R (no second register set). A sched_barrier alone does not order it: the fold has no
+        // side effects, so instruction selection placed it BEHIND the loads and paid 16 v_mov per step to keep the
+        // rows alive. The empty statement makes the load address depend on it: the folded values exist before the
+        // loads are issued.
+        NLK_PIN_FOLD(F, o_load);
+        __builtin_amdgcn_sched_barrier(0);
+        rows_read(o_load, wrap ? p0sel : pnsel, wrap ? min(ch + 1, CH - 1) : ch, R);
         onext = slot_off(wrap ? 1 : b + 2, pnsel);
         __builtin_amdgcn_sched_barrier(0);
         nlk_f4 C[4];
@@ -469,6 +485,21 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       if (SMO) nlk_rows_load(psrc + off, g.w, g4, Rp);
     }
     int offn = member_off(4);
+    // Where every member lands in the tile, worked out once per target with one member per lane: its offset
+    // (floats) inside a plane, and one bit per member "inside the tile" (entries past the last member count as
+    // inside). A step whose four members are all inside - every step of a temporal target: the tile's halo is
+    // the temporal radius - then aggregates in straight-line code. (Before, each member brought ~20 scalar
+    // instructions and five branches with it: a sixth of the kernel's time, measured with the member loop
+    // compiled out.)
+    uint32_t mbase[2];
+    uint64_t inside[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int lx = nlk_x(greg[m]) - rx0, ly = nlk_y(greg[m]) - ry0;
+      const bool in = lx >= 0 && ly >= 0 && lx + PSZ <= rw && ly + PSZ <= rh;
+      mbase[m] = (uint32_t)(ly * rwp + lx);
+      inside[m] = __ballot(in || lane + 64 * m >= nagg);
+    }
     // the reference adds the same per-coefficient terms once per group member
     float vp = nlk_wave_sum_dpp(part_sum) * (float)nagg;
     if (passthrough) vp = 0.f;
@@ -486,8 +517,8 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         // reference: :1775) is A + a (B - A), and every step from here to the frame is linear: the member's
         // pixels are its image patch + IDCT(a . DCT(previous patch - image patch)), and the image patches,
         // added with the members' weights, sum to image x weight plane. So only the SECOND term goes through
-        // the transforms - one forward transform of the pixel difference instead of two - and k_normalize adds
-        // the image back (nlk_ctx::acc_residual).
+        // the transforms - one forward transform of the pixel difference instead of two - and the image term is
+        // added where the tile leaves for the frame (the flush below): image x the tile's weight plane.
 #pragma unroll
         for (int c = 0; c < 16; ++c) R[c] = Rp[c] - R[c];
       }
@@ -532,6 +563,30 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         for (int q = 0; q < 4; ++q)
           Z[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(Y[q][s], dI[q][s], Z[q], 0, 0, 0);
       // register m of Z = member n0+m, plane g4, folded pixel lo
+      const uint32_t in4 = (uint32_t)((n0 < 64 ? inside[0] >> n0 : inside[1] >> (n0 - 64)) & 0xfull);
+      if (in4 == 0xfu && n0 + 4 <= nagg) {
+        const uint32_t mb = n0 < 64 ? mbase[0] : mbase[1];
+        // (read with every lane active: a lane read inside `if (agg_on)` is only defined for the lanes that are
+        // on there, and the member index runs over all 64)
+        int tile_off[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) tile_off[m] = __builtin_amdgcn_readlane((int)mb, (n0 & 63) + m);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const float e0 = Z[0][m] + Z[1][m], e1 = Z[0][m] - Z[1][m];
+          const float o0 = Z[2][m] + Z[3][m], o1 = Z[2][m] - Z[3][m];
+          const float px[4] = {e0 + o0, e1 + o1, e0 - o0, e1 - o1};
+          if (agg_on) {  // (CH = 3: every lane group owns a plane)
+            float* dst = smem + tile_off[m];
+            float old[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) old[kk] = dst[poff[kk]];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) dst[poff[kk]] = fmaf(ww[kk], px[kk], old[kk]);
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         if (n0 + m >= nagg) break;
@@ -552,7 +607,14 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
             for (int kk = 0; kk < 4; ++kk) dst[poff[kk]] = fmaf(ww[kk], px[kk], old[kk]);
           }
         } else if (agg_on) {
+          // a member outside the tile (never with the smoother's own halo; kept complete): straight to the frame,
+          // the smoother's image term with it
           float* dst = acc_p + (size_t)qy * g.w + qx;
+          if (SMO && g4 < CH) {
+            const float* ip = src + (size_t)g4 * npix + (size_t)qy * g.w + qx;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) px[kk] += ip[goff[kk]];
+          }
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) unsafeAtomicAdd(dst + goff[kk], ww[kk] * px[kk]);
         }
@@ -569,6 +631,20 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       if (any_target) { atomicAdd(&tl.tcount[0], 1); atomicAdd(&tl.tcount[1 + tile_y], 1); }
     }
     if (any_target) {
+      if (SMO) {
+        // (the smoother's tile holds weighted sums of member - image: the image term, image x weight plane, joins
+        // here, so that a slab means what every other slab means)
+        const float* wsp = smem + CH * plane;
+        for (int p = 0; p < CH; ++p) {
+          const float* ip = src + (size_t)p * npix + (size_t)ry0 * g.w + rx0;
+          for (int y = 0; y < rh; ++y)
+            for (int xx = lane; xx < rw; xx += 64) {
+              const float wv = wsp[y * rwp + xx];
+              if (wv != 0.f) smem[p * plane + y * rwp + xx] = fmaf(ip[(size_t)y * g.w + xx], wv, smem[p * plane + y * rwp + xx]);
+            }
+        }
+        __syncthreads();
+      }
       nlk_f4* dst = reinterpret_cast<nlk_f4*>(tl.slab + (size_t)tile_id * (CH + 1) * plane);
       for (int i = lane; i < (CH + 1) * plane / 4; i += 64) dst[i] = reinterpret_cast<const nlk_f4*>(smem)[i];
     }
@@ -578,13 +654,22 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     const bool two = rw <= 32;
     const int fx = two ? (lane & 31) : lane, fy = two ? (lane >> 5) : 0;
     const int sx = two ? 32 : 64, sy = two ? 2 : 1;
+    const float* wsp = smem + CH * plane;
     for (int p = 0; p <= CH; ++p) {
       const float* sp = smem + p * plane;
       float* dp = acc + (size_t)p * npix + (size_t)ry0 * g.w + rx0;
+      const float* ip = src + (size_t)min(p, CH - 1) * npix + (size_t)ry0 * g.w + rx0;
 #pragma unroll 4
       for (int y = fy; y < rh; y += sy)
         for (int xx = fx; xx < rw; xx += sx) {
-          const float v = sp[y * rwp + xx];
+          float v = sp[y * rwp + xx];
+          if (SMO && p < CH) {
+            // the smoother's tile holds weighted sums of (member - image): the image term of every member that
+            // landed on this pixel is image x the tile's weight, added here - the accumulator keeps its meaning
+            // (weighted sums of member pixels) for whoever normalises or reduces it
+            const float wv = wsp[y * rwp + xx];
+            if (wv != 0.f) v = fmaf(ip[(size_t)y * g.w + xx], wv, v);
+          }
           if (v != 0.f) unsafeAtomicAdd(dp + (size_t)y * g.w + xx, v);
         }
     }

@@ -7,6 +7,17 @@
 #include <math.h>
 #include <time.h>
 
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+// (the 12-point flow graph of the device code, compiled for the host: nlk_host_tables lets the tests pin it)
+namespace nlk_host12 {
+#define NLK_HD static inline
+#include "k_dct12.h"
+#undef NLK_HD
+}  // namespace nlk_host12
+
 #include "k_commit.h"
 #include "k_frame.h"
 #include "k_match.h"   // NlkTile (the kernels themselves are compiled in tu_match.hip)
@@ -15,6 +26,10 @@
 char nlk_g_err[512] = "";
 
 namespace {
+
+// live contexts (nlk_ctx_reload_switches(NULL) re-reads the environment for all of them)
+std::mutex g_live_mu;
+std::vector<nlk_ctx*> g_live;
 
 typedef NlkBuf Buf;
 
@@ -64,12 +79,10 @@ int launch_group(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cu
   // row)), NLK_GENERIC_GROUP=1 (LDS-DCT kernel, which also takes the lists of more than 128 entries)
   const bool ch13 = g.ch == 1 || g.ch == 3;
   const bool lists_fit = g.kmax <= 128 && g.gstride <= 128;
-  c->acc_residual = false;  // (set by the launcher whose kernel accumulates residuals: nlk_launch_group8)
   if (g.psz > 16) return nlk_launch_group_any(c, g, img, cur, prev, acc, active);  // (k_group_any.h: 17..32)
-  if (getenv("NLK_GENERIC_GROUP") || !lists_fit) return nlk_launch_group_generic(c, g, img, cur, prev, acc, active);
-  if (g.psz == 8 && ch13 && !getenv("NLK_GROUP_PACKED"))
+  if (nlk_set(c->sw.generic_group) || !lists_fit) return nlk_launch_group_generic(c, g, img, cur, prev, acc, active);
+  if (g.psz == 8 && ch13 && !nlk_set(c->sw.group_packed))
     return nlk_launch_group8(c, g, img, cur, prev, acc, active);
-  if (g.psz == 12 && ch13 && getenv("NLK_GROUP12_ROWS")) return nlk_launch_group12(c, g, img, cur, prev, acc, active);
   if (g.psz <= 8) return nlk_launch_groupp_a(c, g, img, cur, prev, acc, active);
   if (g.psz <= 12) return nlk_launch_groupp_b(c, g, img, cur, prev, acc, active);
   return nlk_launch_groupp_c(c, g, img, cur, prev, acc, active);
@@ -132,12 +145,17 @@ int nlk_ctx_create(nlk_ctx** out, int device) {
     return fail(nullptr, NLK_EHIP, "cannot create a stream on device %d", device);
   }
   c->stream = c->own_stream;
-  c->deterministic = getenv("NLK_DETERMINISTIC") && atoi(getenv("NLK_DETERMINISTIC")) != 0;
+  c->sw.load();
+  c->deterministic = nlk_or(c->sw.deterministic, 0) != 0;
   bool ok = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) == hipSuccess;
   for (hipEvent_t& e : c->sync_ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     nlk_ctx_destroy(c);
     return fail(nullptr, NLK_EHIP, "cannot create the second stream / events on device %d", device);
+  }
+  {
+    std::lock_guard<std::mutex> lock(g_live_mu);
+    g_live.push_back(c);
   }
   *out = c;
   return NLK_OK;
@@ -145,6 +163,10 @@ int nlk_ctx_create(nlk_ctx** out, int device) {
 
 void nlk_ctx_destroy(nlk_ctx* c) {
   if (!c) return;
+  {
+    std::lock_guard<std::mutex> lock(g_live_mu);
+    g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end());
+  }
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
@@ -214,6 +236,16 @@ int nlk_ctx_get_timings(nlk_ctx* c, struct nlk_timings* t) {
 int nlk_ctx_set_deterministic(nlk_ctx* c, int on) {
   if (!c) return NLK_EINVAL;
   c->deterministic = on != 0;
+  return NLK_OK;
+}
+
+int nlk_ctx_reload_switches(nlk_ctx* c) {
+  std::lock_guard<std::mutex> lock(g_live_mu);
+  for (nlk_ctx* x : g_live)
+    if (!c || x == c) {
+      x->sw.load();
+      if (nlk_set(x->sw.deterministic)) x->deterministic = x->sw.deterministic != 0;
+    }
   return NLK_OK;
 }
 
@@ -435,7 +467,7 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   // the tiled matching kernels exist for patch sizes 4 / 6 / 8 / 10 / 12 / 16, 1 or 3 channels and
   // windows of up to 1024 candidates; everything else the reference accepts goes to k_bm_generic
   pl.generic = !(g.psz == 4 || g.psz == 6 || g.psz == 8 || g.psz == 10 || g.psz == 12 || g.psz == 16) ||
-               !(ch == 1 || ch == 3) || ncand > 64 * 16 || getenv("NLK_GENERIC_MATCH");
+               !(ch == 1 || ch == 3) || ncand > 64 * 16 || nlk_set(c->sw.generic_match);
   g.kmax = max(max(g.npx, g.npt), 1);
   const int ngrid = g.ngx * g.ngy;
   const int npix = w * h;
@@ -479,8 +511,8 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   // (fewer than ~4 such tiles per CU: 256 x 256, 640 x 480) is latency bound instead: 4 x 2 tiles, one
   // target at a time, two targets per wavefront (C1: match 0.058 -> 0.02 ms)
   const bool small_grid = (size_t)((g.ngx + 7) / 8) * ((g.ngy + 3) / 4) < 1024;
-  tl.tgx = getenv("NLK_MTX") ? atoi(getenv("NLK_MTX")) : (small_grid ? 4 : 8);
-  tl.tgy = getenv("NLK_MTY") ? atoi(getenv("NLK_MTY")) : (small_grid ? 2 : 4);
+  tl.tgx = nlk_or(c->sw.mtx, small_grid ? 4 : 8);
+  tl.tgy = nlk_or(c->sw.mty, small_grid ? 2 : 4);
   // 8 wavefronts per workgroup where the search radius is the temporal one (FLT1 / FLT2 temporal, SMO1), measured at
   // 1080p, match ms with 8 x 8 patches: 8 x 4 tile, 4 wavefronts, blocks of 4 x 2 targets 0.305 (20 wavefronts per CU);
   // 8 x 8 tile, 8 wavefronts, 4 x 2 blocks 0.294 (45 KB: three per CU = 24); 8 x 4 tile, 8 wavefronts with a block of
@@ -491,11 +523,10 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   tl.threads = NLK_BM_THREADS;
   tl.bx = 4;
   {
-    const char *e = getenv("NLK_MATCH_WG8"), *e2 = getenv("NLK_MATCH_BX2");
     const int halo0 = (g.smoother || g.have_prev) ? g.wsz_t : g.wsz_x;
-    const bool tiles84 = tl.tgx == 8 && tl.tgy == 4 && (getenv("NLK_MATCH_BLOCK") || !small_grid);  // (the tiles of a full-size frame)
-    if (e && atoi(e) != 0 && g.psz <= 8 && tiles84) { tl.threads = 512; tl.tgy = 8; }
-    else if ((e2 ? atoi(e2) != 0 : true) && tiles84 &&
+    const bool tiles84 = tl.tgx == 8 && tl.tgy == 4 && (nlk_set(c->sw.match_block) || !small_grid);  // (the tiles of a full-size frame)
+    if (nlk_or(c->sw.match_wg8, 0) != 0 && g.psz <= 8 && tiles84) { tl.threads = 512; tl.tgy = 8; }
+    else if (nlk_or(c->sw.match_bx2, 1) != 0 && tiles84 &&
              ((halo0 <= 6 && g.psz >= 8) || (g.psz == 8 && (2 * halo0 + 1) * (2 * halo0 + 1) <= 448))) {
       // (... and the seven-round blocks of a first frame, 441 candidates: 2 x 2 targets per block need 128 registers
       // instead of 168 + spills, two 8-wavefront workgroups per CU instead of three of 4: match 0.947 -> 0.828)
@@ -504,7 +535,7 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
     }
   }
   tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
-  tl.block = getenv("NLK_MATCH_NOBLOCK") ? 0 : (getenv("NLK_MATCH_BLOCK") ? 1 : !small_grid);
+  tl.block = nlk_set(c->sw.match_noblock) ? 0 : (nlk_set(c->sw.match_block) ? 1 : !small_grid);
   // LDS holds the halo of the dominant window; its row stride = window width
   // (mod 32): candidate i of a window then sits on bank i mod 32, so a
   // wavefront's 64 candidate reads are conflict free
@@ -582,7 +613,7 @@ static int commit_rows(nlk_ctx* c, hipStream_t stream, const uint64_t* marks, ui
     HIPCHK(c, hipMemsetAsync(active + (size_t)first * ngx, 1, (size_t)nrows * ngx, stream));
     return NLK_OK;
   }
-  if (R == 1 && ngx <= 2048 && !getenv("NLK_COMMIT_WAVE") && !getenv("NLK_COMMIT_LDS") && !getenv("NLK_COMMIT_BAND")) {
+  if (R == 1 && ngx <= 2048 && !nlk_set(c->sw.commit_wave) && !nlk_set(c->sw.commit_lds) && !nlk_set(c->sw.commit_band)) {
     // reach 1: one grid row per step on bit planes (k_commit.h); the arrays cover the whole grid, padded to
     // whole batches (a band's last batch may run into the rows of the next): 4 planes + decisions + row states
     const int rows_pad = (total + NLK_CR_BATCH - 1) / NLK_CR_BATCH * NLK_CR_BATCH + 3 * NLK_CR_BATCH;
@@ -599,10 +630,10 @@ static int commit_rows(nlk_ctx* c, hipStream_t stream, const uint64_t* marks, ui
     HIPCHK(c, hipGetLastError());
     return NLK_OK;
   }
-  if (R <= 3 && (first != 0 || !getenv("NLK_COMMIT_LDS"))) {
+  if (R <= 3 && (first != 0 || !nlk_set(c->sw.commit_lds))) {
     // one lane per grid row, up to 1024 rows per launch; more rows in pieces that start with the
     // previous piece's last R rows as context (k_commit.h)
-    int band = getenv("NLK_COMMIT_BAND") ? atoi(getenv("NLK_COMMIT_BAND")) : 1024;
+    int band = nlk_or(c->sw.commit_band, 1024);
     band = band < 2 * R + 2 ? 2 * R + 2 : (band > 1024 ? 1024 : band);
     auto pre = R == 1 ? k_marks_skew<1> : (R == 2 ? k_marks_skew<2> : k_marks_skew<3>);
     auto kern = R == 1 ? k_mask_commit_wave<1> : (R == 2 ? k_mask_commit_wave<2> : k_mask_commit_wave<3>);
@@ -669,11 +700,10 @@ static int group_rows(nlk_ctx* c, hipStream_t stream, float* acc, const uint8_t*
 // gains. Kept as an option (and as the exactness test of banding); profiling always runs one band.
 static int frame_bands(const nlk_ctx* c, const NlkGeom& g) {
   if (c->profiling || c->deterministic || g.R == 0 || g.R > 3) return 1;  // (deterministic mode: one slab set, one sum order)
-  const char* e = getenv("NLK_BANDS");
   // default: one band where the replay is the row formulation (reach 1: 2 % of a frame); four where it
   // is the diagonal one (reach 2 / 3, i.e. spatial frames of small patches: 0.28 ms of a 2.6 ms first
   // frame at 1080p on one compute unit - with four bands 2.36 ms, with two 2.41, profiles/README.md round 3)
-  int nb = e ? atoi(e) : (g.R >= 2 ? 4 : 1);
+  int nb = nlk_or(c->sw.bands, g.R >= 2 ? 4 : 1);
   nb = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
   while (nb > 1 && g.ngy / nb < 4 * (g.R + 1) + 8) --nb;  // (thin bands: nothing to gain)
   return nb;
@@ -803,7 +833,7 @@ int nlk_dev_frame_normalize(nlk_ctx* c, float* out, const float* acc, const floa
   NLK_USE_DEVICE(c);
   mark(c, 5);
   hipLaunchKernelGGL(k_normalize, dim3(2048), dim3(256), 0, c->stream, out, acc, cur, w, h, ch,
-                     y0, y1, c->acc_residual ? 1 : 0);
+                     y0, y1);
   HIPCHK(c, hipGetLastError());
   mark(c, 6);
   return NLK_OK;
@@ -870,7 +900,7 @@ static int frame_host(nlk_ctx* c, float* out_h, const float* cur_h, const float*
   const int ngy = (psz >= 2 && h >= psz) ? (h - psz) / step + 1 : 0;
   const int wall = smoother ? P->search_sz_t : max(P->search_sz_x, P->search_sz_t);  // reach of any window / group
   const int R = ((smoother || prev_h) ? P->search_sz_t : P->search_sz_x) / max(step, 1);
-  int nb = getenv("NLK_HOST_BANDS") ? atoi(getenv("NLK_HOST_BANDS")) : 5;  // (1080p: 2 bands 2.43 ms, 3 2.30, 4 2.25, 5 2.20, 6 2.22; one upload + call + download 2.9)
+  int nb = nlk_or(c->sw.host_bands, 5);  // (1080p: 2 bands 2.43 ms, 3 2.30, 4 2.25, 5 2.20, 6 2.22; one upload + call + download 2.9)
   nb = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
   while (nb > 1 && ngy / nb < 4 * (R + 1) + 8) --nb;
   if (nb < 2 || R > 3 || c->deterministic || c->profiling || psz > 16 || w < psz || h < psz) {
@@ -906,7 +936,7 @@ static int frame_host(nlk_ctx* c, float* out_h, const float* cur_h, const float*
   hipStream_t st[2] = {c->stream, c->aux_stream};
   int up0 = 0, v0 = 0, nz0 = 0, nz[9];
   nz[0] = 0;
-  const bool trace = getenv("NLK_HOST_TRACE") != nullptr;
+  const bool trace = nlk_set(c->sw.host_trace);
   struct timespec ts0, ts1, ts2;
   if (trace) clock_gettime(CLOCK_MONOTONIC, &ts0);
   hipStream_t const home = c->stream;
@@ -940,7 +970,7 @@ static int frame_host(nlk_ctx* c, float* out_h, const float* cur_h, const float*
     if (nz[b + 1] > nz0) {
       if (b > 0) HIPCHK(c, hipStreamWaitEvent(s, c->band_ev[E_GRP][b - 1], 0));
       hipLaunchKernelGGL(k_normalize, dim3(1024), dim3(256), 0, s, d_out, (const float*)acc, (const float*)d_cur, w, h,
-                         ch, nz0, nz[b + 1], c->acc_residual ? 1 : 0);
+                         ch, nz0, nz[b + 1]);
       HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(c->band_ev[E_DONE][b], s));
@@ -983,7 +1013,13 @@ int nlk_host_tables(int psz, float* basis, float* window, float* basis12_regs) {
   if (psz < 2 || psz > 64) return fail(nullptr, NLK_EINVAL, "patch size %d", psz);
   if (basis) host_basis(basis, psz);
   if (window) host_window(window, psz);
-  if (basis12_regs) memcpy(basis12_regs, nlk_basis12_table(), sizeof(float) * 144);  // compile-time table of k_group12.h
+  if (basis12_regs)  // the matrix the 12-point flow graph of k_dct12.h (what k_groupp<12> runs) applies: graph(e_j) = column j
+    for (int j = 0; j < 12; ++j) {
+      float e[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      e[j] = 1.f;
+      nlk_host12::nlk_dct12_fast_fwd(e);
+      for (int k = 0; k < 12; ++k) basis12_regs[k * 12 + j] = e[k];
+    }
   return NLK_OK;
 }
 

@@ -32,8 +32,37 @@ struct NlkRecView {
   uint32_t* wide = nullptr;      // [0] = queue length, then the queued targets (k_bm_wide)
 };
 
+// The NLK_* environment switches (variants for comparison tests and experiments, none
+// needed in production) are read ONCE, when a context is created - not on every frame call - and again only
+// on request (nlk_ctx_reload_switches: the tests change the environment under a live context).
+// A field holds atoi(value), or NLK_UNSET when the variable does not exist.
+#define NLK_UNSET (-2147483647 - 1)
+#define NLK_SWITCH_LIST(X)                                                                                   \
+  X(deterministic, "NLK_DETERMINISTIC") X(generic_group, "NLK_GENERIC_GROUP") X(group_packed, "NLK_GROUP_PACKED") \
+  X(group_dpp, "NLK_GROUP_DPP") X(generic_match, "NLK_GENERIC_MATCH") X(mtx, "NLK_MTX") X(mty, "NLK_MTY")    \
+  X(match_wg8, "NLK_MATCH_WG8") X(match_bx2, "NLK_MATCH_BX2") X(match_block, "NLK_MATCH_BLOCK")              \
+  X(match_noblock, "NLK_MATCH_NOBLOCK") X(commit_wave, "NLK_COMMIT_WAVE") X(commit_lds, "NLK_COMMIT_LDS")    \
+  X(commit_band, "NLK_COMMIT_BAND") X(bands, "NLK_BANDS") X(host_bands, "NLK_HOST_BANDS")                    \
+  X(host_trace, "NLK_HOST_TRACE") X(gtx, "NLK_GTX") X(gty, "NLK_GTY") X(g8_tail, "NLK_G8_TAIL")              \
+  X(g8_single, "NLK_G8_SINGLE") X(tv_wg_pixels, "NLK_TV_WG_PIXELS") X(tv_unblocked, "NLK_TV_UNBLOCKED")      \
+  X(tv_batch, "NLK_TV_BATCH") X(tv_mid, "NLK_TV_MID") X(tv_shape, "NLK_TV_SHAPE") X(tv_deep, "NLK_TV_DEEP")  \
+  X(tv_inline, "NLK_TV_INLINE") X(tv_look, "NLK_TV_LOOK") X(tv_look2, "NLK_TV_LOOK2") X(tv_trace, "NLK_TV_TRACE")
+struct NlkSwitches {
+#define NLK_X(field, name) int field = NLK_UNSET;
+  NLK_SWITCH_LIST(NLK_X)
+#undef NLK_X
+  void load() {
+#define NLK_X(field, name) { const char* e_ = getenv(name); field = e_ ? atoi(e_) : NLK_UNSET; }
+    NLK_SWITCH_LIST(NLK_X)
+#undef NLK_X
+  }
+};
+static inline bool nlk_set(int v) { return v != NLK_UNSET; }                 // the variable exists (any value)
+static inline int nlk_or(int v, int dflt) { return v != NLK_UNSET ? v : dflt; }  // its value, or the default
+
 struct nlk_ctx {
   int device = 0;
+  NlkSwitches sw;                    // NLK_* switches as of nlk_ctx_create / nlk_ctx_reload_switches
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipStream_t aux_stream = nullptr;  // second stream of the banded frame pipeline (run_frame)
@@ -51,7 +80,6 @@ struct nlk_ctx {
   hipStream_t up_stream = nullptr, dn_stream = nullptr;
   hipEvent_t band_ev[5][8] = {};  // per band: uploaded / laid out / mask rows replayed / groups filtered / rows normalised
   bool deterministic = false;     // nlk_ctx_set_deterministic / NLK_DETERMINISTIC=1
-  bool acc_residual = false;      // what the last group launch left in the accumulator's value planes (k_normalize)
   NlkTvMail* tv_host = nullptr;   // pinned: the solver state, posted by the kernels (k_tvl1.h)
   unsigned tv_seq = 0;
   int tabs_psz = 0;
@@ -109,11 +137,9 @@ static inline int reserve(nlk_ctx* c, NlkBuf& b, size_t bytes) {
 }
 
 // ---- launchers (one translation unit each; all enqueue on c->stream)
-// tu_group8.hip / tu_group12.hip: the register / matrix-core group kernels for 8x8 and 12x12 patches
+// tu_group8.hip: the matrix-core / register group kernels for 8x8 patches
 int nlk_launch_group8(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur, const float* prev,
                       float* acc, const uint8_t* active);
-int nlk_launch_group12(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur, const float* prev,
-                       float* acc, const uint8_t* active);
 // tu_groupp_{a,b,c}.hip: the packed-lane kernel (k_groupp.h), patch sizes 2..8 / 9..12 / 13..16, any channel count
 int nlk_launch_groupp_a(nlk_ctx* c, const NlkGeom& g, const float* img, const float* cur, const float* prev,
                         float* acc, const uint8_t* active);
@@ -131,5 +157,3 @@ int nlk_launch_group_any(nlk_ctx* c, const NlkGeom& g, const float* img, const f
 int nlk_launch_match(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds, const float* img,
                      int maxm, bool wide);
 int nlk_launch_match_generic(nlk_ctx* c, const NlkGeom& g, const float* img);
-// the 12x12 table of k_group12.h (nlk_host_tables)
-const float* nlk_basis12_table(void);

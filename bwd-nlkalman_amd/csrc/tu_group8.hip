@@ -13,7 +13,7 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
   constexpr int PSZ = 8;
   // psz 8 runs its DCTs on the matrix cores (k_group8m.h); NLK_GROUP_DPP selects the
   // register/DPP kernel (k_group8.h) for comparison
-  const bool mfma = !getenv("NLK_GROUP_DPP");
+  const bool mfma = !nlk_set(c->sw.group_dpp);
   if (c->deterministic && !mfma)
     return fail(c, NLK_EUNSUP, "deterministic aggregation is not available in the NLK_GROUP_DPP variant");
   // Deterministic mode runs a temporal frame's far-reaching (spatial-branch) groups in a second
@@ -37,10 +37,10 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
     // tile would leave LDS room for ~1 wavefront per SIMD: 2 x 1 at most then.
     auto tiles_with = [&](int t) { return (size_t)((g.ngx + t - 1) / t) * g.ngy; };
     const int tgx_fill = tiles_with(3) >= 30000 ? 3 : (tiles_with(2) >= 2560 ? 2 : 1);
-    tl.tgx = getenv("NLK_GTX") ? atoi(getenv("NLK_GTX")) : min(tgx_fill, tl.wmax > 6 ? 2 : 4);
+    tl.tgx = nlk_or(c->sw.gtx, min(tgx_fill, tl.wmax > 6 ? 2 : 4));
     // (round 3, matrix-core kernel with the leaner pass A, 1080p: 3 x 2 targets 0.957 ms, 2 x 2 0.970, 3 x 1 0.976,
     // 4 x 2 1.10, 2 x 3 1.05, 3 x 3 1.04 - two target rows share the tile's vertical halo: 40 % fewer flushed bytes)
-    tl.tgy = getenv("NLK_GTY") ? atoi(getenv("NLK_GTY")) : ((mfma && tgx_fill == 3 && tl.wmax <= 6) ? 2 : 1);
+    tl.tgy = nlk_or(c->sw.gty, (mfma && tgx_fill == 3 && tl.wmax <= 6) ? 2 : 1);
     tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
     tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
     tl.nty_full = tl.nty;
@@ -50,8 +50,8 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
       // wavefront slots): the chip would drain for most of a tile's time. So the last ~0.8 slots' worth of tiles
       // hold one grid row (3 x 1), and the last ~0.9 slots' worth of targets go one per workgroup
       // (1080p: 16 + 6 of 269 grid rows; group 0.950 -> 0.900 ms. NLK_G8_TAIL / NLK_G8_SINGLE override)
-      int tail = tl.tgy == 1 ? 0 : (getenv("NLK_G8_TAIL") ? atoi(getenv("NLK_G8_TAIL")) : (2560 + tl.ntx / 2) / tl.ntx);
-      int single = getenv("NLK_G8_SINGLE") ? atoi(getenv("NLK_G8_SINGLE")) : (2880 + g.ngx / 2) / g.ngx;
+      int tail = tl.tgy == 1 ? 0 : nlk_or(c->sw.g8_tail, (2560 + tl.ntx / 2) / tl.ntx);
+      int single = nlk_or(c->sw.g8_single, (2880 + g.ngx / 2) / g.ngx);
       single = max(0, min(single, g.ngy / 8));
       tail = max(0, min(tail, g.ngy / 4));
       tl.single = single;
@@ -72,7 +72,10 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
       tl.rwp = rw_max | 1;
       tl.plane = tl.rwp * tl.rh_max;
     }
-    const size_t lds = sizeof(float) * ((size_t)(CH + 1) * tl.plane + (mfma ? (CH + 2) * NLK_G8_SST : 0));
+#ifndef NLK_G8_LDS_PAD
+#define NLK_G8_LDS_PAD 0  // (experiments: bytes of unused LDS per workgroup, to cut the occupancy)
+#endif
+    const size_t lds = sizeof(float) * ((size_t)(CH + 1) * tl.plane + (mfma ? (CH + 2) * NLK_G8_SST : 0)) + NLK_G8_LDS_PAD;
     if (lds > 160 * 1024) return fail(c, NLK_EUNSUP, "aggregation tile needs %zu bytes of LDS", lds);
     const size_t ntiles = (size_t)tl.ntx * tl.nty;
     if (c->deterministic) {
@@ -80,7 +83,7 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
       if (pass == 0) {
         size_t need = ntiles * (CH + 1) * tl.plane, nflag = ntiles;
         if (split) {
-          const int tgx2 = getenv("NLK_GTX") ? atoi(getenv("NLK_GTX")) : min(tgx_fill, g.wsz_x > 6 ? 2 : 4);
+          const int tgx2 = nlk_or(c->sw.gtx, min(tgx_fill, g.wsz_x > 6 ? 2 : 4));
           const int rw2 = (tgx2 - 1) * g.step + 2 * g.wsz_x + g.psz, rh2 = (tl.tgy - 1) * g.step + 2 * g.wsz_x + g.psz;
           const size_t nt2 = (size_t)((g.ngx + tgx2 - 1) / tgx2) * tl.nty;
           need += nt2 * (CH + 1) * ((size_t)(rw2 + 32) * rh2 + 32);
@@ -103,7 +106,6 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
                  const uint32_t*, const NlkTarget*, const uint32_t*, const uint8_t*, const float*,
                  const float*, float*);
     kern = mfma ? k_group8m<CH, SMO> : k_group8<CH, SMO>;
-    if (mfma && SMO) c->acc_residual = true;  // (k_group8m's smoother accumulates member - image, k_normalize adds the image)
     HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
     const float* basis = (const float*)c->tabs.p;

@@ -72,7 +72,7 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
   L.part = part; L.st = st; L.mail = c->tv_host;
   L.nx = nx; L.ny = ny; L.nwarps = P.nwarps;
   L.l_t = P.lambda * P.theta; L.theta = P.theta; L.taut = P.tau / P.theta; L.eps2 = P.epsilon * P.epsilon;
-  size_t wg_max = getenv("NLK_TV_WG_PIXELS") ? (size_t)atoi(getenv("NLK_TV_WG_PIXELS")) : NLK_TV_WG_PIXELS;
+  size_t wg_max = nlk_set(c->sw.tv_wg_pixels) ? (size_t)c->sw.tv_wg_pixels : NLK_TV_WG_PIXELS;
   if (wg_max > NLK_TV_WG_PIXELS) wg_max = NLK_TV_WG_PIXELS;  // (the kernel's LDS arrays)
   if (n <= wg_max) {  // the whole level inside one workgroup
     hipLaunchKernelGGL(k_tv_level_wg, dim3(1), dim3(NLK_TV_THREADS), 0, c->stream, L);
@@ -82,8 +82,8 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
   const dim3 grid((nx + 63) / 64, (ny + 3) / 4);
   const int nparts = grid.x * grid.y;
   hipLaunchKernelGGL(k_tv_init, grid, dim3(256), 0, c->stream, L);
-  if (getenv("NLK_TV_UNBLOCKED")) {  // one launch per half iteration (kept for comparison)
-    const int batch = getenv("NLK_TV_BATCH") ? atoi(getenv("NLK_TV_BATCH")) : 12;
+  if (nlk_set(c->sw.tv_unblocked)) {  // one launch per half iteration (kept for comparison)
+    const int batch = nlk_or(c->sw.tv_batch, 12);
     for (int wi = 0; wi < P.nwarps; ++wi) {
       hipLaunchKernelGGL(k_tv_warp, grid, dim3(256), 0, c->stream, L);
       int launched = 0;
@@ -114,11 +114,11 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
   // tile load or store while the other computes
   const int tx = (nx + NLK_TV_TW - 1) / NLK_TV_TW;
   const int nb16 = tx * ((ny + NLK_TV_TH - 1) / NLK_TV_TH), nb32 = tx * ((ny + NLK_TV_TH2 - 1) / NLK_TV_TH2);
-  int shape = nb32 >= 512 ? 2 : nb16 >= 400 ? (getenv("NLK_TV_MID") ? atoi(getenv("NLK_TV_MID")) : 1) : 0;
-  if (getenv("NLK_TV_SHAPE")) shape = atoi(getenv("NLK_TV_SHAPE"));
+  int shape = nb32 >= 512 ? 2 : nb16 >= 400 ? nlk_or(c->sw.tv_mid, 1) : 0;
+  shape = nlk_or(c->sw.tv_shape, shape);
   const int th = shape >= 1 && shape <= 2 ? NLK_TV_TH2 : NLK_TV_TH;
   const int bt = shape >= 2 ? NLK_TV_BT2 : NLK_TV_BT;
-  const bool deep = shape == 0 && getenv("NLK_TV_DEEP");  // (8 iterations per launch: measured slower, kept for experiments)
+  const bool deep = shape == 0 && nlk_set(c->sw.tv_deep);  // (8 iterations per launch: measured slower, kept for experiments)
   const int K = deep ? NLK_TV_K2 : NLK_TV_K;
   const auto block_kernel = shape == 0 ? (deep ? k_tv_block<NLK_TV_TH, NLK_TV_BT, NLK_TV_K2> : k_tv_block<NLK_TV_TH, NLK_TV_BT, NLK_TV_K>)
                           : shape == 1 ? k_tv_block<NLK_TV_TH2, NLK_TV_BT, NLK_TV_K>
@@ -127,10 +127,10 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
   const auto decide_kernel = deep ? k_tv_decide<NLK_TV_K2> : k_tv_decide<NLK_TV_K>;
   const dim3 bgrid((nx + NLK_TV_TW - 1) / NLK_TV_TW, (ny + th - 1) / th);
   const int nblocks = bgrid.x * bgrid.y;
-  const bool inline_judge = nblocks <= (getenv("NLK_TV_INLINE") ? atoi(getenv("NLK_TV_INLINE")) : 600);
+  const bool inline_judge = nblocks <= nlk_or(c->sw.tv_inline, 600);
   // batches between two looks at the state (a warp needs 5 to 50 iterations, mostly under 16)
-  const int look = deep ? (getenv("NLK_TV_LOOK2") ? atoi(getenv("NLK_TV_LOOK2")) : 2)
-                        : (getenv("NLK_TV_LOOK") ? atoi(getenv("NLK_TV_LOOK")) : 4);
+  const int look = deep ? nlk_or(c->sw.tv_look2, 2)
+                        : nlk_or(c->sw.tv_look, 4);
   for (int wi = 0; wi < P.nwarps; ++wi) {
     hipLaunchKernelGGL(k_tv_warp, grid, dim3(256), 0, c->stream, L);
     NlkTvBuf cur = {L.u1, L.u2, L.p11, L.p12, L.p21, L.p22};
@@ -166,7 +166,7 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
     const bool final_is_start = (used % 2) == 0;
     const NlkTvBuf fin = final_is_start ? (cur_is_a ? A : B) : (cur_is_a ? B : A);
     L.u1 = fin.u1; L.u2 = fin.u2; L.p11 = fin.p11; L.p12 = fin.p12; L.p21 = fin.p21; L.p22 = fin.p22;
-    if (getenv("NLK_TV_TRACE"))
+    if (nlk_set(c->sw.tv_trace))
       fprintf(stderr, "tvl1 %dx%d warp %d: %d iterations, %d batches launched\n", nx, ny, wi, c->tv_host->st.last, batches);
   }
   if (L.u1 != u1) {  // the level's flow belongs in the pyramid arrays

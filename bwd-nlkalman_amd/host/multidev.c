@@ -20,6 +20,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "nlk_hip.h"
 #include "nlkalman.h"
@@ -56,9 +57,15 @@ static pthread_barrier_t g_bar;
 static unsigned g_gen = 0;
 static int g_quit = 0, g_reach[NLK_MAXDEV];
 
+/* Fatal error on any device thread. exit() would run md_atexit, which joins the workers - but they are
+ * parked in pthread_barrier_wait (nothing releases a barrier short of every party arriving), the caller
+ * may BE a worker (joining itself), and two threads in exit() at once is undefined. So: message, flush,
+ * and leave without the exit handlers; the driver reclaims the device memory of a dead process. */
 static void md_die(const char *what, nlk_ctx *c) {
   fprintf(stderr, "nlkalman (hip, %d devices): %s: %s\n", g_ndev, what, nlk_last_error(c));
-  exit(1);
+  fflush(stderr);
+  fflush(stdout);
+  _exit(1);
 }
 
 static void md_atexit(void) {

@@ -74,6 +74,10 @@ int nlk_ctx_get_timings(nlk_ctx *ctx, struct nlk_timings *t);
  * this switch every workgroup writes its tile to a slab of its own and a gather kernel sums the
  * slabs in a fixed order. Also set by NLK_DETERMINISTIC=1 in the environment at context creation. */
 int nlk_ctx_set_deterministic(nlk_ctx *ctx, int on);
+/* The NLK_* environment switches (variants for comparison tests and experiments: DESIGN.md appendix) are read
+ * once, by nlk_ctx_create. This reads them again - for `ctx`, or for every live context of the process when
+ * ctx is NULL (the test suite changes the environment under live contexts). */
+int nlk_ctx_reload_switches(nlk_ctx *ctx);
 /* run the context's work on an externally owned hipStream_t; NULL is the legacy
  * default stream itself (what torch.cuda.current_stream() is unless changed), so
  * that the kernels order with the caller's own work on that stream.
@@ -217,8 +221,9 @@ int nlk_ctx_read_records(nlk_ctx *ctx, int *ngrid, int *kmax, int *gmax,
 
 /* the host-side tables a frame call uploads (tests only; no device needed): the orthonormal
  * DCT-II basis [psz][psz] that stands for FFTW REDFT10/REDFT01 x the reference's scaling
- * (src/nlkalman.c:204-220, 281-298, 335-353), the aggregation window (:365-419), and the
- * compile-time 12x12 basis of the register kernel. Any pointer may be NULL. */
+ * (src/nlkalman.c:204-220, 281-298, 335-353), the aggregation window (:365-419), and the 12 x 12 matrix the
+ * 12-point flow graph of the packed-lane kernel applies (csrc/k_dct12.h, evaluated on the host: column j =
+ * graph(e_j)). Any pointer may be NULL. */
 int nlk_host_tables(int psz, float *basis, float *window, float *basis12_regs);
 
 #ifdef __cplusplus

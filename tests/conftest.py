@@ -48,3 +48,26 @@ def ctx(built):
     c = built.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(autouse=True)
+def _switches_follow_the_environment(monkeypatch):
+    """The product reads its NLK_* switches once per context (include/nlk_hip.h:
+    nlk_ctx_reload_switches); the tests change them under the session's live contexts. So: every
+    test starts from the current environment, and monkeypatch.setenv / delenv re-read it."""
+    def reload_():
+        pkg_ = sys.modules.get("bwd-nlkalman_amd")   # (not imported yet: no context exists either)
+        if pkg_ is not None:
+            pkg_.reload_switches()
+    reload_()
+    setenv, delenv = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv_(name, value, *a, **k):
+        setenv(name, value, *a, **k)
+        reload_()
+
+    def delenv_(name, *a, **k):
+        delenv(name, *a, **k)
+        reload_()
+    monkeypatch.setenv, monkeypatch.delenv = setenv_, delenv_
+    yield

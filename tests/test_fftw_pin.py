@@ -4,8 +4,8 @@ The reference's only un-vendored arithmetic is FFTW's single-precision REDFT10 /
 (src/nlkalman.c:204-220, 278, 355), absent from this image. tests/golden/fftw_single_dct.npz
 holds FFTW-computed single-precision transforms of x = 0..n-1 (provenance:
 tests/golden/make_fftw_pin.py). Here the oracle's basis (oracle/nlk_oracle.c:nlko_dct_basis), the
-basis the product uploads to the device (csrc/nlk_hip.hip:host_basis) and the compile-time table
-of the 12x12 register kernel (csrc/k_group12.h:NLK_C12) are each driven with that input, the
+basis the product uploads to the device (csrc/nlk_hip.hip:host_basis) and the matrix that the 12-point
+flow graph of the packed-lane kernel applies (csrc/k_dct12.h) are each driven with that input, the
 reference's scaling (src/nlkalman.c:281-298 forward, :335-353 inverse) is undone / replayed in
 float, and the result must agree with FFTW's to <= 2 ulp of the vector's largest element.
 
@@ -74,15 +74,16 @@ def test_oracle_basis_against_fftw(O, gold):
 
 def test_device_tables_against_fftw_and_oracle(built, O, gold):
     """What upload_tables() sends to the GPU, bit for bit the oracle's basis and window, and
-    FFTW-pinned the same way; likewise the 12x12 register kernel's compile-time table."""
+    FFTW-pinned the same way; likewise the matrix that the 12-point flow graph of the packed-lane kernel
+    applies (csrc/k_dct12.h, compiled for the host by nlk_host_tables)."""
     for n in SIZES:
         b, w, b12 = built.host_tables(n)
         assert np.array_equal(b, O.dct_basis(n)), f"device basis {n} != oracle basis"
         assert np.array_equal(w, O.window(n)), f"device window {n} != oracle window"
         _check_basis(b, n, gold, "device basis")
-    # the table is written with 9 significant digits: same floats as the computed basis
-    assert np.abs(b12 - O.dct_basis(12)).max() <= np.spacing(F(0.41))
-    _check_basis(b12, 12, gold, "NLK_C12")
+    # (a flow graph rounds differently from the table: entries within 2 ulp of the largest one)
+    assert np.abs(b12 - O.dct_basis(12)).max() <= 2 * np.spacing(F(0.41))
+    _check_basis(b12, 12, gold, "k_dct12.h flow graph")
 
 
 def test_oracle_2d_transform_replays_reference_scaling_of_fftw(O, gold):
