@@ -31,6 +31,9 @@ HIP_SYMBOLS = [
     "nlk_tvl1_default_params", "nlk_tvl1_scales", "nlk_dev_tvl1_flow", "nlk_dev_gray",
     "nlk_dev_occlusion_mask", "nlk_dev_image_dct", "nlk_dev_copy_block", "nlk_host_tables", "nlk_ctx_set_deterministic", "nlk_dev_zero", "nlk_dev_add", "nlk_dev_copy_peer",
     "nlk_filter_frame_host", "nlk_smooth_frame_host", "nlk_dev_strip_match_part", "nlk_ctx_reload_switches",
+    "nlk_strips_create", "nlk_strips_destroy", "nlk_strips_last_error", "nlk_rccl_unique_id", "nlk_strips_rccl_init",
+    "nlk_strips_transport", "nlk_strips_load", "nlk_strips_set_options", "nlk_strips_step", "nlk_strips_sync",
+    "nlk_strips_own_rows", "nlk_strips_ctx", "nlk_strips_geometry", "nlk_strips_stats",
 ]
 API_SYMBOLS = [
     "rgb2opp", "opp2rgb", "warp_bicubic", "nlkalman_default_params",
@@ -136,6 +139,24 @@ def hip():
         L.nlk_host_tables.argtypes = [i, vp, vp, vp]
         L.nlk_ctx_set_deterministic.argtypes = [vp, i]
         L.nlk_ctx_reload_switches.argtypes = [vp]
+        L.nlk_strips_create.argtypes = [C.POINTER(vp), i, C.POINTER(i), i, i, i, i, i, C.c_float, C.POINTER(Params), i, i]
+        L.nlk_strips_destroy.argtypes = [vp]
+        L.nlk_strips_destroy.restype = None
+        L.nlk_strips_last_error.argtypes = [vp]
+        L.nlk_strips_last_error.restype = C.c_char_p
+        L.nlk_rccl_unique_id.argtypes = [vp]
+        L.nlk_strips_rccl_init.argtypes = [vp, vp]
+        L.nlk_strips_transport.argtypes = [vp]
+        L.nlk_strips_transport.restype = C.c_char_p
+        L.nlk_strips_load.argtypes = [vp, i, vp, vp]
+        L.nlk_strips_set_options.argtypes = [vp, i, i, i]
+        L.nlk_strips_step.argtypes = [vp]
+        L.nlk_strips_sync.argtypes = [vp]
+        L.nlk_strips_own_rows.argtypes = [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+        L.nlk_strips_ctx.argtypes = [vp, i]
+        L.nlk_strips_ctx.restype = vp
+        L.nlk_strips_geometry.argtypes = [vp, i, C.POINTER(i)]
+        L.nlk_strips_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(i)]
         _hip = L
     return _hip
 
@@ -416,3 +437,86 @@ class Context:
             rec["np0"].ctypes.data, rec["nagg"].ctypes.data, rec["topk"].ctypes.data,
             rec["gcoords"].ctypes.data))
         return rec
+
+
+class Strips:
+    """nlk_strips wrapper (include/nlk_hip.h, csrc/strips.hip): one frame over `world` row strips, driven from C.
+    devices = one HIP device index (this process holds rank `rank0` of the world: RCCL between the processes,
+    call rccl_init) or `world` of them (every strip in this process, device copies; indices may repeat)."""
+    PHASES = ("exchange_prev", "match", "marks", "commit", "group", "exchange_acc", "normalize")
+
+    def __init__(self, devices, rank0, world, w, h, ch, sigma, params, smoother=False, have_prev=True):
+        self.L = hip()
+        self.h = C.c_void_p()
+        self.w, self.hh, self.ch, self.world, self.nlocal = w, h, ch, world, len(devices)
+        dev = (C.c_int * len(devices))(*devices)
+        rc = self.L.nlk_strips_create(C.byref(self.h), len(devices), dev, rank0, world, w, h, ch, float(sigma),
+                                      C.byref(params), int(smoother), int(have_prev))
+        if rc:
+            raise NlkError(f"rc={rc}: " + self.L.nlk_last_error(None).decode())
+
+    def _chk(self, rc):
+        if rc:
+            raise NlkError(f"rc={rc}: " + self.L.nlk_strips_last_error(self.h).decode() + " / " + self.L.nlk_last_error(None).decode())
+
+    def close(self):
+        if self.h:
+            self.L.nlk_strips_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        rc = hip().nlk_rccl_unique_id(buf)
+        if rc:
+            raise NlkError(hip().nlk_last_error(None).decode())
+        return bytes(buf.raw)
+
+    def rccl_init(self, id128):
+        self._chk(self.L.nlk_strips_rccl_init(self.h, C.c_char_p(id128)))
+
+    def transport(self):
+        return self.L.nlk_strips_transport(self.h).decode()
+
+    def load(self, local, d_cur_full, d_prev_full):
+        self._chk(self.L.nlk_strips_load(self.h, local, d_cur_full, d_prev_full))
+
+    def set_options(self, overlap=True, timing=False, graph=False):
+        self._chk(self.L.nlk_strips_set_options(self.h, int(overlap), int(timing), int(graph)))
+
+    def step(self):
+        self._chk(self.L.nlk_strips_step(self.h))
+
+    def sync(self):
+        self._chk(self.L.nlk_strips_sync(self.h))
+
+    def geometry(self, local=0):
+        g = (C.c_int * 6)()
+        self._chk(self.L.nlk_strips_geometry(self.h, local, g))
+        return dict(zip(("gy0", "gy1", "Y0", "Y1", "own0", "own1"), g))
+
+    def own_rows(self, local=0):
+        """(y0, y1, device pointer to the output rows, pointer to the whole-grid decisions)"""
+        y0, y1, rows, act = C.c_int(), C.c_int(), C.c_void_p(), C.c_void_p()
+        self._chk(self.L.nlk_strips_own_rows(self.h, local, C.byref(y0), C.byref(y1), C.byref(rows), None, C.byref(act)))
+        return y0.value, y1.value, rows.value, act.value
+
+    def download_rows(self, local=0):
+        y0, y1, rows, _ = self.own_rows(local)
+        out = np.empty((y1 - y0, self.w, self.ch), np.float32)
+        c = self.L.nlk_strips_ctx(self.h, local)
+        rc = self.L.nlk_d2h(c, out.ctypes.data, rows, out.nbytes)
+        if rc:
+            raise NlkError(self.L.nlk_last_error(c).decode())
+        return y0, y1, out
+
+    def stats(self):
+        ph, us, g = (C.c_float * 7)(), C.c_float(), C.c_int()
+        self._chk(self.L.nlk_strips_stats(self.h, ph, C.byref(us), C.byref(g)))
+        return dict(zip(self.PHASES, (round(float(v), 4) for v in ph))), float(us.value), bool(g.value)

@@ -55,7 +55,7 @@ static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER, g_peer_mu = PTHREAD_MUT
 static pthread_cond_t g_cv = PTHREAD_COND_INITIALIZER;
 static pthread_barrier_t g_bar;
 static unsigned g_gen = 0;
-static int g_quit = 0, g_reach[NLK_MAXDEV];
+static int g_quit = 0, g_reach[NLK_MAXDEV], g_fail_at = -1;
 
 /* Fatal error on any device thread. exit() would run md_atexit, which joins the workers - but they are
  * parked in pthread_barrier_wait (nothing releases a barrier short of every party arriving), the caller
@@ -135,6 +135,7 @@ int nlk_multi_devices(void) {
     }
   }
   g_ndev = n;
+  if (getenv("NLK_MULTI_TEST_FAIL")) g_fail_at = atoi(getenv("NLK_MULTI_TEST_FAIL"));
   pthread_barrier_init(&g_bar, NULL, (unsigned)n);
   for (int d = 1; d < n; ++d)
     if (pthread_create(&g_thr[d], NULL, worker, (void *)(long)d)) md_die("cannot start a device thread", NULL);
@@ -199,6 +200,10 @@ static void run_device(int d) {
       md_die("strip_match", D->c);
   }
   pthread_barrier_wait(&g_bar);
+  /* (test hook, tests/test_gpu_parity.py: NLK_MULTI_TEST_FAIL=<d> makes device d report an error here - with
+   * the other device threads on their way to the next barrier - to show that the process leaves with status 1
+   * instead of hanging) */
+  if (g_fail_at == d) md_die("injected failure (NLK_MULTI_TEST_FAIL)", D->c);
   /* 2b: the mark words of every strip, device to device; whole-grid replay on each; 3: the strip's groups */
   if (on) {
     for (int e = 0; e < n; ++e)

@@ -219,6 +219,49 @@ int nlk_ctx_read_records(nlk_ctx *ctx, int *ngrid, int *kmax, int *gmax,
                          unsigned char *active, int *nsel, int *np0, int *nagg,
                          unsigned int *topk, unsigned int *gcoords);
 
+/* ---- One frame over several GPUs, driven from C (csrc/strips.hip; the reference's analogue is
+ * the static row split of its OpenMP loop, src/nlkalman.c:586). The patch-grid rows are cut into `world` strips.
+ * Per step and strip: the previous frame's halo rows come from the neighbours, the strip is matched (its interior
+ * while the halo travels), every strip's 64-bit mark words go to every strip, the raster-order mask is replayed
+ * over the WHOLE grid (so the output is the serial order's for any number of strips), the strip's groups are
+ * filtered, the accumulator rows written outside the own rows go to their owner, the own rows are normalised.
+ * Transports: RCCL over xGMI with one strip per process (grouped ncclSend / ncclRecv between neighbours, the mark
+ * words as one group of ncclBroadcast; librccl is dlopen'ed - the copy the process already holds, if any), or
+ * device copies with every strip in one process (`devices` may repeat an index: the whole decomposition on one
+ * GPU). A step only enqueues work; nlk_strips_sync waits for it. */
+typedef struct nlk_strips nlk_strips;
+/* `nlocal` strips of this process = ranks rank0 .. rank0 + nlocal - 1 of `world` (nlocal == 1, or == world),
+ * strip i on HIP device devices[i]. have_prev = 0: first-frame calls (no previous frame, nothing to exchange). */
+int nlk_strips_create(nlk_strips **out, int nlocal, const int *devices, int rank0, int world, int w, int h,
+                      int ch, float sigma, const struct nlkalman_params *prms, int smoother, int have_prev);
+void nlk_strips_destroy(nlk_strips *s);
+const char *nlk_strips_last_error(const nlk_strips *s);
+/* one strip per process: a 128-byte communicator id made on one rank (carried to the others by whatever
+ * started them), then the communicator of the world on every rank */
+int nlk_rccl_unique_id(void *id128);
+int nlk_strips_rccl_init(nlk_strips *s, const void *id128);
+const char *nlk_strips_transport(const nlk_strips *s);
+/* rows of full device-resident HWC frames (on that strip's device) into local strip `local`: cur with its halo,
+ * prev with its OWN rows only (may be NULL) */
+int nlk_strips_load(nlk_strips *s, int local, const float *cur_full, const float *prev_full);
+/* overlap: match the interior rows while the halo travels (default 1); timing: per-phase device times, one
+ * synchronisation per step (diagnosis); graph: capture the step into a HIP graph once and replay it (one strip
+ * per process; falls back to plain launches by itself if the capture is refused) */
+int nlk_strips_set_options(nlk_strips *s, int overlap, int timing, int graph);
+int nlk_strips_step(nlk_strips *s);
+int nlk_strips_sync(nlk_strips *s);
+/* own rows [*y0, *y1) of the output of local strip `local` (device pointer, valid until the next step); the
+ * whole-grid mark words and decisions it used (any pointer may be NULL) */
+int nlk_strips_own_rows(nlk_strips *s, int local, int *y0, int *y1, float **rows, void **marks_full,
+                        unsigned char **active_full);
+nlk_ctx *nlk_strips_ctx(nlk_strips *s, int local);
+/* gy0, gy1 (patch-grid rows), Y0, Y1 (pixel rows held), own0, own1 (pixel rows owned) of a local strip */
+int nlk_strips_geometry(nlk_strips *s, int local, int geom[6]);
+/* phase_ms[7]: mean device time of [previous-frame halo, matching, mark words, mask replay, groups, accumulator
+ * halos, normalisation] on local strip 0 over the steps made with timing on; *issue_us: mean host time a step
+ * took to enqueue since the last call; *graph: the steps are replayed from a captured graph */
+int nlk_strips_stats(nlk_strips *s, float phase_ms[7], float *issue_us, int *graph);
+
 /* the host-side tables a frame call uploads (tests only; no device needed): the orthonormal
  * DCT-II basis [psz][psz] that stands for FFTW REDFT10/REDFT01 x the reference's scaling
  * (src/nlkalman.c:204-220, 281-298, 335-353), the aggregation window (:365-419), and the 12 x 12 matrix the

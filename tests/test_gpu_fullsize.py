@@ -7,7 +7,9 @@ Reference: src/nlkalman.c:597-600 (mask skip), :630-639 (spatial window), :930-9
 Tolerances as in test_gpu_parity.py: integer records exact, pixels max-abs 2e-3 / RMSE 2e-4 on the
 0..255 scale. The only excused samples are pixels whose summed weight lies within 1e-4 relative of
 the reference's absolute `aggr > 1e-6` threshold (src/nlkalman.c:939-942), where the order of a
-float sum decides the side; they are counted and bounded."""
+float sum decides the side; they are counted and bounded (cases.excuse_threshold_pixels). Two runs of the
+product against each other excuse exactly the pixels that flipped at that threshold, recognised by their
+signature (cases.excuse_flips). No other flip allowance anywhere in this file."""
 import numpy as np
 import pytest
 
@@ -17,10 +19,14 @@ from test_gpu_parity import _check_records, _dev_frame, _to_o
 pytestmark = pytest.mark.gpu
 
 
-def _excuse_threshold_pixels(g, r, tr, what, most):
-    edge = np.abs(tr["aggr"] - 1e-6) <= 1e-10
-    assert int(edge.sum()) <= most, f"{what}: {int(edge.sum())} pixels sit at the aggregation threshold"
-    return np.where(edge[..., None], r, g), int(edge.sum())
+_excuse_threshold_pixels = cases.excuse_threshold_pixels
+
+
+def _same(a, b, cur, what, most=64):
+    """Two product runs on the same inputs: equal up to the order of the accumulator's adds; the only samples
+    excused are threshold flips, recognised by their signature (cases.excuse_flips)."""
+    a, _ = cases.excuse_flips(a, b, cur, what, most)
+    cases.assert_close(a, b, what)
 
 
 def test_spatial_first_frame_full_size_1080p(ctx, built, O, synth):
@@ -107,8 +113,10 @@ def test_group_tiles_of_mixed_sizes_1080p(ctx, built, O, synth, monkeypatch, tai
     monkeypatch.setenv("NLK_G8_SINGLE", single)
     e1, _ = _dev_frame(ctx, False, o1, d0, None, sigma, p1)
     es, _ = _dev_frame(ctx, True, d0, d1, None, sigma, ps)
-    cases.assert_close(e1, d1, f"tail {tail} single {single}: flt1 temporal", flips=40)
-    cases.assert_close(es, ds, f"tail {tail} single {single}: smo1", flips=40)
+    e1, _ = cases.excuse_flips(e1, d1, o1, f"tail {tail} single {single}: flt1 temporal", 64)
+    es, _ = cases.excuse_flips(es, ds, d0, f"tail {tail} single {single}: smo1", 64)
+    cases.assert_close(e1, d1, f"tail {tail} single {single}: flt1 temporal")
+    cases.assert_close(es, ds, f"tail {tail} single {single}: smo1")
 
 
 def test_single_target_tail_on_single_row_tiles_720p(ctx, built, O, synth, monkeypatch):
@@ -133,8 +141,10 @@ def test_single_target_tail_on_single_row_tiles_720p(ctx, built, O, synth, monke
         monkeypatch.setenv("NLK_G8_SINGLE", single)
         e0, _ = _dev_frame(ctx, False, o0, None, None, sigma, p1)
         e1, _ = _dev_frame(ctx, False, o1, d0, None, sigma, p1)
-        cases.assert_close(e0, d0, f"single {single}: spatial", flips=40)
-        cases.assert_close(e1, d1, f"single {single}: temporal", flips=40)
+        e0, _ = cases.excuse_flips(e0, d0, o0, f"single {single}: spatial", 64)
+        e1, _ = cases.excuse_flips(e1, d1, o1, f"single {single}: temporal", 64)
+        cases.assert_close(e0, d0, f"single {single}: spatial")
+        cases.assert_close(e1, d1, f"single {single}: temporal")
 
 
 def test_4k_patch8_temporal_against_serial_oracle(ctx, built, O, synth):
@@ -151,7 +161,7 @@ def test_4k_patch8_temporal_against_serial_oracle(ctx, built, O, synth):
     r, tr = O.filter_frame(o1, prev, None, sigma, _to_o(O, p), trace=True)
     _check_records(rec, tr, "4K psz 8")
     g, _ = _excuse_threshold_pixels(g, r, tr, "4K psz 8", 256)
-    cases.assert_close(g, r, "4K psz 8", flips=160)
+    cases.assert_close(g, r, "4K psz 8")
     assert abs(synth.psnr(built.opp2rgb(g), c1) - synth.psnr(O.opp2rgb(r), c1)) <= 0.02
 
 
@@ -177,11 +187,11 @@ def test_host_pointer_calls_pipeline_the_frame_in_row_bands(ctx, built, synth, m
         if bands:
             monkeypatch.setenv("NLK_HOST_BANDS", bands)
         tag = f"host bands {bands or 'default'}"
-        cases.assert_close(built.filter_frame(o0, None, None, sigma, p1), d0, f"{tag}: flt1 spatial", flips=40)
-        cases.assert_close(built.filter_frame(o1, hole, None, sigma, p1), d1, f"{tag}: flt1 temporal", flips=40)
+        _same(built.filter_frame(o0, None, None, sigma, p1), d0, o0, f"{tag}: flt1 spatial")
+        _same(built.filter_frame(o1, hole, None, sigma, p1), d1, o1, f"{tag}: flt1 temporal")
         if bands is None:
-            cases.assert_close(built.filter_frame(o1, hole, d1, sigma, p2), d2, f"{tag}: flt2", flips=40)
-            cases.assert_close(built.smooth_frame(d0, d2, None, sigma, ps), ds, f"{tag}: smo1", flips=40)
+            _same(built.filter_frame(o1, hole, d1, sigma, p2), d2, o1, f"{tag}: flt2")
+            _same(built.smooth_frame(d0, d2, None, sigma, ps), ds, d0, f"{tag}: smo1")
 
 
 @pytest.mark.parametrize("seed", [3, 4, 5])
@@ -206,6 +216,121 @@ def test_host_pointer_pipeline_on_odd_sizes(ctx, built, synth, seed):
     d1, _ = _dev_frame(ctx, False, o1, hole, None, sigma, p1)
     d2, _ = _dev_frame(ctx, False, o1, hole, d1, sigma, p2)
     what = f"host pipeline {w}x{h}x{ch} psz {psz}"
-    cases.assert_close(built.filter_frame(o0, None, None, sigma, p1), d0, what + ": flt1 spatial", flips=40)
-    cases.assert_close(built.filter_frame(o1, hole, None, sigma, p1), d1, what + ": flt1 temporal", flips=40)
-    cases.assert_close(built.filter_frame(o1, hole, d1, sigma, p2), d2, what + ": flt2", flips=40)
+    _same(built.filter_frame(o0, None, None, sigma, p1), d0, o0, what + ": flt1 spatial")
+    _same(built.filter_frame(o1, hole, None, sigma, p1), d1, o1, what + ": flt1 temporal")
+    _same(built.filter_frame(o1, hole, d1, sigma, p2), d2, o1, what + ": flt2")
+
+
+def _warped_previous(O, prev, seed):
+    """What every real temporal call receives (src/nlkalman.c:29-88): the previous output through
+    warp_bicubic - here with zero flow and a blob-shaped occlusion mask - i.e. a NaN ring (1 px left /
+    top, 2 px right / bottom) and NaN holes."""
+    h, w, _ = prev.shape
+    out = O.warp_bicubic(prev, np.zeros((h, w, 2), np.float32), cases.blob_mask(w, h, seed))
+    nan = np.isnan(out[..., 0])
+    assert nan[0].all() and nan[:, 0].all() and nan[-2:].all() and nan[:, -2:].all()     # the ring
+    assert 0.01 < nan[4:-4, 4:-4].mean() < 0.2                                            # the holes
+    return out
+
+
+def test_nan_ring_and_holes_full_size_1080p_against_serial_oracle(ctx, built, O, synth):
+    """SURVEY.md §8(d)'s second variant at full size: FLT1 temporal, FLT2 temporal and SMO1
+    at 1920x1080 RGB with a previous frame that went through warp_bicubic (NaN ring + occlusion holes): targets
+    without a valid previous patch take the spatial branch with the wide window and do not mark the mask
+    (src/nlkalman.c:605-609, 637, 931), candidates without one leave the Kalman statistics (:725-732), the
+    smoother passes such targets through (:1795-1804). Serial oracle: records exact, pixels 2e-3, threshold
+    pixels excused and counted, nothing else."""
+    w, h, ch, sigma = 1920, 1080, 3, 20.0
+    n0, n1, c1 = synth.noisy_pair(w, h, ch, sigma, 1)
+    o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+    p1, p2, ps = (built.default_params(sigma, m) for m in (built.FLT1, built.FLT2, built.SMO1))
+    f0, _ = _dev_frame(ctx, False, o0, None, None, sigma, p1)
+    wp = _warped_previous(O, f0, 11)
+    # FLT1 temporal
+    r1, tr1 = O.filter_frame(o1, wp, None, sigma, _to_o(O, p1), trace=True)
+    g1, rec1 = _dev_frame(ctx, False, o1, wp, None, sigma, p1)
+    a = tr1["active"].astype(bool)
+    assert (tr1["np0"][a] == 0).mean() > 0.005          # spatial-branch targets inside a temporal frame
+    _check_records(rec1, tr1, "flt1 temporal, NaN ring + holes, 1080p")
+    g1, n1e = _excuse_threshold_pixels(g1, r1, tr1, "flt1 temporal, NaN ring + holes, 1080p", 64)
+    cases.assert_close(g1, r1, "flt1 temporal, NaN ring + holes, 1080p")
+    # FLT2 temporal on the oracle's basic estimate
+    r2, tr2 = O.filter_frame(o1, wp, r1, sigma, _to_o(O, p2), trace=True)
+    g2, rec2 = _dev_frame(ctx, False, o1, wp, r1, sigma, p2)
+    _check_records(rec2, tr2, "flt2 temporal, NaN ring + holes, 1080p")
+    g2, _ = _excuse_threshold_pixels(g2, r2, tr2, "flt2 temporal, NaN ring + holes, 1080p", 64)
+    cases.assert_close(g2, r2, "flt2 temporal, NaN ring + holes, 1080p")
+    # SMO1 of frame 0 against frame 1's result warped back (another ring, other holes)
+    ws = _warped_previous(O, r2, 12)
+    rs, trs = O.smooth_frame(f0, ws, None, sigma, _to_o(O, ps), trace=True)
+    gs, recs = _dev_frame(ctx, True, f0, ws, None, sigma, ps)
+    a = trs["active"].astype(bool)
+    assert (trs["np0"][a] == 0).mean() > 0.005          # pass-through targets
+    _check_records(recs, trs, "smo1, NaN ring + holes, 1080p")
+    gs, _ = _excuse_threshold_pixels(gs, rs, trs, "smo1, NaN ring + holes, 1080p", 64)
+    cases.assert_close(gs, rs, "smo1, NaN ring + holes, 1080p")
+    assert abs(synth.psnr(built.opp2rgb(g2), c1) - synth.psnr(O.opp2rgb(r2), c1)) <= 0.02
+
+
+def test_free_running_chain_1080p_psnr(ctx, built, O, synth):
+    """BASELINE.json configs[4] end to end, nobody fed by the other: the product runs
+    flt1 -> flt2 on frame 0, warps, flt1 -> flt2 on frame 1, warps back, smo1 of frame 0 - every stage on its
+    OWN previous outputs - and so does the serial oracle. What BASELINE.json's "PSNR delta vs ref" is about:
+    |dPSNR| <= 0.02 dB against the clean frames on the flt2 and smo1 outputs (and the outputs themselves stay
+    within a small RMSE of each other: the chains may differ where a near-tied k-NN rank flipped upstream)."""
+    w, h, ch, sigma = 1920, 1080, 3, 20.0
+    n0, n1, c1 = synth.noisy_pair(w, h, ch, sigma, 1)
+    c0 = synth.clean_frame(w, h, ch, 0)
+    flow, occ = cases.flow_and_occ(w, h)
+
+    def chain(B, frame):
+        p1, p2, ps = (B.default_params(sigma, m) for m in (0, 1, 2))
+        o0, o1 = B.rgb2opp(n0), B.rgb2opp(n1)
+        f1_0 = frame(False, o0, None, None, p1)
+        f2_0 = frame(False, o0, None, f1_0, p2)
+        f1_1 = frame(False, o1, B.warp_bicubic(f1_0, flow, occ), None, p1)
+        f2_1 = frame(False, o1, B.warp_bicubic(f2_0, flow, occ), f1_1, p2)
+        s1_0 = frame(True, f2_0, B.warp_bicubic(f2_1, -flow, occ), None, ps)
+        return B.opp2rgb(f2_1), B.opp2rgb(s1_0)
+    g21, gs0 = chain(built, lambda smo, cur, prev, basic, p: _dev_frame(ctx, smo, cur, prev, basic, sigma, p)[0])
+    r21, rs0 = chain(O, lambda smo, cur, prev, basic, p: (O.smooth_frame if smo else O.filter_frame)(cur, prev, basic, sigma, p))
+    for name, g, r, clean in (("flt2 of frame 1", g21, r21, c1), ("smo1 of frame 0", gs0, rs0, c0)):
+        dp = synth.psnr(g, clean) - synth.psnr(r, clean)
+        rm = float(np.sqrt(np.mean((g - r) ** 2)))
+        print(f"free-running 1080p chain, {name}: dPSNR {dp:+.5f} dB, RMSE vs oracle chain {rm:.2e}")
+        assert abs(dp) <= 0.02, f"{name}: dPSNR {dp}"
+        assert rm <= 0.05, f"{name}: RMSE {rm}"
+        assert synth.psnr(g, clean) > synth.psnr(n1 if clean is c1 else n0, clean) + 8
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103])
+def test_random_parameters_full_size_soak(ctx, built, O, seed):
+    """tools/soak_fullsize.py as a test: two random configurations per seed at ~1080p -
+    random size, 1 or 3 channels, FLT1 / FLT2 / SMO1, random radius, list lengths and group sizes, a previous
+    frame with NaN holes - against the serial oracle: records exact, pixels 2e-3, threshold pixels excused."""
+    rng = np.random.default_rng(seed)
+    for it in range(2):
+        w, h = int(rng.integers(1700, 2300)), int(rng.integers(950, 1300))
+        ch = int(rng.choice([1, 3]))
+        smoother = rng.random() < 0.3
+        mode = built.SMO1 if smoother else int(rng.choice([built.FLT1, built.FLT2]))
+        sigma = float(rng.choice([10.0, 20.0, 40.0]))
+        over = dict(patch_sz=8, search_sz_t=int(rng.integers(2, 7)), npatches_t=int(rng.integers(2, 64)),
+                    npatches_tagg=int(rng.integers(1, 45)), npatches_x=int(rng.integers(2, 64)))
+        p = built.default_params(sigma, mode, **over)
+        base = np.add.outer(np.linspace(20, 220, h), np.linspace(0, 30, w))[..., None] * np.ones(ch)
+        cur = (base + rng.normal(0, sigma, base.shape)).astype(np.float32)
+        prev = (base + rng.normal(0, sigma / 3, base.shape)).astype(np.float32)
+        for _ in range(6):
+            y0, x0 = int(rng.integers(0, h - 40)), int(rng.integers(0, w - 60))
+            prev[y0:y0 + int(rng.integers(1, 40)), x0:x0 + int(rng.integers(1, 60))] = np.nan
+        basic = (base + rng.normal(0, 3, base.shape)).astype(np.float32) if mode == built.FLT2 else None
+        fn = O.smooth_frame if smoother else O.filter_frame
+        r, tr = fn(cur, prev, basic, sigma, _to_o(O, p), trace=True)
+        g, rec = _dev_frame(ctx, smoother, cur, prev, basic, sigma, p)
+        what = f"soak seed {seed} #{it}: {w}x{h}x{ch} mode {mode} {over} sigma {sigma}"
+        _check_records(rec, tr, what)
+        # (a ramp image with identical patches everywhere puts many pixels on the same summed weight: the bound
+        # is a sanity guard - 0.05 % of the frame -, what it excuses is still only |aggr - 1e-6| <= 1e-10)
+        g, _ = _excuse_threshold_pixels(g, r, tr, what, 1024)
+        cases.assert_close(g, r, what)

@@ -472,7 +472,8 @@ def test_full_size_1080p_against_oracle(ctx, built, O, synth):
     assert np.array_equal(tr["active"].astype(bool), rec["active"].astype(bool))
     assert 0.2 < 1 - tr["active"].mean() < 0.4          # ~30 % of targets are skipped
     _check_records(rec, tr, "1080p")
-    cases.assert_close(g, r, "1080p", flips=40)
+    g, _ = cases.excuse_threshold_pixels(g, r, tr, "1080p", 64)
+    cases.assert_close(g, r, "1080p")
     dpsnr = synth.psnr(built.opp2rgb(g), c1) - synth.psnr(O.opp2rgb(r), c1)
     assert abs(dpsnr) <= 0.02
     # size-independent property: a DC offset on every input shifts the output by it
@@ -648,8 +649,9 @@ def test_4k_patch12_against_parallel_oracle(ctx, built, O, synth):
     prev, _ = _dev_frame(ctx, False, o0, None, None, sigma, p)
     g, rec = _dev_frame(ctx, False, o1, prev, None, sigma, p)
     assert rec["active"].all()
-    r = O.filter_frame(o1, prev, None, sigma, po, nthreads=min(O.max_threads(), 100))
-    cases.assert_close(g, r, "4K psz12", flips=160)
+    r, tr = O.filter_frame(o1, prev, None, sigma, po, nthreads=min(O.max_threads(), 100), trace=True)
+    g, _ = cases.excuse_threshold_pixels(g, r, tr, "4K psz12", 256)
+    cases.assert_close(g, r, "4K psz12")
     assert abs(synth.psnr(built.opp2rgb(g), c1) - synth.psnr(O.opp2rgb(r), c1)) <= 0.02
     assert synth.psnr(built.opp2rgb(g), c1) > synth.psnr(n1, c1) + 8
 
@@ -665,7 +667,8 @@ def test_smoother_full_size_1080p(ctx, built, O, synth):
     g, rec = _dev_frame(ctx, True, f0, f1, None, sigma, ps)
     r, tr = O.smooth_frame(f0, f1, None, sigma, _to_o(O, ps), trace=True)
     _check_records(rec, tr, "smo 1080p")
-    cases.assert_close(g, r, "smo 1080p", flips=40)
+    g, _ = cases.excuse_threshold_pixels(g, r, tr, "smo 1080p", 64)
+    cases.assert_close(g, r, "smo 1080p")
 
 
 @pytest.mark.parametrize("launch", ["auto", "large-grid", "large-grid-4x2"])
@@ -779,7 +782,8 @@ def test_second_iteration_full_size_1080p(ctx, built, O, synth):
     r, tr = O.filter_frame(o1, f0, f1, sigma, _to_o(O, p2), trace=True)
     assert tr["active"].all()                       # npatches_tagg = 1: the mask skip never fires
     _check_records(rec, tr, "flt2 1080p")
-    cases.assert_close(g, r, "flt2 1080p", flips=40)
+    g, _ = cases.excuse_threshold_pixels(g, r, tr, "flt2 1080p", 64)
+    cases.assert_close(g, r, "flt2 1080p")
     assert abs(synth.psnr(built.opp2rgb(g), c1) - synth.psnr(O.opp2rgb(r), c1)) <= 0.02
 
 
@@ -827,7 +831,43 @@ def test_config4_decomposition_1080p_eight_strips(ctx, built, synth):
     got = ctx.download(d_out, o1.shape)
     for x in (d_acc, d_cur, d_out, d_marks, d_active):
         ctx.free(x)
-    cases.assert_close(got, whole, "8 exact strips at 1080p vs whole frame", maxabs=5e-4, rmse=5e-5, flips=40)
+    got, _ = cases.excuse_flips(got, whole, o1, "8 exact strips at 1080p vs whole frame", 64)
+    cases.assert_close(got, whole, "8 exact strips at 1080p vs whole frame", maxabs=5e-4, rmse=5e-5)
+
+
+def test_accumulators_of_filter_and_smoother_interleaved(ctx, built, O, synth):
+    """The accumulate / normalise split of the C-ABI (include/nlk_hip.h): a planar accumulator holds ch weighted
+    sums and the weights, whatever kernel filled it - no state in the context says how to read it (ADVICE r3:
+    the smoother on the matrix cores used to leave (member - image) sums and a hidden flag for the normaliser).
+    A filter accumulate, then a smoother accumulate on the SAME context, then the two normalisations in that
+    order: each must equal its whole-frame call, and the oracle's."""
+    w, h, ch, sigma = 200, 136, 3, 20.0
+    n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, 23)
+    o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+    p1, ps = built.default_params(sigma, built.FLT1), built.default_params(sigma, built.SMO1)
+    f0, _ = _dev_frame(ctx, False, o0, None, None, sigma, p1)
+    f1, _ = _dev_frame(ctx, False, o1, f0, None, sigma, p1)
+    whole_f, _ = _dev_frame(ctx, False, o1, f0, None, sigma, p1)
+    whole_s, _ = _dev_frame(ctx, True, f0, f1, None, sigma, ps)
+    ngy = (h - 8) // 4 + 1
+    d_o1, d_f0, d_f1 = ctx.upload(o1), ctx.upload(f0), ctx.upload(f1)
+    acc_f = ctx.upload(np.zeros((ch + 1, h, w), np.float32))
+    acc_s = ctx.upload(np.zeros((ch + 1, h, w), np.float32))
+    out_f, out_s = ctx.alloc(o1.nbytes), ctx.alloc(o1.nbytes)
+    ctx.frame_accumulate(acc_f, d_o1, d_f0, None, w, h, ch, sigma, p1, 0, ngy)                  # filter
+    ctx.frame_accumulate(acc_s, d_f0, d_f1, None, w, h, ch, sigma, ps, 0, ngy, smoother=True)   # smoother, same ctx
+    ctx.frame_normalize(out_f, acc_f, d_o1, w, h, ch, 0, h)
+    ctx.frame_normalize(out_s, acc_s, d_f0, w, h, ch, 0, h)
+    got_f, got_s = ctx.download(out_f, o1.shape), ctx.download(out_s, o1.shape)
+    # the accumulator means what the header says: ch weighted sums of member pixels, then the weights
+    a = ctx.download(acc_s, (ch + 1, h, w))
+    ok = a[ch] > 1e-6
+    assert np.abs(np.moveaxis(a[:ch], 0, -1)[ok] / a[ch][ok][:, None] - got_s[ok]).max() <= 1e-3
+    for x in (d_o1, d_f0, d_f1, acc_f, acc_s, out_f, out_s):
+        ctx.free(x)
+    cases.assert_close(got_f, whole_f, "filter accumulate / normalise around a smoother accumulate", maxabs=5e-4, rmse=5e-5)
+    cases.assert_close(got_s, whole_s, "smoother accumulate / normalise after a filter accumulate", maxabs=5e-4, rmse=5e-5)
+    cases.assert_close(got_s, O.smooth_frame(f0, f1, None, sigma, _to_o(O, ps)), "smoother through the split API vs oracle")
 
 
 def test_local_mode_single_patch(ctx, built, O):
@@ -897,9 +937,13 @@ def test_deterministic_aggregation_is_bit_reproducible(built, O, synth, psz):
             # (default mode: float atomics in varying order; a pixel whose summed weight sits at the
             # reference's 1e-6 threshold can fall on either side of it from run to run: a few dozen
             # samples of the second iteration's single-member groups with the small patches)
-            cases.assert_close(x, z, f"psz {psz} {name}: deterministic vs default mode", flips=150)
+            cur = o0 if name == "flt1 spatial" else (x * 0 + a[0] if name == "smo1" else o1)   # (the pass-through image)
+            x, _ = cases.excuse_flips(x, z, cur, f"psz {psz} {name}: deterministic vs default mode", 150)
+            cases.assert_close(x, z, f"psz {psz} {name}: deterministic vs default mode")
         po = _to_o(O, p1)
-        cases.assert_close(a[0], O.filter_frame(o0, None, None, sigma, po), f"psz {psz}: deterministic vs oracle", flips=4)
+        r0, tr0 = O.filter_frame(o0, None, None, sigma, po, trace=True)
+        g0, _ = cases.excuse_threshold_pixels(a[0], r0, tr0, f"psz {psz}: deterministic vs oracle", 16)
+        cases.assert_close(g0, r0, f"psz {psz}: deterministic vs oracle")
     finally:
         det.close()
         dflt.close()
@@ -919,7 +963,8 @@ def test_deterministic_full_size_1080p_runs_are_identical(built, synth):
         b = _frame(det, (o1, prev, None), sigma, p)
         assert np.array_equal(a, b)
         d1 = _frame(dflt, (o1, prev, None), sigma, p)
-        cases.assert_close(a, d1, "deterministic vs atomics at 1080p", flips=40)
+        a, _ = cases.excuse_flips(a, d1, o1, "deterministic vs atomics at 1080p", 64)
+        cases.assert_close(a, d1, "deterministic vs atomics at 1080p")
     finally:
         det.close()
         dflt.close()
@@ -1019,7 +1064,7 @@ hole = ref.get("f0", f0).copy(); hole[100:130, 50:90] = np.nan
 f1 = pkg.filter_frame(o1, hole, None, sigma, p1)
 f2 = pkg.filter_frame(o1, hole, ref.get("f1", f1), sigma, p2)
 s0 = pkg.smooth_frame(ref.get("f0", f0), ref.get("f2", f2), None, sigma, p3)
-np.savez(sys.argv[2], f0=f0, f1=f1, f2=f2, s0=s0)
+np.savez(sys.argv[2], f0=f0, f1=f1, f2=f2, s0=s0, o0=o0, o1=o1)
 """
 
 
@@ -1048,8 +1093,33 @@ def test_c_api_split_over_devices(built, tmp_path, devices):
         assert r.returncode == 0, r.stderr[-2000:]
         with np.load(tmp_path / f"{tag}.npz") as z:
             outs[tag] = {k: z[k] for k in z.files}
-    for k in ("f0", "f1", "f2", "s0"):
-        cases.assert_close(outs["split"][k], outs["one"][k], f"NLK_DEVICES={devices}: {k}", maxabs=5e-4, rmse=5e-5, flips=8)
+    for k, cur in (("f0", "o0"), ("f1", "o1"), ("f2", "o1"), ("s0", "f0")):
+        got, _ = cases.excuse_flips(outs["split"][k], outs["one"][k], outs["one"][cur], f"NLK_DEVICES={devices}: {k}", 16)
+        cases.assert_close(got, outs["one"][k], f"NLK_DEVICES={devices}: {k}", maxabs=5e-4, rmse=5e-5)
+
+
+@pytest.mark.parametrize("who", ["0", "1"])
+def test_c_api_device_error_exits_instead_of_hanging(built, tmp_path, who):
+    """An error on any device thread of the NLK_DEVICES path (the caller's own = device 0, or a worker) must end
+    the process with status 1 like the reference's `exit(1)` (src/nlkalman.c:165-177) - not hang in exit
+    handlers that join threads parked at a barrier. NLK_MULTI_TEST_FAIL injects the error."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "fail.py"
+    script.write_text('''
+import importlib, sys
+sys.path.insert(0, sys.argv[1])
+pkg = importlib.import_module("bwd-nlkalman_amd")
+synth = importlib.import_module("bwd-nlkalman_amd.synth")
+n0, _, _ = synth.noisy_pair(320, 256, 3, 20.0, 3)
+pkg.filter_frame(pkg.rgb2opp(n0), None, None, 20.0, pkg.default_params(20.0, pkg.FLT1, search_sz_x=5))
+print("survived")
+''')
+    e = dict(os.environ, NLK_DEVICES="0,0", NLK_MULTI_TEST_FAIL=who)
+    r = subprocess.run([sys.executable, str(script), root], env=e, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1, (r.returncode, r.stderr[-1000:])
+    assert "injected failure" in r.stderr and "survived" not in r.stdout
 
 
 def test_c_api_device_list_falls_back_to_one_device(built, tmp_path):
@@ -1080,5 +1150,8 @@ np.save(sys.argv[2], pkg.filter_frame(pkg.rgb2opp(n0), None, None, 20.0, p))
         if tag == "list2":
             assert "not split" in r.stderr
         outs[tag] = np.load(out)
+    synth = importlib.import_module("bwd-nlkalman_amd.synth")
+    cur = built.rgb2opp(synth.noisy_pair(120, 96, 3, 20.0, 3)[0])
     for tag in ("list2", "list1"):
-        cases.assert_close(outs[tag], outs["one"], f"NLK_DEVICES fallback ({tag})", maxabs=5e-4, rmse=5e-5, flips=8)
+        got, _ = cases.excuse_flips(outs[tag], outs["one"], cur, f"NLK_DEVICES fallback ({tag})", 16)
+        cases.assert_close(got, outs["one"], f"NLK_DEVICES fallback ({tag})", maxabs=5e-4, rmse=5e-5)

@@ -72,16 +72,19 @@ def test_resident_sequence_equals_oracle_recursion(ctx, built, O, synth):
             fl = np.stack([u, v], -1)
             occ = O.tvl1_occlusion_mask(fl, th)
             w1, w2 = O.warp_bicubic(got1[t - 1], fl, occ), O.warp_bicubic(got2[t - 1], fl, occ)
-        cases.assert_close(got1[t], O.filter_frame(nz, w1, None, SIGMA, p1), f"flt1 frame {t}", flips=10)
-        cases.assert_close(got2[t], O.filter_frame(nz, w2, got1[t], SIGMA, p2), f"flt2 frame {t}", flips=10)
+        for name, got, (r, tr) in (("flt1", got1[t], O.filter_frame(nz, w1, None, SIGMA, p1, trace=True)),
+                                   ("flt2", got2[t], O.filter_frame(nz, w2, got1[t], SIGMA, p2, trace=True))):
+            g, _ = cases.excuse_threshold_pixels(got, r, tr, f"{name} frame {t}", 16)
+            cases.assert_close(g, r, f"{name} frame {t}")
     smo = [ctx.download(d, (H, W, CH)) for d in sf.smooth()]
     assert np.array_equal(smo[-1], got2[-1])
     for t in range(NF - 2, -1, -1):
         u, v = O.tvl1_flow(_lum(O.opp2rgb(got2[t])), _lum(O.opp2rgb(smo[t + 1])), lam=lam, fscale=fscale)
         fl = np.stack([u, v], -1)
         occ = O.tvl1_occlusion_mask(fl, th)
-        ref = O.smooth_frame(got2[t], O.warp_bicubic(smo[t + 1], fl, occ), None, SIGMA, ps)
-        cases.assert_close(smo[t], ref, f"smo1 frame {t}", flips=10)
+        ref, tr = O.smooth_frame(got2[t], O.warp_bicubic(smo[t + 1], fl, occ), None, SIGMA, ps, trace=True)
+        g, _ = cases.excuse_threshold_pixels(smo[t], ref, tr, f"smo1 frame {t}", 16)
+        cases.assert_close(g, ref, f"smo1 frame {t}")
     assert len(sf.flow_iterations) == 2 * (NF - 1) and min(sf.flow_iterations) > 0
     # free-running oracle chain: same quality
     r1, r2, rs = _oracle_chain(O, frames, lam, fscale, th)
