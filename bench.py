@@ -39,6 +39,13 @@ WORKLOADS = {
     # flow + occlusion mask + 2 warps + FLT1 + FLT2 (bwd-nlkalman_amd/sequence.py)
     "S1": (1920, 1080, 3, 20.0, 8, 1),
 }
+_JSON_FD = 1
+
+
+def emit(res):
+    os.write(_JSON_FD, (json.dumps(res) + "\n").encode())
+
+
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense f32 MFMA peak (= the f32 vector peak)
 
@@ -216,7 +223,7 @@ def bench_flow(args, pkg, synth, ctx, torch, dist, rank, world, dev):
         res["parity_crop_480x270"] = {
             "max_abs": round(float(max(np.abs(cf[..., 0] - cu).max(), np.abs(cf[..., 1] - cv).max())), 6),
             "bit_exact": bool(np.array_equal(cf[..., 0], cu) and np.array_equal(cf[..., 1], cv))}
-    print(json.dumps(res))
+    emit(res)
 
 
 def bench_sequence(args, pkg, synth, ctx, torch, rank, world, dev):
@@ -272,7 +279,7 @@ def bench_sequence(args, pkg, synth, ctx, torch, rank, world, dev):
                       "flow_iterations_last_frame": sf.flow_iterations[-1]},
            "psnr_flt2_db": round(float(synth.psnr(out, c1)), 4),
            "psnr_noisy_db": round(float(synth.psnr(n1, c1)), 4)}
-    print(json.dumps(res))
+    emit(res)
 
 
 def launch_ranks(n):
@@ -319,12 +326,25 @@ def main():
                          "normalise wall times per rank")
     ap.add_argument("--force-strips", action="store_true",
                     help="run the N > 1 strip machinery even at N = 1 (measures its fixed overhead)")
+    ap.add_argument("--strip-driver", choices=["c", "py"], default="c",
+                    help="row-strip runs: the step enqueued from C (csrc/strips.hip: RCCL called from C, one ctypes call "
+                         "per step - the default) or from Python (strips.py over torch.distributed)")
+    ap.add_argument("--strip-graph", action="store_true",
+                    help="C strip driver: capture the step into a HIP graph once and replay it")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` by itself: start the N ranks as CHILD processes before this
         # process makes any GPU call (it never does), forward rank 0's line, exit with their status
         raise SystemExit(launch_ranks(args.gpus))
+
+    # The ONE JSON line goes out through a private copy of stdout; whatever else this process writes to file
+    # descriptor 1 from here on - librccl prints a five-line version banner there when a communicator is made -
+    # goes to stderr instead.
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -384,6 +404,7 @@ def main():
     torch.cuda.synchronize()
     t_out = torch.empty_like(t_n1)
 
+    cs, c_driver_note = None, None
     if args.workload == "C5":
         if world != 1:
             raise SystemExit("workload C5 is single-GPU")
@@ -401,6 +422,38 @@ def main():
             ctx.filter_frame(t_out.data_ptr(), t_n1.data_ptr(), t_prev.data_ptr(), None,
                              w, h, ch, sigma, p)
     else:
+        if args.strip_driver == "c" and not one_gpu:
+            # the step enqueued from C: rank 0 makes the RCCL id, torch.distributed only carries it to the others.
+            # If the C driver cannot be set up on some rank (an error code, e.g. no usable librccl), EVERY rank
+            # falls back to the Python driver - agreed on by an all-reduce - and the line says so.
+            ident = [None]
+            if rank == 0:
+                try:
+                    ident = [pkg.Strips.unique_id()]
+                except Exception as e:                                       # noqa: BLE001
+                    c_driver_note = f"C strip driver not usable on rank 0: {e}"
+            if world > 1:
+                dist.broadcast_object_list(ident, src=0)                     # (every rank takes part, whatever happened)
+            try:
+                if ident[0] is None:
+                    raise RuntimeError("no RCCL id from rank 0")
+                cs = pkg.Strips([local], rank, world, w, h, ch, sigma, p)
+                cs.rccl_init(ident[0])
+                cs.set_options(overlap=True, timing=False, graph=args.strip_graph)
+                cs.load(0, t_n1.data_ptr(), t_prev.data_ptr())
+            except Exception as e:                                           # noqa: BLE001
+                c_driver_note = c_driver_note or f"C strip driver not usable on rank {rank}: {e}"
+                cs = None
+            if world > 1:
+                okt = torch.tensor([0 if cs is None else 1], dtype=torch.int32, device=dev)
+                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+                if int(okt.item()) == 0 and cs is not None:
+                    cs.close()
+                    cs, c_driver_note = None, "C strip driver not usable on another rank"
+        if cs is not None:
+            ctx = pkg.Context.from_handle(cs.L.nlk_strips_ctx(cs.h, 0))   # the strip's own context: its timings and records
+            one_step = cs.step
+    if cs is None and (world > 1 or args.force_strips) and args.workload != "C5":
         def accumulate(acc, cur, prev, oy, ngy_):
             ctx.frame_accumulate(acc.data_ptr(), cur.data_ptr(), prev.data_ptr(), None, w,
                                  cur.shape[0], ch, sigma, p, oy, ngy_)
@@ -442,6 +495,9 @@ def main():
     dt = time.perf_counter() - t0
     # Per-kernel times: a second, untimed loop of the same steps with HIP events around every kernel
     # on the context's stream (the timed loop above runs the same single-stream order, unprofiled).
+    if cs is not None:
+        _, issue_us, replayed = cs.stats()          # (of the timed loop)
+        cs.set_options(overlap=True, timing=False, graph=False)   # (a replayed graph carries no profiling events)
     ctx.set_profiling(True)
     for _ in range(args.steps):
         one_step()
@@ -452,7 +508,11 @@ def main():
     # transforms this rank's group kernel really ran (from its records): the roofline's flops
     import numpy as np
     rec = ctx.read_records()
-    if striped and args.workload != "C5":
+    if striped and args.workload != "C5" and cs is not None:
+        geo = cs.geometry(0)
+        _, _, _, act_ptr = cs.own_rows(0)
+        act = ctx.download(act_ptr, (ngx * ngy,), np.uint8)[geo["gy0"] * ngx:geo["gy1"] * ngx].astype(bool)
+    elif striped and args.workload != "C5":
         p_ = sf.p
         act = sf.active_full[p_["gy0"] * sf.ngx:p_["gy1"] * sf.ngx].cpu().numpy().astype(bool)
     else:
@@ -466,8 +526,22 @@ def main():
     nsel_a, np0_a, nagg_a = (rec[k_][act].astype(np.float64) for k_ in ("nsel", "np0", "nagg"))
     ntr_local = float((nsel_a * (1 + (np0_a > 0)) + nagg_a).sum())                     # patch transforms per channel
     nother_local = float((nsel_a * ch * psz * psz * 16 + ch * psz * psz * 68 + nagg_a * psz * psz * (ch + 1) * 2).sum())
-    phase_ms = None
-    if striped and args.phase_times and args.workload != "C5":
+    phase_ms, strip_info = None, None
+    if cs is not None:
+        strip_info = {"driver": "C (csrc/strips.hip), one call per step", "transport": cs.transport(),
+                      "enqueue_us_per_step": round(issue_us, 1), "hip_graph": replayed}
+        if args.phase_times:
+            cs.set_options(overlap=True, timing=True, graph=False)
+            for _ in range(args.steps):
+                one_step()
+            barrier()
+            phase_ms = cs.stats()[0]
+            cs.set_options(overlap=True, timing=False, graph=False)
+    elif striped and args.workload != "C5":
+        strip_info = {"driver": "Python (strips.py over torch.distributed)"}
+        if c_driver_note:
+            strip_info["note"] = c_driver_note
+    if cs is None and striped and args.phase_times and args.workload != "C5":
         sf.timers, sf.phase_s = True, {}
         for _ in range(args.steps):
             one_step()
@@ -486,13 +560,22 @@ def main():
             allp = [None] * world
             dist.all_gather_object(allp, phase_ms)
             phase_ms = allp
-        y0, y1, rows = sf.own_rows()
         full = torch.zeros_like(t_n1)
-        full[y0:y1] = rows
+        if cs is not None:
+            y0, y1, rows_ptr, _ = cs.own_rows(0)
+            ctx.d2d(full[y0:y1].data_ptr(), rows_ptr, (y1 - y0) * w * ch * 4)
+            ctx.sync()
+        else:
+            y0, y1, rows = sf.own_rows()
+            full[y0:y1] = rows
         dist.all_reduce(full)
         t_out = full
     else:
         ntr_total, nother_total = ntr_local, nother_local
+        if cs is not None:   # (--force-strips at N = 1: the one strip is the frame)
+            y0, y1, rows_ptr, _ = cs.own_rows(0)
+            ctx.d2d(t_out.data_ptr(), rows_ptr, (y1 - y0) * w * ch * 4)
+            ctx.sync()
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -549,6 +632,8 @@ def main():
                "kernels_ms_note": "second loop of the same steps with HIP events around every kernel on the "
                                   "context's stream; ms_per_step is the timed (unprofiled) loop",
                "roofline": roof}
+        if strip_info is not None:
+            res["strip_step"] = strip_info
         if phase_ms is not None:
             res["strip_phase_ms"] = phase_ms
         if one_gpu and world > 1:
@@ -588,7 +673,7 @@ def main():
             res["max_abs_vs_cpu"] = round(float(np.abs(out - ref).max()), 6)
             if cb is not None:
                 res["speedup_vs_cpu"] = round(value / cb["value"], 1)
-        print(json.dumps(res))
+        emit(res)
     if world > 1:
         dist.destroy_process_group()
 

@@ -291,10 +291,17 @@ class Context:
         if rc:
             raise NlkError(self.L.nlk_last_error(None).decode())
 
+    @classmethod
+    def from_handle(cls, handle):
+        """A view of a context somebody else owns (a strip's: nlk_strips_ctx); never destroyed from here."""
+        c = cls.__new__(cls)
+        c.L, c.h, c._borrowed = hip(), C.c_void_p(handle), True
+        return c
+
     def close(self):
-        if self.h:
+        if self.h and not getattr(self, "_borrowed", False):
             self.L.nlk_ctx_destroy(self.h)
-            self.h = C.c_void_p()
+        self.h = C.c_void_p()
 
     def __del__(self):
         try:

@@ -115,7 +115,7 @@ struct nlk_strips {
   std::vector<Strip> s;              // the local ones
   ncclComm_t comm = nullptr;
   bool rccl = false, overlap = true, have_prev = true, timing = false, want_graph = false, graph_failed = false;
-  int timed_steps = 0;
+  int timed_steps = 0, steps_done = 0;
   double phase_ms[PH_N] = {}, issue_us = 0;
   int issue_n = 0;
   char err[512] = "";
@@ -496,7 +496,10 @@ int nlk_strips_step(nlk_strips* S) {
   clock_gettime(CLOCK_MONOTONIC, &t0);
   int rc = NLK_OK;
   Strip& T0 = S->s[0];
-  const bool graphable = S->want_graph && !S->graph_failed && !S->timing && S->nlocal == 1;
+  // (the first steps size the contexts' scratch buffers and upload the tables - allocation and host copies, which
+  // a capture does not take: they run as plain launches)
+  const bool graphable = S->want_graph && !S->graph_failed && !S->timing && S->nlocal == 1 && S->steps_done >= 2;
+  S->steps_done++;
   if (graphable && T0.graph) {
     HIPCHK(T0.c, hipSetDevice(T0.device));
     HIPCHK(T0.c, hipGraphLaunch(T0.graph, T0.c->stream));

@@ -114,15 +114,18 @@ def excuse_threshold_pixels(g, r, tr, what, most):
     return np.where(edge[..., None], r, g), n
 
 
-def excuse_flips(a, b, cur, what, most):
+def excuse_flips(a, b, cur, what, most, tol=5e-4):
     """Two runs of the PRODUCT on the same inputs (different tilings / bands / strips) add the accumulator in
     different orders, so a pixel whose summed weight sits at the 1e-6 threshold may be normalised in one and
     passed through in the other. Such a pixel carries its signature: in exactly one of the two outputs it
-    equals the input `cur` bit for bit, in every channel. Those pixels - and no others - are excused, counted
-    and bounded; returns a with them taken from b, and their number."""
+    equals the input `cur` bit for bit, in every channel, and the two outputs differ by more than `tol` there
+    (a pixel that a smoother's pass-through patch dominates equals the input up to rounding in both). Those
+    pixels - and no others - are excused, counted and bounded; returns a with them taken from b, and their
+    number."""
     a, b, cur = np.asarray(a), np.asarray(b), np.asarray(cur)
     pa, pb = (a == cur).all(-1), (b == cur).all(-1)
-    flip = pa != pb
+    with np.errstate(invalid="ignore"):
+        flip = (pa != pb) & (np.nan_to_num(np.abs(a - b)).max(-1) > tol)
     n = int(flip.sum())
     assert n <= most, f"{what}: {n} pixels flipped at the aggregation threshold (at most {most} expected)"
     return np.where(flip[..., None], b, a), n
