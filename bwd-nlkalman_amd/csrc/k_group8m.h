@@ -93,16 +93,27 @@ __device__ __forceinline__ void nlk_fold(const float (&R)[16], float (&F)[4][4])
                "+v"(F[1][2]), "+v"(F[1][3]), "+v"(F[2][0]), "+v"(F[2][1]), "+v"(F[2][2]), "+v"(F[2][3]),          \
                "+v"(F[3][0]), "+v"(F[3][1]), "+v"(F[3][2]), "+v"(F[3][3]), "+v"(o))
 
-// C_q += X^T D_q^T (patches along the rows) or D_q X (swapped: coefficients along the rows)
+// One quadrant's 16 x 16 product: C += X D (the data x(s = 0..3) as the A operand: its rows are the lanes' slots)
+// or, SWAP, C += D X (the data as the B operand: its columns are the lanes' slots). Exact f32: the f32 MFMA is an
+// fmaf chain. (Round 4 tried the f16 matrix cores at f32 accuracy instead - every operand split in two f16 halves,
+// x = x1 + x2, d = d1 + d2, two v_mfma_f32_16x16x32_f16 with operands [x1 | x1] / [x2 | x2] against [d1 | d2] for the
+// four f32 MFMAs, products exact in f32, round-trip error 4e-4 against 1.5e-4: parity green, but the ~16 vector
+// instructions per quadrant that split the operands cost more than the 96 matrix-core cycles they save:
+// group 0.866 ms against 0.832, profiles/README.md round 4.)
+typedef nlk_f4 nlk_basis_op;   // d(s = 0..3) of a quadrant
 template <bool SWAP>
-__device__ __forceinline__ void nlk_mfma_fwd(const float (&F)[4][4], const float (&dA)[4][4],
-                                             nlk_f4 (&C)[4]) {
+__device__ __forceinline__ nlk_f4 nlk_mfma_q(const float (&x)[4], const nlk_basis_op& d, nlk_f4 C) {
 #pragma unroll
   for (int s = 0; s < 4; ++s)
+    C = SWAP ? __builtin_amdgcn_mfma_f32_16x16x4f32(d[s], x[s], C, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x4f32(x[s], d[s], C, 0, 0, 0);
+  return C;
+}
+
+// C_q += X^T D_q^T (patches along the rows) or D_q X (swapped: coefficients along the rows)
+template <bool SWAP>
+__device__ __forceinline__ void nlk_mfma_fwd(const float (&F)[4][4], const nlk_basis_op (&dA)[4], nlk_f4 (&C)[4]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      C[q] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x4f32(dA[q][s], F[q][s], C[q], 0, 0, 0)
-                  : __builtin_amdgcn_mfma_f32_16x16x4f32(F[q][s], dA[q][s], C[q], 0, 0, 0);
+  for (int q = 0; q < 4; ++q) C[q] = nlk_mfma_q<SWAP>(F[q], dA[q], C[q]);
 }
 
 // sum over the 64 lanes, in every lane, without LDS: two butterfly steps inside the quads and two mirror steps
@@ -204,15 +215,19 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   const int lo = lane & 15, g4 = lane >> 4;
   // D_q as the forward operand (dA: D_q[coef lo][pixel 4*g4+s]) and as the inverse
   // operand (dI: D_q[coef 4*g4+s][pixel lo]); q = 2*qr + qc
-  float dA[4][4], dI[4][4];
+  nlk_basis_op dA[4], dI[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < 4; ++q) {
+    const int qr = q >> 1, qc = q & 1;
+    float a[4], b[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int qr = q >> 1, qc = q & 1;
-      dA[q][s] = basis[(2 * (lo >> 2) + qr) * 8 + g4] * basis[(2 * (lo & 3) + qc) * 8 + s];
-      dI[q][s] = basis[(2 * g4 + qr) * 8 + (lo >> 2)] * basis[(2 * s + qc) * 8 + (lo & 3)];
+      a[s] = basis[(2 * (lo >> 2) + qr) * 8 + g4] * basis[(2 * (lo & 3) + qc) * 8 + s];
+      b[s] = basis[(2 * g4 + qr) * 8 + (lo >> 2)] * basis[(2 * s + qc) * 8 + (lo & 3)];
     }
+    dA[q] = nlk_f4{a[0], a[1], a[2], a[3]};
+    dI[q] = nlk_f4{b[0], b[1], b[2], b[3]};
+  }
   // aggregation role: folded pixel lo = (pi, pj) of plane g4 -> 4 pixels of the patch
   const int pi = lo >> 2, pj = lo & 3;
   const bool agg_on = g4 <= CH;
@@ -558,10 +573,10 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
 #pragma unroll
       for (int q = 0; q < 4; ++q) Z[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          Z[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(Y[q][s], dI[q][s], Z[q], 0, 0, 0);
+      for (int q = 0; q < 4; ++q) {
+        const float y[4] = {Y[q][0], Y[q][1], Y[q][2], Y[q][3]};
+        Z[q] = nlk_mfma_q<false>(y, dI[q], Z[q]);
+      }
       // register m of Z = member n0+m, plane g4, folded pixel lo
       const uint32_t in4 = (uint32_t)((n0 < 64 ? inside[0] >> n0 : inside[1] >> (n0 - 64)) & 0xfull);
       if (in4 == 0xfu && n0 + 4 <= nagg) {

@@ -90,6 +90,26 @@ def test_default_bench_line():
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert abs(d["psnr_delta_db"]) <= 0.02       # BASELINE.json's quality bar, on the bench frame itself
     assert d["value"] > 30 * cb["value"]          # north_star: >= 30x the CPU path on the same box
+    # beside the resident call: the first frame of a sequence and the host-pointer API - never `value`
+    assert d["first_frame_ms"] > d["ms_per_step"] and d["api_wall_ms"] > d["ms_per_step"]
+    assert 0 < ro["valu"]["frac"] < 1
+
+
+@pytest.mark.gpu
+def test_strip_step_from_c_at_one_gpu():
+    """--force-strips: the N > 1 step (enqueued from C over RCCL, csrc/strips.hip) with a world of one - what can be
+    measured of it on a one-GPU box: its fixed cost over the whole-frame call, the host time to enqueue a step,
+    the per-phase device times; with --strip-graph the step is replayed from a captured HIP graph."""
+    plain = _bench("--steps", "20", "--warmup", "3", "--no-cpu")
+    for extra in ((), ("--strip-graph",)):
+        d = _bench("--steps", "20", "--warmup", "3", "--no-cpu", "--force-strips", "--phase-times", *extra)
+        st = d["strip_step"]
+        assert st["driver"].startswith("C (") and "rccl" in st["transport"]
+        assert 0 < st["enqueue_us_per_step"] < 200
+        assert st["hip_graph"] is (len(extra) > 0)
+        assert set(d["strip_phase_ms"]) == {"exchange_prev", "match", "marks", "commit", "group", "exchange_acc", "normalize"}
+        assert d["ms_per_step"] < 1.1 * plain["ms_per_step"]          # the three-phase machinery costs a few per cent
+        assert 0 < d["roofline"]["frac"] < 1
 
 
 @pytest.mark.gpu
@@ -97,7 +117,7 @@ def test_flow_bench_line():
     d = _bench("--workload", "F1", "--steps", "2", "--warmup", "1")
     for k in REQUIRED:
         assert k in d, k
-    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.5
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.0
     assert d["cpu_baseline"]["kind"] in ("reference", "port")
     assert d["parity_crop_480x270"]["bit_exact"] is True
 

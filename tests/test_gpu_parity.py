@@ -1150,6 +1150,7 @@ np.save(sys.argv[2], pkg.filter_frame(pkg.rgb2opp(n0), None, None, 20.0, p))
         if tag == "list2":
             assert "not split" in r.stderr
         outs[tag] = np.load(out)
+    import importlib
     synth = importlib.import_module("bwd-nlkalman_amd.synth")
     cur = built.rgb2opp(synth.noisy_pair(120, 96, 3, 20.0, 3)[0])
     for tag in ("list2", "list1"):
