@@ -133,17 +133,28 @@ int nlk_ctx_create(nlk_ctx** out, int device) {
   if (!out) return fail(nullptr, NLK_EINVAL, "null ctx pointer");
   *out = nullptr;
   int n = 0;
+  struct timespec tt0;
+  clock_gettime(CLOCK_MONOTONIC, &tt0);
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
     return fail(nullptr, NLK_ENODEV, "no HIP device visible (the HIP path is mandatory: there is no CPU fallback)");
   if (device < 0 || device >= n)
     return fail(nullptr, NLK_ENODEV, "device %d out of range (%d visible)", device, n);
   nlk_ctx* c = new nlk_ctx();
   c->device = device;
+  const bool trace = getenv("NLK_CLI_TRACE") != nullptr;   // (where a one-shot process spends its start-up)
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    fprintf(stderr, "[nlk_ctx_create +%7.2f ms] %s\n", (t.tv_sec - tt0.tv_sec) * 1e3 + (t.tv_nsec - tt0.tv_nsec) * 1e-6, what);
+  };
+  lap("hipGetDeviceCount (runtime initialised)");
   if (hipSetDevice(device) != hipSuccess ||
       hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return fail(nullptr, NLK_EHIP, "cannot create a stream on device %d", device);
   }
+  lap("first stream");
   c->stream = c->own_stream;
   c->sw.load();
   c->deterministic = nlk_or(c->sw.deterministic, 0) != 0;
@@ -153,6 +164,7 @@ int nlk_ctx_create(nlk_ctx** out, int device) {
     nlk_ctx_destroy(c);
     return fail(nullptr, NLK_EHIP, "cannot create the second stream / events on device %d", device);
   }
+  lap("second stream + events");
   {
     std::lock_guard<std::mutex> lock(g_live_mu);
     g_live.push_back(c);

@@ -100,3 +100,46 @@ void cli_parse(const struct cli_option *opts, const char *prog, const char *desc
     exit(1);
   }
 }
+
+/* ---- start-up helpers of the command-line tools (cli_args.h) */
+#include <pthread.h>
+#include <time.h>
+
+struct nlk_ctx;
+struct nlk_ctx *nlkalman_hip_context(void); /* process-wide context of libnlkalman.so (exits on failure) */
+
+static pthread_t g_warm_thread;
+static int g_warm_started = 0;
+
+static void *warm_main(void *arg) {
+  (void)arg;
+  (void)nlkalman_hip_context();
+  return NULL;
+}
+
+void cli_warm_start(void) {
+  if (!g_warm_started && pthread_create(&g_warm_thread, NULL, warm_main, NULL) == 0) g_warm_started = 1;
+}
+
+void cli_warm_join(void) {
+  if (g_warm_started) pthread_join(g_warm_thread, NULL);
+  g_warm_started = 0;
+}
+
+void cli_trace(const char *what) {
+  static int on = -1;
+  static struct timespec t0;
+  struct timespec t;
+  if (on < 0) {
+    on = getenv("NLK_CLI_TRACE") != NULL;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+  }
+  if (!on) return;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  fprintf(stderr, "[cli %8.2f ms] %s\n", (t.tv_sec - t0.tv_sec) * 1e3 + (t.tv_nsec - t0.tv_nsec) * 1e-6, what);
+}
+
+int cli_leave(int status) {
+  cli_trace("leaving");
+  return status;
+}

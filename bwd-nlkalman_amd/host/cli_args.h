@@ -24,4 +24,17 @@ void cli_parse(const struct cli_option *opts, const char *prog, const char *desc
                int argc, const char **argv);
 void cli_usage(const struct cli_option *opts, const char *prog, const char *description);
 
+/* One frame call per process is how the pipelines use the tools (scripts/nlkalman-seq.sh:39-41): the ~0.1 s the
+ * HIP runtime takes to come up is on every call's critical path. cli_warm_start() begins creating the
+ * process-wide device context on a second thread as soon as the arguments are known good, so that it overlaps
+ * the reading / decoding of the input files; cli_warm_join() waits for it (call it before the first use of the
+ * context). cli_trace() prints the elapsed time since program start to stderr when NLK_CLI_TRACE is set. */
+void cli_warm_start(void);
+void cli_warm_join(void);
+void cli_trace(const char *what);
+/* last trace point; returns `status`. (Leaving through _exit() instead of the exit handlers was measured: no
+ * gain - the ~0.3 s of a one-shot process are the dynamic loading of the ROCm runtime before main (~0.1 s) and
+ * hipInit (~0.17 s), against ~0.05 s of reading, computing and writing: profiles/README.md round 4.) */
+int cli_leave(int status);
+
 #endif

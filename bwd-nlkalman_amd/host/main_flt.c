@@ -93,6 +93,7 @@ int main(int argc, const char **argv) {
       {CLI_GROUP, 0, NULL, NULL, "Program options"},
       {CLI_INT, 'v', "verbose", &verbose, "verbose output"},
       {CLI_END, 0, NULL, NULL, NULL}};
+  cli_trace("start");
   cli_parse(options, "nlkalman-flt", "Patch-based Kalman filter for video denoising.", argc, argv);
 
   /* mode (reference: src/main-flt.c:129-149) */
@@ -110,6 +111,7 @@ int main(int argc, const char **argv) {
 
   nlkalman_default_params(&f1, sigma, FLT1);
   nlkalman_default_params(&f2, sigma, FLT2);
+  cli_warm_start(); /* the GPU comes up while the input files are read */
 
   if (verbose) {
     printf("data input:\n\tnoise         %05.2f\n\tnoisy frames  %s\n\tbwd flows     %s\n"
@@ -157,7 +159,10 @@ int main(int argc, const char **argv) {
   }
 
   /* run on the GPU, frames resident (reference: src/main-flt.c:335-388) */
+  cli_trace("inputs read");
+  cli_warm_join();
   nlk_ctx *c = nlkalman_hip_context();
+  cli_trace("device context ready");
   const size_t n = (size_t)w * h * ch, bytes = n * sizeof(float);
   float *d_nisy = to_dev(c, nisy, n), *d_flo = to_dev(c, bflo, (size_t)w * h * 2);
   float *d_occ = to_dev(c, bocc, (size_t)w * h);
@@ -181,6 +186,7 @@ int main(int argc, const char **argv) {
     CHK(nlk_dev_rgb2opp(c, d_f11, w, h, ch));
   }
 
+  cli_trace("first iteration enqueued");
   float *host = malloc(bytes);
   if (apply_filt2) {
     const float *prev = d_f20;
@@ -201,6 +207,7 @@ int main(int argc, const char **argv) {
     CHK(nlk_d2h(c, host, d_f11, bytes));
     if (img_write(flt11_path, host, w, h, ch)) return fprintf(stderr, "cannot write %s\n", flt11_path), 1;
   }
+  cli_trace("outputs written");
   free(host); free(nisy); free(bflo); free(bocc); free(flt10); free(flt20); free(flt11);
-  return EXIT_SUCCESS;
+  return cli_leave(EXIT_SUCCESS);
 }
