@@ -80,9 +80,9 @@ def kernel_sources_sha():
 def measured_traffic(workload, instance, largest_grid=False):
     """HBM-side bytes per launch of kernel `instance` (full template name, e.g. "k_bm_topk<8, 3, 2>": the
     instantiation this run timed) from the committed PMC passes (profiles/<tag>_traffic.json, made by
-    tools/profile_round.sh + tools/make_traffic.py; tag = NLK_TRAFFIC_TAG, default r03) - only while the
+    tools/profile_round.sh + tools/make_traffic.py; tag = NLK_TRAFFIC_TAG, default r04) - only while the
     kernel sources are still the ones the table was measured on; otherwise (None, why)."""
-    tag = os.environ.get("NLK_TRAFFIC_TAG", "r03")
+    tag = os.environ.get("NLK_TRAFFIC_TAG", "r04")
     tpath = os.path.join(ROOT, "profiles", f"{tag}_traffic.json")
     if not os.path.exists(tpath):
         return None, f"no PMC table profiles/{tag}_traffic.json committed"

@@ -465,12 +465,60 @@ k_groupp(const float* __restrict__ img,   // matching / statistics image (planar
   float ww[PB];
 #pragma unroll
   for (int e = 0; e < PB; ++e) ww[e] = wgt * wv[e];
+  // where every member lands in the tile, once per target with one member per lane (as k_group8m.h): its
+  // offset (floats) inside a plane and an "inside the tile" bit (entries past the last member count as inside)
+  uint32_t mbase[2];
+  uint64_t inside[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int lx = nlk_x(greg[m]) - rx0, ly = nlk_y(greg[m]) - ry0;
+    const bool in = lx >= 0 && ly >= 0 && lx + PSZ <= rw && ly + PSZ <= rh;
+    mbase[m] = (uint32_t)(ly * rwp + lx);
+    inside[m] = __ballot(in || lane + 64 * m >= nagg);
+  }
 
   // ---------------- pass B: shrink, invert and aggregate the group members
   // rows staged in `scratch` as [slot][u][PP]; member n0 + s of the round is added by PSZ x NBK lanes
   auto add_round = [&](float (&px)[PSZ], int n0, int c) {
     if (on) nlk_pp_put_row<PSZ>(scratch + (sl * PSZ + u) * PP, px);
     NLK_PP_SYNC();
+    // a round whose NS members are all inside the tile (every round of a temporal target: the tile's halo is the
+    // temporal radius) is added in straight-line code: no per-member in-tile test, list select or loop branch
+    {
+      const int b0 = n0 & 63;
+      const uint64_t im = n0 < 64 ? inside[0] : inside[1];
+      if (b0 + NS <= 64 && n0 + NS <= nagg && ((im >> b0) & ((1ull << NS) - 1ull)) == (1ull << NS) - 1ull) {
+        const uint32_t mb = n0 < 64 ? mbase[0] : mbase[1];
+        int toff[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) toff[s] = __builtin_amdgcn_readlane((int)mb, b0 + s);  // (every lane active here)
+        if (agg_on) {
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            const float* sp = scratch + (s * PSZ + au) * PP + PB * ablk;
+            float* dst = vplane + toff[s] + au * rwp + PB * ablk;
+            float v[PB], o[PB];
+#pragma unroll
+            for (int e = 0; e < PB; ++e) v[e] = sp[e];
+#pragma unroll
+            for (int e = 0; e < PB; ++e) o[e] = PB * ablk + e < PSZ ? dst[e] : 0.f;
+#pragma unroll
+            for (int e = 0; e < PB; ++e)
+              if (PB * ablk + e < PSZ) dst[e] = fmaf(ww[e], v[e], o[e]);
+            if (c == 0) {
+              float* dw = wplane + toff[s] + au * rwp + PB * ablk;
+#pragma unroll
+              for (int e = 0; e < PB; ++e) o[e] = PB * ablk + e < PSZ ? dw[e] : 0.f;
+#pragma unroll
+              for (int e = 0; e < PB; ++e)
+                if (PB * ablk + e < PSZ) dw[e] = o[e] + ww[e];
+            }
+          }
+        }
+        NLK_PP_SYNC();
+        return;
+      }
+    }
 #pragma unroll 1
     for (int s = 0; s < NS; ++s) {
       const int mi = n0 + s;

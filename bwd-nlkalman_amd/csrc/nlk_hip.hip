@@ -186,7 +186,7 @@ void nlk_ctx_destroy(nlk_ctx* c) {
                  &c->tinfo, &c->gcoords, &c->marks, &c->active, &c->acc, &c->tabs, &c->wide, &c->tv, &c->skew, &c->ms,
                  &c->slab, &c->tflag, &c->hw_cur, &c->hw_prev, &c->hw_basic, &c->hw_out};
   for (Buf* b : bufs)
-    if (b->p) hipFree(b->p);
+    if (b->p) hipFree(b->base ? b->base : b->p);
   if (c->tv_host) (void)hipHostFree(c->tv_host);
   if (c->ev) {
     for (int i = 0; i < nlk_ctx::MAXSETS * nlk_ctx::NEV; ++i) (void)hipEventDestroy(c->ev[i]);

@@ -19,6 +19,7 @@ struct NlkGTile;    // k_group8.h
 struct NlkBuf {
   void* p = nullptr;
   size_t cap = 0;
+  void* base = nullptr;  // what hipMalloc returned (NLK_DEBUG_GUARD: p sits at the END of the allocation)
 };
 
 // what a launcher works on: the stream and the per-target records of the patch-grid rows it is
@@ -126,9 +127,20 @@ static inline int fail(nlk_ctx* c, int code, const char* fmt, ...) {
 
 static inline int reserve(nlk_ctx* c, NlkBuf& b, size_t bytes) {
   if (bytes <= b.cap) return NLK_OK;
-  if (b.p) HIPCHK(c, hipFree(b.p));
-  b.p = nullptr;
+  if (b.p) HIPCHK(c, hipFree(b.base ? b.base : b.p));
+  b.p = b.base = nullptr;
   b.cap = 0;
+  // NLK_DEBUG_GUARD=1 (debugging aid): no slack, and the buffer ends where its allocation ends (allocations are
+  // mapped in 2 MiB pieces), so that a kernel reading or writing past the end of a scratch buffer faults instead
+  // of landing in the slack of this or in the next allocation
+  static const bool guard = getenv("NLK_DEBUG_GUARD") != nullptr;
+  if (guard) {
+    const size_t page = (size_t)2 << 20, used = (bytes + 255) & ~(size_t)255, want = (used + page - 1) / page * page;
+    if (hipMalloc(&b.base, want) != hipSuccess) return fail(c, NLK_ENOMEM, "hipMalloc of %zu bytes failed", want);
+    b.p = (char*)b.base + (want - used);
+    b.cap = bytes;
+    return NLK_OK;
+  }
   const size_t want = bytes + bytes / 8 + 256;
   if (hipMalloc(&b.p, want) != hipSuccess)
     return fail(c, NLK_ENOMEM, "hipMalloc of %zu bytes failed", want);

@@ -19,9 +19,8 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
   // Deterministic mode runs a temporal frame's far-reaching (spatial-branch) groups in a second
   // launch whose tiles have the spatial halo, so that no member ever leaves its tile (k_group8.h)
   const bool split = c->deterministic && g.have_prev && !g.smoother && g.wsz_x > g.wsz_t;
-  size_t slab_off = 0, flag_off = 0;  // (the second pass's slabs follow the first's)
-  int* cnt_base = nullptr;
-  for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
+  // the tiles of a pass: halo, targets per tile, LDS strides
+  auto shape = [&](int pass) {
     NlkGTile tl{};
     tl.split = split;
     tl.far = pass;
@@ -39,7 +38,8 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
     const int tgx_fill = tiles_with(3) >= 30000 ? 3 : (tiles_with(2) >= 2560 ? 2 : 1);
     tl.tgx = nlk_or(c->sw.gtx, min(tgx_fill, tl.wmax > 6 ? 2 : 4));
     // (round 3, matrix-core kernel with the leaner pass A, 1080p: 3 x 2 targets 0.957 ms, 2 x 2 0.970, 3 x 1 0.976,
-    // 4 x 2 1.10, 2 x 3 1.05, 3 x 3 1.04 - two target rows share the tile's vertical halo: 40 % fewer flushed bytes)
+    // 4 x 2 1.10, 2 x 3 1.05, 3 x 3 1.04 - two target rows share the tile's vertical halo: 40 % fewer flushed bytes;
+    // round 4, straight-line aggregation: 3 x 2 0.831, 2 x 2 0.851, 3 x 1 0.869, 3 x 3 0.891, 4 x 2 0.993)
     tl.tgy = nlk_or(c->sw.gty, (mfma && tgx_fill == 3 && tl.wmax <= 6) ? 2 : 1);
     tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
     tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
@@ -72,36 +72,41 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
       tl.rwp = rw_max | 1;
       tl.plane = tl.rwp * tl.rh_max;
     }
+    return tl;
+  };
+  const int npass = split ? 2 : 1;
+  NlkGTile tls[2] = {shape(0), shape(split ? 1 : 0)};
+  // Deterministic mode: slabs, "written" flags and tile-row counters of BOTH passes, sized from each pass's OWN
+  // tiles before the first launch (growing a buffer frees it). (Round 3 sized the far pass with the near pass's
+  // tile rows - half as many since the near tiles hold two grid rows - and its counters likewise: writes past
+  // the end that the allocation slack hid; found with NLK_DEBUG_GUARD=1.)
+  size_t slab_at[2] = {0, 0}, flag_at[2] = {0, 0}, cnt_at[2] = {0, 0};
+  if (c->deterministic) {
+    size_t need = 0, nflag = 0, ncnt = 0;
+    for (int pass = 0; pass < npass; ++pass) {
+      const size_t ntiles = (size_t)tls[pass].ntx * tls[pass].nty;
+      slab_at[pass] = need; flag_at[pass] = nflag; cnt_at[pass] = ncnt;
+      need += ntiles * (CH + 1) * tls[pass].plane;
+      nflag += ntiles;
+      ncnt += 1 + (size_t)tls[pass].nty;
+    }
+    const size_t cnt_off = (nflag + 15) & ~(size_t)15, cnt_bytes = sizeof(int) * ncnt;
+    int rc;
+    if ((rc = reserve(c, c->slab, sizeof(float) * need)) || (rc = reserve(c, c->tflag, cnt_off + cnt_bytes))) return rc;
+    HIPCHK(c, hipMemsetAsync((uint8_t*)c->tflag.p + cnt_off, 0, cnt_bytes, c->rv.stream));
+    for (int pass = 0; pass < npass; ++pass) {
+      tls[pass].slab = (float*)c->slab.p + slab_at[pass];
+      tls[pass].tflag = (uint8_t*)c->tflag.p + flag_at[pass];
+      tls[pass].tcount = (int*)((uint8_t*)c->tflag.p + cnt_off) + cnt_at[pass];
+    }
+  }
+  for (int pass = 0; pass < npass; ++pass) {
+    const NlkGTile& tl = tls[pass];
 #ifndef NLK_G8_LDS_PAD
 #define NLK_G8_LDS_PAD 0  // (experiments: bytes of unused LDS per workgroup, to cut the occupancy)
 #endif
     const size_t lds = sizeof(float) * ((size_t)(CH + 1) * tl.plane + (mfma ? (CH + 2) * NLK_G8_SST : 0)) + NLK_G8_LDS_PAD;
     if (lds > 160 * 1024) return fail(c, NLK_EUNSUP, "aggregation tile needs %zu bytes of LDS", lds);
-    const size_t ntiles = (size_t)tl.ntx * tl.nty;
-    if (c->deterministic) {
-      // (both passes' slabs are sized before the first launch: growing the buffer frees it)
-      if (pass == 0) {
-        size_t need = ntiles * (CH + 1) * tl.plane, nflag = ntiles;
-        if (split) {
-          const int tgx2 = nlk_or(c->sw.gtx, min(tgx_fill, g.wsz_x > 6 ? 2 : 4));
-          const int rw2 = (tgx2 - 1) * g.step + 2 * g.wsz_x + g.psz, rh2 = (tl.tgy - 1) * g.step + 2 * g.wsz_x + g.psz;
-          const size_t nt2 = (size_t)((g.ngx + tgx2 - 1) / tgx2) * tl.nty;
-          need += nt2 * (CH + 1) * ((size_t)(rw2 + 32) * rh2 + 32);
-          nflag += nt2;
-        }
-        int rc;
-        // (flags, then the tile-row counters of both passes: 2 x (1 + nty) ints, cleared per call)
-        const size_t cnt_off = (nflag + 15) & ~(size_t)15, cnt_bytes = sizeof(int) * 2 * (1 + (size_t)tl.nty);
-        if ((rc = reserve(c, c->slab, sizeof(float) * need)) || (rc = reserve(c, c->tflag, cnt_off + cnt_bytes))) return rc;
-        HIPCHK(c, hipMemsetAsync((uint8_t*)c->tflag.p + cnt_off, 0, cnt_bytes, c->rv.stream));
-        cnt_base = (int*)((uint8_t*)c->tflag.p + cnt_off);
-      }
-      tl.slab = (float*)c->slab.p + slab_off;
-      tl.tflag = (uint8_t*)c->tflag.p + flag_off;
-      tl.tcount = cnt_base + pass * (1 + tl.nty);
-      slab_off += ntiles * (CH + 1) * tl.plane;
-      flag_off += ntiles;
-    }
     void (*kern)(const float*, const float*, const float*, const uint8_t*, NlkGeom, NlkGTile,
                  const uint32_t*, const NlkTarget*, const uint32_t*, const uint8_t*, const float*,
                  const float*, float*);

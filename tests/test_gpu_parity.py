@@ -931,7 +931,14 @@ def test_deterministic_aggregation_is_bit_reproducible(built, O, synth, psz):
             f2 = _frame(c, (o1, hole, f1), sigma, p2)
             s0 = _frame(c, (f0, f2, None), sigma, p3, smoother=True)
             return f0, f1, f2, s0
-        a, b, d = chain(det), chain(det), chain(dflt)
+        a, b = chain(det), chain(det)
+        # the default mode stage by stage on the deterministic run's outputs (a free-running second chain would
+        # feed its second iteration a basic estimate that differs by summation noise: a near-tied k-NN rank
+        # flips and moves a few dozen samples by hundredths - not what this test is about)
+        hole_a = a[0].copy()
+        hole_a[40:70, 100:160] = np.nan
+        d = (_frame(dflt, (o0, None, None), sigma, p1), _frame(dflt, (o1, hole_a, None), sigma, p1),
+             _frame(dflt, (o1, hole_a, a[1]), sigma, p2), _frame(dflt, (a[0], a[2], None), sigma, p3, smoother=True))
         for name, x, y, z in zip(("flt1 spatial", "flt1 temporal", "flt2", "smo1"), a, b, d):
             assert np.array_equal(x, y, equal_nan=True), f"psz {psz} {name}: two deterministic runs differ"
             # (default mode: float atomics in varying order; a pixel whose summed weight sits at the

@@ -15,6 +15,8 @@ done
 [ -f $SRC/pmc_F1_summary.txt ] && cp $SRC/pmc_F1_summary.txt profiles/${TAG}_pmc_F1_summary.txt
 [ -f $SRC/mode_times_1080p.txt ] && cp $SRC/mode_times_1080p.txt profiles/${TAG}_mode_times_1080p.txt
 [ -f $SRC/api_wall.txt ] && cp $SRC/api_wall.txt profiles/${TAG}_api_wall.txt
+[ -f $SRC/startup_times.txt ] && cp $SRC/startup_times.txt profiles/${TAG}_startup_times.txt
+[ -f $SRC/power_probe.txt ] && cp $SRC/power_probe.txt profiles/${TAG}_power_probe.txt
 # the traffic table reads gpurun_out/<tag>/pmc_*_summary.txt
 mkdir -p gpurun_out/$TAG
 cp $SRC/pmc_*_summary.txt gpurun_out/$TAG/

@@ -4,7 +4,7 @@
 #   tools/profile_round.sh <tag>      -> gpurun_out/<tag>/ ; then tools/make_traffic.py <tag>
 # Every command runs under `timeout` (a profiler that does not come back must not eat the GPU budget).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -19,6 +19,15 @@ NLK_DETERMINISTIC=1 $T python3 $ROOT/bench.py --no-cpu --workload C3 > $OUT/benc
 # the N > 1 code path of bench.py on the one GPU of this box (every rank on device 0 over gloo): plumbing, NOT a measurement
 NLK_BENCH_ONE_GPU=1 timeout 600 python3 $ROOT/bench.py --gpus 2 --steps 5 --warmup 2 --phase-times > $OUT/bench_C2_2ranks_onegpu.json 2> $OUT/bench_C2_2ranks_onegpu.err
 NLK_BENCH_ONE_GPU=1 timeout 900 python3 $ROOT/bench.py --gpus 8 --steps 5 --warmup 2 --phase-times > $OUT/bench_C2_8ranks_onegpu.json 2> $OUT/bench_C2_8ranks_onegpu.err
+# the N > 1 step at N = 1 (--force-strips): enqueued from C (plain launches / replayed HIP graph) and from Python,
+# with the per-phase device times: what the three-phase machinery costs over the whole-frame call
+for W in C2 C3; do
+  $T python3 $ROOT/bench.py --no-cpu --workload $W --force-strips --phase-times > $OUT/bench_${W}_force_strips_c.json 2>/dev/null
+  $T python3 $ROOT/bench.py --no-cpu --workload $W --force-strips --phase-times --strip-graph > $OUT/bench_${W}_force_strips_c_graph.json 2>/dev/null
+  $T python3 $ROOT/bench.py --no-cpu --workload $W --force-strips --phase-times --strip-driver py > $OUT/bench_${W}_force_strips_py.json 2>/dev/null
+done
+$T python3 $ROOT/tools/startup_times.py > $OUT/startup_times.txt 2>&1
+$T python3 $ROOT/tools/power_probe.py --steps 3000 --warmup 50 --no-cpu > $OUT/power_probe.txt 2>&1
 $T python3 $ROOT/tools/mode_times.py > $OUT/mode_times_1080p.txt 2>&1
 NLK_HOST_TRACE=1 $T python3 $ROOT/tools/api_wall.py > $OUT/api_wall.txt 2>&1
 for W in C2 C3; do
