@@ -150,6 +150,50 @@ def test_oracle_vs_survey_shim_build(O, name):
     cases.assert_close(O.opp2rgb(s1), R["s1_0"], "s1_0", maxabs=1e-3)
 
 
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_oracle_against_the_reference_filter(O, name):
+    """THE pin the oracle lacks: src/nlkalman.c itself, compiled unmodified against a real FFTW3
+    by `make -C oracle ref` where one exists (oracle/Makefile: _ref/libnlkalman_ref.so, serial build). This image
+    has no FFTW: the test skips, and every filter parity statement stays "unpinned". Where the library exists,
+    every stage of the golden chain must agree with the reference to the FP noise floor of two DCT
+    implementations (max-abs 2e-4, RMSE 2.5e-5)."""
+    import ctypes as C
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libnlkalman_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("no reference filter build (FFTW3 absent from this image): parity unpinned")
+    R = C.CDLL(so)
+    fp = C.POINTER(C.c_float)
+
+    class Ref:   # the same function names as the oracle module, backed by the reference's own code
+        FLT1, FLT2, SMO1 = 0, 1, 2
+        default_params = staticmethod(O.default_params)
+        rgb2opp, opp2rgb, warp_bicubic = staticmethod(O.rgb2opp), staticmethod(O.opp2rgb), staticmethod(O.warp_bicubic)
+
+        @staticmethod
+        def _frame(fn, cur, prev, basic, sigma, p):
+            cur = np.ascontiguousarray(cur, np.float32)
+            out = np.empty_like(cur)
+            h, w, ch = cur.shape
+            ptr = lambda a: None if a is None else np.ascontiguousarray(a, np.float32).ctypes.data_as(fp)
+            keep = [np.ascontiguousarray(a, np.float32) if a is not None else None for a in (prev, basic)]
+            fn.argtypes = [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, type(p), C.c_int]
+            fn.restype = None
+            fn(out.ctypes.data_as(fp), cur.ctypes.data_as(fp), ptr(keep[0]), ptr(keep[1]), w, h, ch, C.c_float(sigma), p, 0)
+            return out
+
+        @classmethod
+        def filter_frame(cls, cur, prev, basic, sigma, p):
+            return cls._frame(R.nlkalman_filter_frame, cur, prev, basic, sigma, p)
+
+        @classmethod
+        def smooth_frame(cls, cur, prev, basic, sigma, p):
+            return cls._frame(R.nlkalman_smooth_frame, cur, prev, basic, sigma, p)
+    ref = cases.run_chain(Ref, name)
+    got = cases.run_chain_stagewise(O, ref, name)
+    for k in ("f1_0", "f2_0", "f1_1", "f2_1", "s1_0"):
+        cases.assert_close(got[k], ref[k], f"oracle vs reference filter, {name}/{k}", maxabs=1e-3, rmse=1e-4)
+
+
 # ------------------------------------------- independent numpy restatement
 
 def _small(synth, w, h, ch, sigma, seed):
