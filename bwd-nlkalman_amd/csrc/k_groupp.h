@@ -566,8 +566,10 @@ k_groupp(const float* __restrict__ img,   // matching / statistics image (planar
   };
   // a tile plane -> HBM (coalesced rows, untouched entries skipped), cleared for the next channel
   // (a narrow tile puts two or four rows on the 64 lanes: fewer, fuller atomic instructions)
-  const int sx = rw <= 16 ? 16 : (rw <= 32 ? 32 : 64), sy = 64 / sx;
-  const int fx = lane & (sx - 1), fy = lane / sx;
+  // (the region walked as one run of rw x rh entries, 64 per atomic instruction: a wavefront's flush is paced by
+  // the atomics it may have in flight, i.e. by their number - k_group8m.h)
+  const int qstep = 64 / rw, rstep = 64 - qstep * rw;
+  const int fy0 = lane / rw, fx0 = lane - fy0 * rw;
   auto flush = [&](float* sp, int p, bool clear) {
     if (tl.slab) {  // deterministic mode: the plane as it stands, into this target's slab
       nlk_f4* dst = reinterpret_cast<nlk_f4*>(tl.slab + ((size_t)ti * (CH + 1) + p) * plane);
@@ -579,15 +581,17 @@ k_groupp(const float* __restrict__ img,   // matching / statistics image (planar
       return;
     }
     float* dp = acc + (size_t)p * npix + (size_t)ry0 * g.w + rx0;
-#pragma unroll 4
-    for (int y = fy; y < rh; y += sy)
-      for (int xx = fx; xx < rw; xx += sx) {
-        const float v = sp[y * rwp + xx];
-        if (v != 0.f) {
-          unsafeAtomicAdd(dp + (size_t)y * g.w + xx, v);
-          if (clear) sp[y * rwp + xx] = 0.f;
-        }
+    int y = fy0, xx = fx0;
+#pragma unroll 2
+    for (; y < rh; ) {
+      const float v = sp[y * rwp + xx];
+      if (v != 0.f) {
+        unsafeAtomicAdd(dp + (size_t)y * g.w + xx, v);
+        if (clear) sp[y * rwp + xx] = 0.f;
       }
+      xx += rstep; y += qstep;
+      if (xx >= rw) { xx -= rw; ++y; }
+    }
     NLK_PP_SYNC();
   };
   // The member rows of a step are requested one step ahead (also across the change of channel), and
