@@ -338,6 +338,8 @@ def main():
     ap.add_argument("--strip-driver", choices=["c", "py"], default="c",
                     help="row-strip runs: the step enqueued from C (csrc/strips.hip: RCCL called from C, one ctypes call "
                          "per step - the default) or from Python (strips.py over torch.distributed)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip first_frame_ms / api_wall_ms (profiler passes: only the timed call's kernels run)")
     ap.add_argument("--strip-graph", action="store_true",
                     help="C strip driver: capture the step into a HIP graph once and replay it")
     args = ap.parse_args()
@@ -649,7 +651,7 @@ def main():
                "kernels_ms_note": "second loop of the same steps with HIP events around every kernel on the "
                                   "context's stream; ms_per_step is the timed (unprofiled) loop",
                "roofline": roof}
-        if world == 1 and not striped and args.workload in ("C1", "C2", "C3"):
+        if world == 1 and not striped and not args.no_extras and args.workload in ("C1", "C2", "C3"):
             # beside the resident temporal call: the first frame of a sequence (deno0 = NULL: the spatial branch
             # everywhere, 441-candidate windows) and the drop-in API on host pointers (PCIe
             # included; pageable host memory, frame in row bands). Neither is `value`.

@@ -31,7 +31,7 @@ $T python3 $ROOT/tools/power_probe.py --steps 3000 --warmup 50 --no-cpu > $OUT/p
 $T python3 $ROOT/tools/mode_times.py > $OUT/mode_times_1080p.txt 2>&1
 NLK_HOST_TRACE=1 $T python3 $ROOT/tools/api_wall.py > $OUT/api_wall.txt 2>&1
 for W in C2 C3; do
-  $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -o s -- python3 $ROOT/bench.py --no-cpu --workload $W > $OUT/bench_${W}_under_rocprof.json 2>/dev/null
+  $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -o s -- python3 $ROOT/bench.py --no-cpu --no-extras --workload $W > $OUT/bench_${W}_under_rocprof.json 2>/dev/null
   i=0
   for SET in \
    "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" \
@@ -39,7 +39,7 @@ for W in C2 C3; do
    "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 GRBM_GUI_ACTIVE" \
    "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum"; do
     i=$((i+1))
-    $T rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/pmc_$W/p$i -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --workload $W > /dev/null 2>&1
+    $T rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/pmc_$W/p$i -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-extras --workload $W > /dev/null 2>&1
   done
   python3 $ROOT/tools/pmc_summary.py $OUT/pmc_$W > $OUT/pmc_${W}_summary.txt 2>&1
 done
