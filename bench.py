@@ -340,6 +340,10 @@ def main():
                          "per step - the default) or from Python (strips.py over torch.distributed)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip first_frame_ms / api_wall_ms (profiler passes: only the timed call's kernels run)")
+    ap.add_argument("--strip-model", action="store_true",
+                    help="N = 1 only: additionally step ONE middle rank of a world of 2 / 4 / 8 alone, every exchange "
+                         "skipped (csrc/strips.hip dry run): the kernels + launch gaps one rank pays per frame at that "
+                         "world size - an upper bound of the scaling curve a one-GPU box can measure, not a result")
     ap.add_argument("--strip-graph", action="store_true",
                     help="C strip driver: capture the step into a HIP graph once and replay it")
     args = ap.parse_args()
@@ -674,6 +678,38 @@ def main():
             res["api_wall_ms"] = round(min(walls) * 1e3, 4)
             res["api_wall_note"] = ("nlkalman_filter_frame on pageable host images (75 MB up, 25 MB down at 1080p RGB), "
                                     f"best of {reps}; PCIe-inclusive, never `value`")
+        if args.strip_model and world == 1 and args.workload in ("C2", "C3"):
+            model = []
+            for nw in (2, 4, 8):
+                row = {"world": nw, "rank": nw // 2}
+                for graph in (False, True):
+                    m = pkg.Strips([local], nw // 2, nw, w, h, ch, sigma, p)
+                    m.set_dry_run(True)
+                    m.set_options(overlap=True, timing=False, graph=graph)
+                    m.load(0, t_n1.data_ptr(), t_prev.data_ptr())
+                    for _ in range(5):
+                        m.step()
+                    m.sync()
+                    m.stats()
+                    t1 = time.perf_counter()
+                    for _ in range(args.steps):
+                        m.step()
+                    m.sync()
+                    dtm = (time.perf_counter() - t1) / args.steps * 1e3
+                    _, us, rep = m.stats()
+                    row["graph_ms" if graph else "ms"] = round(dtm, 4)
+                    row["graph_enqueue_us" if graph else "enqueue_us"] = round(us, 1)
+                    if graph:
+                        row["graph_replayed"] = rep
+                    g_ = m.geometry(0)
+                    row["grid_rows"] = g_["gy1"] - g_["gy0"]
+                    m.close()
+                row["mpix_s_if_every_rank_took_this"] = round(w * h / (min(row["ms"], row["graph_ms"]) * 1e-3) / 1e6, 1)
+                model.append(row)
+            res["strip_model"] = {"note": "ONE middle rank of a world of N stepped alone on this GPU, exchanges skipped: its "
+                                          "kernels and launch gaps per frame; the last column is the frame rate if every rank "
+                                          "took that long and the exchanges were free - an upper bound, not a measurement",
+                                  "ranks": model}
         if strip_info is not None:
             res["strip_step"] = strip_info
         if phase_ms is not None:

@@ -30,10 +30,10 @@ HIP_SYMBOLS = [
     "nlk_dev_strip_match", "nlk_dev_strip_match_rows", "nlk_dev_mask_commit", "nlk_dev_strip_group",
     "nlk_tvl1_default_params", "nlk_tvl1_scales", "nlk_dev_tvl1_flow", "nlk_dev_gray",
     "nlk_dev_occlusion_mask", "nlk_dev_image_dct", "nlk_dev_copy_block", "nlk_host_tables", "nlk_ctx_set_deterministic", "nlk_dev_zero", "nlk_dev_add", "nlk_dev_copy_peer",
-    "nlk_filter_frame_host", "nlk_smooth_frame_host", "nlk_dev_strip_match_part", "nlk_ctx_reload_switches",
+    "nlk_filter_frame_host", "nlk_smooth_frame_host", "nlk_dev_strip_match_part", "nlk_ctx_reload_switches", "nlk_ctx_set_strip_accumulator",
     "nlk_strips_create", "nlk_strips_destroy", "nlk_strips_last_error", "nlk_rccl_unique_id", "nlk_strips_rccl_init",
     "nlk_strips_transport", "nlk_strips_load", "nlk_strips_set_options", "nlk_strips_step", "nlk_strips_sync",
-    "nlk_strips_own_rows", "nlk_strips_ctx", "nlk_strips_geometry", "nlk_strips_stats",
+    "nlk_strips_own_rows", "nlk_strips_ctx", "nlk_strips_geometry", "nlk_strips_stats", "nlk_strips_set_dry_run",
 ]
 API_SYMBOLS = [
     "rgb2opp", "opp2rgb", "warp_bicubic", "nlkalman_default_params",
@@ -139,6 +139,7 @@ def hip():
         L.nlk_host_tables.argtypes = [i, vp, vp, vp]
         L.nlk_ctx_set_deterministic.argtypes = [vp, i]
         L.nlk_ctx_reload_switches.argtypes = [vp]
+        L.nlk_ctx_set_strip_accumulator.argtypes = [vp, vp]
         L.nlk_strips_create.argtypes = [C.POINTER(vp), i, C.POINTER(i), i, i, i, i, i, C.c_float, C.POINTER(Params), i, i]
         L.nlk_strips_destroy.argtypes = [vp]
         L.nlk_strips_destroy.restype = None
@@ -151,6 +152,7 @@ def hip():
         L.nlk_strips_load.argtypes = [vp, i, vp, vp]
         L.nlk_strips_set_options.argtypes = [vp, i, i, i]
         L.nlk_strips_step.argtypes = [vp]
+        L.nlk_strips_set_dry_run.argtypes = [vp, i]
         L.nlk_strips_sync.argtypes = [vp]
         L.nlk_strips_own_rows.argtypes = [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
         L.nlk_strips_ctx.argtypes = [vp, i]
@@ -496,6 +498,9 @@ class Strips:
 
     def set_options(self, overlap=True, timing=False, graph=False):
         self._chk(self.L.nlk_strips_set_options(self.h, int(overlap), int(timing), int(graph)))
+
+    def set_dry_run(self, on=True):
+        self._chk(self.L.nlk_strips_set_dry_run(self.h, int(on)))
 
     def step(self):
         self._chk(self.L.nlk_strips_step(self.h))

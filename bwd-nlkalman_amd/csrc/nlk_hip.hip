@@ -403,7 +403,7 @@ static NlkRecView view_rows(nlk_ctx* c, const NlkGeom& g, hipStream_t stream, in
   v.topk = (uint32_t*)c->topk.p + t0 * g.kmax;
   v.tinfo = (NlkTarget*)c->tinfo.p + t0;
   v.gcoords = (uint32_t*)c->gcoords.p + t0 * g.gstride;
-  v.marks = (uint64_t*)c->marks.p + t0;
+  v.marks = (c->marks_ext ? c->marks_ext : (uint64_t*)c->marks.p) + t0;
   v.wide = (uint32_t*)c->wide.p + t0 + band;  // (every band: its own counter in front of its own list)
   return v;
 }
@@ -790,18 +790,20 @@ int nlk_dev_strip_match_part(nlk_ctx* c, const float* cur, const float* prev, co
   NlkPlan pl;
   int rc = plan_frame(c, pl, cur, prev, basic, w, h, ch, sigma, P, oy, ngy, smoother, 1, nullptr, false);
   if (rc) return rc;
-  if ((rc = layout_rows(c, cur, prev, basic, nullptr, w, h, ch, pl.g.psz, lay0, lay1, v0, v1))) return rc;
+  // (nlk_ctx_set_strip_accumulator: the rows laid out are also the accumulator rows cleared - no separate memset)
+  if ((rc = layout_rows(c, cur, prev, basic, c->strip_acc, w, h, ch, pl.g.psz, lay0, lay1, v0, v1))) return rc;
   mark(c, 1);
   if (r0 < 0 || rows < 0 || r0 + rows > pl.g.ngy) return fail(c, NLK_EINVAL, "rows [%d, %d) outside the strip's %d target rows", r0, r0 + rows, pl.g.ngy);
-  if (rows > 0 && (rc = match_rows(c, pl, c->stream, r0, rows, 0))) return rc;
+  if (marks_out && pl.g.R > 3)
+    return fail(c, NLK_EUNSUP, "group reach %d grid cells > 3: 64-bit mark words cannot describe it (row strips "
+                "across GPUs are limited to reach 3; whole-frame calls are not)", pl.g.R);
+  // the matcher writes the mark words of these rows straight to their place in the caller's array
+  c->marks_ext = (uint64_t*)marks_out;
+  rc = rows > 0 ? match_rows(c, pl, c->stream, r0, rows, 0) : NLK_OK;
+  c->marks_ext = nullptr;
+  if (rc) return rc;
   mark(c, 2);
   if (reach) *reach = c->last.R;
-  if (marks_out && c->last.R > 3)
-    return fail(c, NLK_EUNSUP, "group reach %d grid cells > 3: 64-bit mark words cannot describe it (row strips "
-                "across GPUs are limited to reach 3; whole-frame calls are not)", c->last.R);
-  if (marks_out && rows > 0)
-    HIPCHK(c, hipMemcpyAsync((uint64_t*)marks_out + (size_t)r0 * c->last.ngx, (const uint64_t*)c->marks.p + (size_t)r0 * c->last.ngx,
-                             sizeof(uint64_t) * (size_t)c->last.ngx * rows, hipMemcpyDeviceToDevice, c->stream));
   return NLK_OK;
 }
 
@@ -816,6 +818,12 @@ int nlk_dev_strip_match(nlk_ctx* c, const float* cur, const float* prev, const f
                         int h, int ch, float sigma, const struct nlkalman_params* P, int oy,
                         int ngy, int smoother, void* marks_out, int* reach) {
   return nlk_dev_strip_match_rows(c, cur, prev, basic, w, h, ch, sigma, P, oy, ngy, smoother, 0, ngy, marks_out, reach);
+}
+
+int nlk_ctx_set_strip_accumulator(nlk_ctx* c, float* acc) {
+  if (!c) return NLK_EINVAL;
+  c->strip_acc = acc;
+  return NLK_OK;
 }
 
 int nlk_dev_mask_commit(nlk_ctx* c, const void* marks, int ngx, int ngy, int reach,

@@ -69,6 +69,8 @@ struct nlk_ctx {
   hipStream_t aux_stream = nullptr;  // second stream of the banded frame pipeline (run_frame)
   hipEvent_t sync_ev[8] = {};        // cross-stream dependencies of that pipeline (no timing)
   NlkRecView rv;                     // set by the orchestration before every launcher call
+  uint64_t* marks_ext = nullptr;     // strip calls: the matcher writes its mark words straight into the caller's array
+  float* strip_acc = nullptr;        // strip calls: accumulator whose rows the layout kernel clears as it lays them out
   char err[512] = "";
   NlkBuf pl_cur, pl_prev, pl_basic, rowok, vmap, topk, tinfo, gcoords, marks, active, acc, tabs, wide;
   NlkBuf skew;                    // mark words in replay-step order (k_marks_skew)

@@ -73,16 +73,24 @@ int load_rccl() {
       return fail(ctx, NLK_EHIP, "%s failed: %s (%s:%d)", #call, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
   } while (0)
 
-// rows [r0, r0 + nr) of every plane of a planar (np, hl, w) accumulator <-> a packed (np, nr, w) buffer
-__global__ void k_pack_rows(float* __restrict__ dst, const float* __restrict__ acc, int w, int hl, int r0, int nr) {
-  const int p = blockIdx.z, r = blockIdx.y;
+// rows [r0, r0 + nr) of every plane of a planar (np, hl, w) accumulator <-> a packed (np, nr, w) buffer; the rows
+// above the strip's own rows (a) and below them (b) in ONE launch each way: blockIdx.y < na is side a
+struct RowSide { float* buf; int r0, nr; };
+__global__ void k_pack_rows(const float* __restrict__ acc, int w, int hl, RowSide a, RowSide b) {
+  const int p = blockIdx.z;
+  const bool first = (int)blockIdx.y < a.nr;
+  const RowSide s = first ? a : b;
+  const int r = first ? blockIdx.y : blockIdx.y - a.nr;
   for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x)
-    dst[((size_t)p * nr + r) * w + x] = acc[((size_t)p * hl + r0 + r) * w + x];
+    s.buf[((size_t)p * s.nr + r) * w + x] = acc[((size_t)p * hl + s.r0 + r) * w + x];
 }
-__global__ void k_add_rows(float* __restrict__ acc, const float* __restrict__ src, int w, int hl, int r0, int nr) {
-  const int p = blockIdx.z, r = blockIdx.y;
+__global__ void k_add_rows(float* __restrict__ acc, int w, int hl, RowSide a, RowSide b) {
+  const int p = blockIdx.z;
+  const bool first = (int)blockIdx.y < a.nr;
+  const RowSide s = first ? a : b;
+  const int r = first ? blockIdx.y : blockIdx.y - a.nr;
   for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x)
-    acc[((size_t)p * hl + r0 + r) * w + x] += src[((size_t)p * nr + r) * w + x];
+    acc[((size_t)p * hl + s.r0 + r) * w + x] += s.buf[((size_t)p * s.nr + r) * w + x];
 }
 
 enum { PH_PREV, PH_MATCH, PH_MARKS, PH_COMMIT, PH_GROUP, PH_ACC, PH_NORM, PH_N };
@@ -115,6 +123,7 @@ struct nlk_strips {
   std::vector<Strip> s;              // the local ones
   ncclComm_t comm = nullptr;
   bool rccl = false, overlap = true, have_prev = true, timing = false, want_graph = false, graph_failed = false;
+  bool dry = false;  // nlk_strips_set_dry_run: exchanges skipped (one rank of a larger world timed alone)
   int timed_steps = 0, steps_done = 0;
   double phase_ms[PH_N] = {}, issue_us = 0;
   int issue_n = 0;
@@ -168,6 +177,7 @@ int enqueue_step(nlk_strips* S) {
     for (Strip& T : S->s) {
       HIPCHK(T.c, hipSetDevice(T.device));
       HIPCHK(T.c, hipStreamWaitEvent(T.comm, T.ev_start, 0));
+      if (S->dry) { HIPCHK(T.c, hipEventRecord(T.ev_prev, T.comm)); continue; }
       const int up = T.rank - 1, dn = T.rank + 1;
       float* top_own = T.prev + (size_t)(T.p.own0 - T.p.Y0) * w * ch;           // my first own rows
       float* bot_own = T.prev + (size_t)(T.p.own1 - T.n_dn - T.p.Y0) * w * ch;  // my last own rows the lower rank reads
@@ -210,7 +220,9 @@ int enqueue_step(nlk_strips* S) {
     const float* pv = S->have_prev ? T.prev : nullptr;
     int reach = 0;
     const bool halo = S->have_prev && S->world > 1 && (T.rank > 0 || T.rank < S->world - 1);
-    if (halo && S->overlap && T.i1 > T.i0) {
+    // (the split costs two more rounds of the matching launches: worth it only while the interior is most of a
+    // sizeable strip - at 1080p up to 3-4 strips; thin strips match in one go behind the halo's arrival)
+    if (halo && S->overlap && T.i1 - T.i0 >= 48 && 4 * (T.i1 - T.i0) >= 3 * T.rows) {
       const int o0 = T.p.own0 - T.p.Y0, o1 = T.p.own1 - T.p.Y0, hl = T.hl;
       SCHK(S, T.c, nlk_dev_strip_match_part(T.c, T.cur, pv, nullptr, w, hl, ch, S->sigma, &S->P, T.oy, T.rows, S->smoother,
                                             T.i0, T.i1 - T.i0, o0, o1, o0, o1 == hl ? o1 : o1 - psz + 1, mk, &reach));
@@ -235,7 +247,7 @@ int enqueue_step(nlk_strips* S) {
     HIPCHK(T.c, hipSetDevice(T.device));
     int rc = tick(T, PH_MARKS);
     if (rc) return rc;
-    if (S->world == 1) continue;
+    if (S->world == 1 || S->dry) continue;
     if (S->rccl) {
       NCCLCHK(T.c, g_rccl.GroupStart());
       for (int r = 0; r < S->world; ++r) {
@@ -260,14 +272,14 @@ int enqueue_step(nlk_strips* S) {
     if (rc) return rc;
     SCHK(S, T.c, nlk_dev_mask_commit(T.c, T.marks_full, ngx, S->ngy, S->reach, T.active_full));
     if ((rc = tick(T, PH_GROUP))) return rc;
-    SCHK(S, T.c, nlk_dev_zero(T.c, T.acc, sizeof(float) * (size_t)(ch + 1) * T.hl * w));
     SCHK(S, T.c, nlk_dev_strip_group(T.c, T.acc, T.active_full + (size_t)T.p.gy0 * ngx));
     if ((rc = tick(T, PH_ACC))) return rc;
     // the accumulator rows written outside my own rows, packed for their owners
-    const dim3 blk(256);
-    if (T.h_top > 0) hipLaunchKernelGGL(k_pack_rows, dim3((w + 255) / 256, T.h_top, ch + 1), blk, 0, T.c->stream, T.snd_top, T.acc, w, T.hl, 0, T.h_top);
-    if (T.h_bot > 0) hipLaunchKernelGGL(k_pack_rows, dim3((w + 255) / 256, T.h_bot, ch + 1), blk, 0, T.c->stream, T.snd_bot, T.acc, w, T.hl, T.p.own1 - T.p.Y0, T.h_bot);
-    HIPCHK(T.c, hipGetLastError());
+    if (T.h_top + T.h_bot > 0) {
+      const RowSide a{T.snd_top, 0, T.h_top}, b{T.snd_bot, T.p.own1 - T.p.Y0, T.h_bot};
+      hipLaunchKernelGGL(k_pack_rows, dim3((w + 255) / 256, T.h_top + T.h_bot, ch + 1), dim3(256), 0, T.c->stream, T.acc, w, T.hl, a, b);
+      HIPCHK(T.c, hipGetLastError());
+    }
     HIPCHK(T.c, hipEventRecord(T.ev_packed, T.c->stream));
   }
   // (6) accumulator halos to their owners, added on arrival; (7) own rows normalised
@@ -276,7 +288,8 @@ int enqueue_step(nlk_strips* S) {
     const int up = T.rank - 1, dn = T.rank + 1;
     const size_t plane = (size_t)w * (ch + 1);
     if (S->world > 1) {
-      if (S->rccl) {
+      if (S->dry) {
+      } else if (S->rccl) {
         NCCLCHK(T.c, g_rccl.GroupStart());
         if (up >= 0) {
           NCCLCHK(T.c, g_rccl.Send(T.snd_top, plane * T.h_top, ncclFloat, up, S->comm, T.c->stream));
@@ -301,10 +314,11 @@ int enqueue_step(nlk_strips* S) {
           if (rc) return rc;
         }
       }
-      const dim3 blk(256);
-      if (up >= 0) hipLaunchKernelGGL(k_add_rows, dim3((w + 255) / 256, T.n_up, ch + 1), blk, 0, T.c->stream, T.acc, T.rcv_top, w, T.hl, T.p.own0 - T.p.Y0, T.n_up);
-      if (dn < S->world) hipLaunchKernelGGL(k_add_rows, dim3((w + 255) / 256, T.n_dn, ch + 1), blk, 0, T.c->stream, T.acc, T.rcv_bot, w, T.hl, T.p.own1 - T.n_dn - T.p.Y0, T.n_dn);
-      HIPCHK(T.c, hipGetLastError());
+      if (T.n_up + T.n_dn > 0) {
+        const RowSide a{T.rcv_top, T.p.own0 - T.p.Y0, T.n_up}, b{T.rcv_bot, T.p.own1 - T.n_dn - T.p.Y0, T.n_dn};
+        hipLaunchKernelGGL(k_add_rows, dim3((w + 255) / 256, T.n_up + T.n_dn, ch + 1), dim3(256), 0, T.c->stream, T.acc, w, T.hl, a, b);
+        HIPCHK(T.c, hipGetLastError());
+      }
     }
     int rc = tick(T, PH_NORM);
     if (rc) return rc;
@@ -314,7 +328,7 @@ int enqueue_step(nlk_strips* S) {
   }
   // (nobody may overwrite a buffer a local neighbour still reads: the next step's first writes - the halo
   // rows of `prev`, the packed accumulator rows - wait for the neighbours' step to be over)
-  if (!S->rccl && S->world > 1)
+  if (!S->rccl && !S->dry && S->world > 1)
     for (Strip& T : S->s) {
       HIPCHK(T.c, hipSetDevice(T.device));
       for (int r : {T.rank - 1, T.rank + 1})
@@ -405,6 +419,7 @@ int nlk_strips_create(nlk_strips** out, int nlocal, const int* devices, int rank
       if ((rc = nlk_dev_alloc(T.c, bufs[b], sizes[b])) || (rc = nlk_dev_zero(T.c, *bufs[b], sizes[b]))) { nlk_strips_destroy(S); return rc; }
     }
     T.comm = T.c->aux_stream;
+    (void)nlk_ctx_set_strip_accumulator(T.c, T.acc);   // (cleared row by row by the layout kernel of every step)
     bool ok = hipSetDevice(T.device) == hipSuccess;
     for (hipEvent_t* e : {&T.ev_start, &T.ev_prev, &T.ev_match, &T.ev_group, &T.ev_packed})
       ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
@@ -475,6 +490,15 @@ int nlk_strips_load(nlk_strips* S, int local, const float* cur_full, const float
   return nlk_sync(T.c);
 }
 
+// One rank of a larger world run ALONE, every exchange skipped (its halo rows and the other strips' mark words are
+// whatever the buffers hold: the output means nothing): what a rank's step costs in kernels and launch gaps at
+// that world size, measurable on a one-GPU box. bench.py --strip-model.
+int nlk_strips_set_dry_run(nlk_strips* S, int on) {
+  if (!S) return NLK_EINVAL;
+  S->dry = on != 0;
+  return NLK_OK;
+}
+
 int nlk_strips_set_options(nlk_strips* S, int overlap, int timing, int graph) {
   if (!S) return NLK_EINVAL;
   S->overlap = overlap != 0;
@@ -490,7 +514,7 @@ int nlk_strips_set_options(nlk_strips* S, int overlap, int timing, int graph) {
 // One frame step on every local strip. Asynchronous: returns when everything is enqueued.
 int nlk_strips_step(nlk_strips* S) {
   if (!S) return NLK_EINVAL;
-  if (S->world > 1 && S->nlocal == 1 && !S->rccl)
+  if (S->world > 1 && S->nlocal == 1 && !S->rccl && !S->dry)
     return sfail(S, NLK_EINVAL, "one strip of several in this process: nlk_strips_rccl_init first", nullptr);
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);

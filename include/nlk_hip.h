@@ -208,6 +208,10 @@ int nlk_dev_strip_match_part(nlk_ctx *ctx, const float *cur, const float *prev,
                              const struct nlkalman_params *prms, int oy, int ngy,
                              int smoother, int r0, int rows, int lay0, int lay1, int v0, int v1,
                              void *marks_out, int *reach);
+/* Strip calls: a planar (ch+1, h, w) accumulator of the strip whose rows nlk_dev_strip_match* clear while they
+ * lay the same pixel rows out (all of them over a strip's calls) - saves the caller a separate clear per step.
+ * NULL (the default) switches it off. */
+int nlk_ctx_set_strip_accumulator(nlk_ctx *ctx, float *acc);
 int nlk_dev_mask_commit(nlk_ctx *ctx, const void *marks, int ngx, int ngy, int reach,
                         unsigned char *active);
 int nlk_dev_strip_group(nlk_ctx *ctx, float *acc, const unsigned char *active);
@@ -248,6 +252,9 @@ int nlk_strips_load(nlk_strips *s, int local, const float *cur_full, const float
  * synchronisation per step (diagnosis); graph: capture the step into a HIP graph once and replay it (one strip
  * per process; falls back to plain launches by itself if the capture is refused) */
 int nlk_strips_set_options(nlk_strips *s, int overlap, int timing, int graph);
+/* a model, not a result: one rank of a larger world stepped ALONE with every exchange skipped (the output means
+ * nothing) - what its kernels and launch gaps cost at that world size on a box with one GPU */
+int nlk_strips_set_dry_run(nlk_strips *s, int on);
 int nlk_strips_step(nlk_strips *s);
 int nlk_strips_sync(nlk_strips *s);
 /* own rows [*y0, *y1) of the output of local strip `local` (device pointer, valid until the next step); the
