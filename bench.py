@@ -454,7 +454,7 @@ def main():
                     raise RuntimeError("no RCCL id from rank 0")
                 cs = pkg.Strips([local], rank, world, w, h, ch, sigma, p)
                 cs.rccl_init(ident[0])
-                cs.set_options(overlap=True, timing=False, graph=args.strip_graph)
+                cs.set_options(overlap=False, timing=False, graph=args.strip_graph)
                 cs.load(0, t_n1.data_ptr(), t_prev.data_ptr())
             except Exception as e:                                           # noqa: BLE001
                 c_driver_note = c_driver_note or f"C strip driver not usable on rank {rank}: {e}"
@@ -512,7 +512,7 @@ def main():
     # on the context's stream (the timed loop above runs the same single-stream order, unprofiled).
     if cs is not None:
         _, issue_us, replayed = cs.stats()          # (of the timed loop)
-        cs.set_options(overlap=True, timing=False, graph=False)   # (a replayed graph carries no profiling events)
+        cs.set_options(overlap=False, timing=False, graph=False)   # (a replayed graph carries no profiling events)
     ctx.set_profiling(True)
     for _ in range(args.steps):
         one_step()
@@ -546,12 +546,12 @@ def main():
         strip_info = {"driver": "C (csrc/strips.hip), one call per step", "transport": cs.transport(),
                       "enqueue_us_per_step": round(issue_us, 1), "hip_graph": replayed}
         if args.phase_times:
-            cs.set_options(overlap=True, timing=True, graph=False)
+            cs.set_options(overlap=False, timing=True, graph=False)
             for _ in range(args.steps):
                 one_step()
             barrier()
             phase_ms = cs.stats()[0]
-            cs.set_options(overlap=True, timing=False, graph=False)
+            cs.set_options(overlap=False, timing=False, graph=False)
     elif striped and args.workload != "C5":
         strip_info = {"driver": "Python (strips.py over torch.distributed)"}
         if c_driver_note:
@@ -685,7 +685,7 @@ def main():
                 for graph in (False, True):
                     m = pkg.Strips([local], nw // 2, nw, w, h, ch, sigma, p)
                     m.set_dry_run(True)
-                    m.set_options(overlap=True, timing=False, graph=graph)
+                    m.set_options(overlap=False, timing=False, graph=graph)
                     m.load(0, t_n1.data_ptr(), t_prev.data_ptr())
                     for _ in range(5):
                         m.step()

@@ -496,7 +496,7 @@ class Strips:
     def load(self, local, d_cur_full, d_prev_full):
         self._chk(self.L.nlk_strips_load(self.h, local, d_cur_full, d_prev_full))
 
-    def set_options(self, overlap=True, timing=False, graph=False):
+    def set_options(self, overlap=False, timing=False, graph=False):
         self._chk(self.L.nlk_strips_set_options(self.h, int(overlap), int(timing), int(graph)))
 
     def set_dry_run(self, on=True):

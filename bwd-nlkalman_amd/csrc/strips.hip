@@ -122,7 +122,7 @@ struct nlk_strips {
   std::vector<StripPlan> plan;       // every rank of the world
   std::vector<Strip> s;              // the local ones
   ncclComm_t comm = nullptr;
-  bool rccl = false, overlap = true, have_prev = true, timing = false, want_graph = false, graph_failed = false;
+  bool rccl = false, overlap = false, have_prev = true, timing = false, want_graph = false, graph_failed = false;
   bool dry = false;  // nlk_strips_set_dry_run: exchanges skipped (one rank of a larger world timed alone)
   int timed_steps = 0, steps_done = 0;
   double phase_ms[PH_N] = {}, issue_us = 0;
@@ -220,8 +220,9 @@ int enqueue_step(nlk_strips* S) {
     const float* pv = S->have_prev ? T.prev : nullptr;
     int reach = 0;
     const bool halo = S->have_prev && S->world > 1 && (T.rank > 0 || T.rank < S->world - 1);
-    // (the split costs two more rounds of the matching launches: worth it only while the interior is most of a
-    // sizeable strip - at 1080p up to 3-4 strips; thin strips match in one go behind the halo's arrival)
+    // (optional, off by default: the split costs two more rounds of the matching launches - ~70 us at 1080p with
+    // 2 or 4 strips, measured on a rank stepped alone - against the < 0.5 MB halo exchange it hides; and only
+    // while the interior is most of a sizeable strip)
     if (halo && S->overlap && T.i1 - T.i0 >= 48 && 4 * (T.i1 - T.i0) >= 3 * T.rows) {
       const int o0 = T.p.own0 - T.p.Y0, o1 = T.p.own1 - T.p.Y0, hl = T.hl;
       SCHK(S, T.c, nlk_dev_strip_match_part(T.c, T.cur, pv, nullptr, w, hl, ch, S->sigma, &S->P, T.oy, T.rows, S->smoother,

@@ -248,7 +248,8 @@ const char *nlk_strips_transport(const nlk_strips *s);
 /* rows of full device-resident HWC frames (on that strip's device) into local strip `local`: cur with its halo,
  * prev with its OWN rows only (may be NULL) */
 int nlk_strips_load(nlk_strips *s, int local, const float *cur_full, const float *prev_full);
-/* overlap: match the interior rows while the halo travels (default 1); timing: per-phase device times, one
+/* overlap: match the interior rows while the halo travels (default 0: the two extra rounds of matching launches
+ * cost more than the exchange they hide at 1080p); timing: per-phase device times, one
  * synchronisation per step (diagnosis); graph: capture the step into a HIP graph once and replay it (one strip
  * per process; falls back to plain launches by itself if the capture is refused) */
 int nlk_strips_set_options(nlk_strips *s, int overlap, int timing, int graph);
