@@ -236,10 +236,20 @@ __device__ __forceinline__ void nlk_block_rows(const float* __restrict__ tile, i
       }
   }
 }
+// window position (wy << 16) | wx of candidate lane + 64 m
+template <int M>
+__device__ __forceinline__ void nlk_window_xy(int wsz, int n, int lane, uint32_t (&wxy)[M]) {
+  const int nwx = 2 * wsz + 1;
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int i = min(lane + 64 * m, n - 1);
+    const int wy = i / nwx, wx = i - wy * nwx;
+    wxy[m] = ((uint32_t)wy << 16) | (uint32_t)wx;
+  }
+}
 template <int PSZ, int CH, int BX, int M>
 __device__ __forceinline__ void nlk_match_block(const float* __restrict__ tile, int plane, int rwp, int tbase,
-                                                int wsz, int n, int lane, float (&acc)[2][BX][M],
-                                                uint32_t (&wxy)[M]) {
+                                                int wsz, int n, int lane, float (&acc)[2][BX][M]) {
   constexpr int step = PSZ / 2;
   const int nwx = 2 * wsz + 1;
   int cq[M];
@@ -247,7 +257,6 @@ __device__ __forceinline__ void nlk_match_block(const float* __restrict__ tile, 
   for (int m = 0; m < M; ++m) {
     const int i = min(lane + 64 * m, n - 1);
     const int wy = i / nwx, wx = i - wy * nwx;
-    wxy[m] = ((uint32_t)wy << 16) | (uint32_t)wx;
     cq[m] = tbase + (wy - wsz) * rwp + (wx - wsz);
 #pragma unroll
     for (int by = 0; by < 2; ++by)
@@ -499,8 +508,14 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
     auto run_block = [&](auto mtag) {
       constexpr int M = decltype(mtag)::value;
       float acc[2][BX][M];
+      nlk_match_block<PSZ, CH, BX, M>(tile, plane, rwp, (py0 - ry0) * rwp + (px0 - rx0), wsz, n, lane, acc);
+      // (the window positions are only needed by the selection: worked out AFTER the row loops - carried through
+      // them they were spilled to scratch at the 64-register budget, 85 MB of traffic per 1080p launch in round 3;
+      // the asm keeps the compiler from hoisting the division back in front of the loops)
+      int wsz_late = wsz;
+      asm volatile("" : "+v"(wsz_late) : "v"(acc[0][0][0]), "v"(acc[1][BX - 1][M - 1]));
       uint32_t wxy[M];
-      nlk_match_block<PSZ, CH, BX, M>(tile, plane, rwp, (py0 - ry0) * rwp + (px0 - rx0), wsz, n, lane, acc, wxy);
+      nlk_window_xy<M>(wsz_late, n, lane, wxy);
 #pragma unroll 1
       for (int j = 0; j < BX * BY; ++j) {
         float a2[M];
