@@ -625,6 +625,10 @@ def main():
                 "achieved": round(tfl, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                 "launch_ms": round(tm[dom + "_ms"], 4),
+                # (round 3's figure for comparison: every term of SURVEY.md §8(d) - transforms, statistics, gains,
+                # aggregation - over the f32 peak; `frac` above is the transforms alone)
+                "frac_all_survey_terms": (round((group_flops + nother_total) / world / dur / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
+                                          if dom == "group" and dur > 0 else None),
                 "algorithmic_flops_per_launch": int(alg_flops[dom] / world),
                 "algorithmic_bytes_per_launch": alg_bytes[dom] // world,
                 "hbm": {"achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
