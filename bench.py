@@ -449,22 +449,34 @@ def main():
                     c_driver_note = f"C strip driver not usable on rank 0: {e}"
             if world > 1:
                 dist.broadcast_object_list(ident, src=0)                     # (every rank takes part, whatever happened)
+            def everybody(ok):   # (the communicator's creation is collective: nobody enters it unless everybody can)
+                if world == 1:
+                    return ok
+                okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+                return int(okt.item()) == 1
             try:
                 if ident[0] is None:
                     raise RuntimeError("no RCCL id from rank 0")
-                cs = pkg.Strips([local], rank, world, w, h, ch, sigma, p)
-                cs.rccl_init(ident[0])
-                cs.set_options(overlap=False, timing=False, graph=args.strip_graph)
-                cs.load(0, t_n1.data_ptr(), t_prev.data_ptr())
+                cs = pkg.Strips([local], rank, world, w, h, ch, sigma, p)        # local: buffers, contexts
             except Exception as e:                                           # noqa: BLE001
                 c_driver_note = c_driver_note or f"C strip driver not usable on rank {rank}: {e}"
                 cs = None
-            if world > 1:
-                okt = torch.tensor([0 if cs is None else 1], dtype=torch.int32, device=dev)
-                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-                if int(okt.item()) == 0 and cs is not None:
+            if everybody(cs is not None):
+                try:
+                    cs.rccl_init(ident[0])                                   # collective: ncclCommInitRank
+                    cs.set_options(overlap=False, timing=False, graph=args.strip_graph)
+                    cs.load(0, t_n1.data_ptr(), t_prev.data_ptr())
+                    ok = True
+                except Exception as e:                                       # noqa: BLE001
+                    c_driver_note, ok = f"C strip driver: RCCL set-up failed on rank {rank}: {e}", False
+                if not everybody(ok):
+                    c_driver_note = c_driver_note or "C strip driver: RCCL set-up failed on another rank"
                     cs.close()
-                    cs, c_driver_note = None, "C strip driver not usable on another rank"
+                    cs = None
+            elif cs is not None:
+                cs.close()
+                cs, c_driver_note = None, "C strip driver not usable on another rank"
         if cs is not None:
             ctx = pkg.Context.from_handle(cs.L.nlk_strips_ctx(cs.h, 0))   # the strip's own context: its timings and records
             one_step = cs.step
