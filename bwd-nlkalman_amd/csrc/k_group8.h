@@ -58,6 +58,9 @@ struct NlkGTile {
   // two launches with a tile halo each (far = 0: the former only, far = 1: the latter only), so that
   // no member ever leaves its tile.
   int split, far;   // split != 0: this launch takes only the targets of kind `far`
+  // k_group8m: start of the allocation that holds every planar image of the call (nlk_ctx::planes, < 4 GiB):
+  // patches are addressed as this base + a 32-bit byte offset
+  const float* pbase;
 };
 
 // does this target's group reach beyond the temporal radius? (np0 = its candidates with a valid previous patch)

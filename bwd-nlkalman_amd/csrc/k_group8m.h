@@ -60,6 +60,21 @@ __device__ __forceinline__ uint32_t nlk_bperm_u(uint32_t v, int src_lane) {
 // rows g4 and 7-g4 of the 8x8 patch at p (row stride w). Always executed: slots without
 // a patch are pointed at some valid patch by the caller and masked out later (loads under
 // divergent control flow would make the compiler wait for every load in flight).
+// ... the same rows addressed as ONE base pointer (wave-uniform: scalar registers) + 32-bit byte offsets per lane:
+// the loads take the "scalar base + vector offset" form and a step's address arithmetic is two 32-bit adds
+// instead of five 64-bit ones. `e` = element offset of the patch from `base` (image and channel plane included),
+// rowa / rowb = g4 * w and (7 - g4) * w. Every image of a frame call lives in one allocation of less than 4 GiB
+// (nlk_hip.hip: plan_frame), so a byte offset fits 32 bits.
+__device__ __forceinline__ void nlk_rows_load32(const float* __restrict__ base, uint32_t e, uint32_t rowa, uint32_t rowb,
+                                                float (&R)[16]) {
+  typedef const __attribute__((address_space(1))) nlk_f4u* gp4;
+  const char* b = reinterpret_cast<const char*>(base);
+  const uint32_t oa = (e + rowa) * 4u, ob = (e + rowb) * 4u;
+  const nlk_f4u a0 = *(gp4)(b + (size_t)oa), a1 = *(gp4)(b + (size_t)oa + 16), b0 = *(gp4)(b + (size_t)ob), b1 = *(gp4)(b + (size_t)ob + 16);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { R[c] = a0[c]; R[4 + c] = a1[c]; R[8 + c] = b0[c]; R[12 + c] = b1[c]; }
+}
+
 __device__ __forceinline__ void nlk_rows_load(const float* __restrict__ p, int w, int g4,
                                               float (&R)[16]) {
   // (explicit global address space: a pointer selected at run time would otherwise be
@@ -243,7 +258,10 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   const size_t npix = (size_t)g.w * g.h;
   float* acc_p = acc + (size_t)(agg_on ? g4 : 0) * npix;
   const float* src = g.have_basic ? cur : img;  // patches that get filtered
-  const ptrdiff_t prev_off = prev ? prev - img : 0;  // (an offset, not a second base pointer, keeps the loads global)
+  // the planar images as element offsets from one base (tl.pbase = the start of the context's image slab)
+  const float* const pbase = tl.pbase;
+  const uint32_t e_img = (uint32_t)(img - pbase), e_src = (uint32_t)(src - pbase), e_prev = prev ? (uint32_t)(prev - pbase) : e_img;
+  const uint32_t rowa = (uint32_t)(g4 * g.w), rowb = (uint32_t)((7 - g4) * g.w);
   const float s2 = g.sigma2;
   // pass-B role of the lane as a load slot: channel / member of slot lo
   const int bch = lo >> 2, bm = lo & 3;
@@ -337,37 +355,37 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       const bool slot_prev = HP && ((lo >> 1) & 1);
       const uint32_t live_need = MODE == 1 ? 0x80000000u : (slot_prev ? 0x80000000u : 0u);
       // slot lo's patch in step bb: offset into an image plane, and whether it is the previous frame's
-      auto slot_off = [&](int bb, bool& prevsel) -> int {
+      // (element offset from the base: the image's or - for a live previous-frame slot - the previous frame's plane 0)
+      const uint32_t e_slot = slot_prev ? e_prev : e_img, e_dead = o_first + e_img;
+      auto slot_off = [&](int bb) -> uint32_t {
         const int ci = CB * bb + slot_c, cl = min(ci, k - 1);
         const uint32_t oc = nlk_bperm_u(cl < 64 ? oreg[0] : oreg[1], cl & 63);
         const bool live = ci < k && (oc & live_need) == live_need;
-        prevsel = live && slot_prev;
-        return live ? (int)(oc & 0x7fffffffu) : (int)o_first;
+        return live ? (oc & 0x7fffffffu) + e_slot : e_dead;
       };
-      // rows g4 and 7-g4 of the patch at `off` of channel cc
-      auto rows_read = [&](int off, bool prevsel, int cc, float (&R)[16]) {
-        nlk_rows_load(img + (prevsel ? prev_off : (ptrdiff_t)0) + (size_t)cc * npix + off, g.w, g4, R);
+      // rows g4 and 7-g4 of the patch at element offset `off` (plane 0) of channel cc
+      auto rows_read = [&](uint32_t off, int cc, float (&R)[16]) {
+        nlk_rows_load32(pbase, off + (uint32_t)cc * (uint32_t)npix, rowa, rowb, R);
       };
       float R[16], F[4][4];
-      bool p0sel, pnsel;
-      const int o_step0 = slot_off(0, p0sel);
-      rows_read(o_step0, p0sel, 0, R);
-      int onext = slot_off(1, pnsel);
+      const uint32_t o_step0 = slot_off(0);
+      rows_read(o_step0, 0, R);
+      uint32_t onext = slot_off(1);
       for (int ch = 0; ch < CH; ++ch)
       for (int b = 0; b < nb; ++b) {
         nlk_fold(R, F);
         // the next step's rows; after a channel's last step the next channel's first (after the very
         // last step: a harmless reload)
         const bool wrap = b + 1 == nb;
-        int o_load = wrap ? o_step0 : onext;
+        uint32_t o_load = wrap ? o_step0 : onext;
         // The reload below reuses R (no second register set). A sched_barrier alone does not order it: the fold has no
         // side effects, so instruction selection placed it BEHIND the loads and paid 16 v_mov per step to keep the
         // rows alive. The empty statement makes the load address depend on it: the folded values exist before the
         // loads are issued.
         NLK_PIN_FOLD(F, o_load);
         __builtin_amdgcn_sched_barrier(0);
-        rows_read(o_load, wrap ? p0sel : pnsel, wrap ? min(ch + 1, CH - 1) : ch, R);
-        onext = slot_off(wrap ? 1 : b + 2, pnsel);
+        rows_read(o_load, wrap ? min(ch + 1, CH - 1) : ch, R);
+        onext = slot_off(wrap ? 1 : b + 2);
         __builtin_amdgcn_sched_barrier(0);
         nlk_f4 C[4];
         if (b == 0) {
@@ -487,19 +505,19 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     // (slot lo = 4*channel + member; slots without a member / channel read a valid patch
     // and their results are not used)
     const int bchc = min(bch, CH - 1);
-    auto member_off = [&](int n0) -> int {
+    auto member_off = [&](int n0) -> uint32_t {   // (element offset inside an image: channel plane + patch)
       const int n = min(n0 + bm, nagg - 1);
       const uint32_t qm = nlk_bperm_u(n < 64 ? greg[0] : greg[1], n & 63);
-      return bchc * (int)npix + nlk_y(qm) * g.w + nlk_x(qm);
+      return (uint32_t)bchc * (uint32_t)npix + (uint32_t)(nlk_y(qm) * g.w + nlk_x(qm));
     };
-    const float* psrc = passthrough ? src : prev;  // (smoother) previous-frame patches
+    const uint32_t e_psrc = passthrough ? e_src : e_prev;  // (smoother) previous-frame patches
     float R[16], Rp[16], F[4][4];
     {
-      const int off = member_off(0);
-      nlk_rows_load(src + off, g.w, g4, R);
-      if (SMO) nlk_rows_load(psrc + off, g.w, g4, Rp);
+      const uint32_t off = member_off(0);
+      nlk_rows_load32(pbase, e_src + off, rowa, rowb, R);
+      if (SMO) nlk_rows_load32(pbase, e_psrc + off, rowa, rowb, Rp);
     }
-    int offn = member_off(4);
+    uint32_t offn = member_off(4);
     // Where every member lands in the tile, worked out once per target with one member per lane: its offset
     // (floats) inside a plane, and one bit per member "inside the tile" (entries past the last member count as
     // inside). A step whose four members are all inside - every step of a temporal target: the tile's halo is
@@ -538,11 +556,11 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         for (int c = 0; c < 16; ++c) R[c] = Rp[c] - R[c];
       }
       nlk_fold(R, F);
-      nlk_rows_load(src + offn, g.w, g4, R);
+      nlk_rows_load32(pbase, e_src + offn, rowa, rowb, R);
 #pragma unroll
       for (int q = 0; q < 4; ++q) Y[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
       if (SMO) {
-        nlk_rows_load(psrc + offn, g.w, g4, Rp);
+        nlk_rows_load32(pbase, e_psrc + offn, rowa, rowb, Rp);
         offn = member_off(n0 + 8);
         __builtin_amdgcn_sched_barrier(0);
         nlk_mfma_fwd<true>(F, dA, Y);

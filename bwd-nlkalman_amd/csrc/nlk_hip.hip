@@ -182,7 +182,7 @@ void nlk_ctx_destroy(nlk_ctx* c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
-  Buf* bufs[] = {&c->pl_cur, &c->pl_prev, &c->pl_basic, &c->rowok, &c->vmap, &c->topk,
+  Buf* bufs[] = {&c->planes, &c->rowok, &c->vmap, &c->topk,
                  &c->tinfo, &c->gcoords, &c->marks, &c->active, &c->acc, &c->tabs, &c->wide, &c->tv, &c->skew, &c->ms,
                  &c->slab, &c->tflag, &c->hw_cur, &c->hw_prev, &c->hw_basic, &c->hw_out};
   for (Buf* b : bufs)
@@ -420,11 +420,14 @@ static NlkGeom band_geom(const NlkGeom& g, int r0, int rows) {
 // the validity map's column test for the rows [v0, v1) (a row needs the row tests of the psz rows from it on)
 static int layout_rows(nlk_ctx* c, const float* cur, const float* prev, const float* basic, float* acc_zero, int w,
                        int h, int ch, int psz, int y0, int y1, int v0, int v1) {
-  const bool planar = ch != 1;  // (one channel: planar == interleaved)
-  if (y1 > y0 && (planar || prev || acc_zero))
-    hipLaunchKernelGGL(k_layout, dim3((w + 255) / 256, y1 - y0), dim3(256), 0, c->stream, cur, (float*)c->pl_cur.p, prev,
-                       (float*)c->pl_prev.p, basic, (float*)c->pl_basic.p, (uint8_t*)c->rowok.p, acc_zero, w, h, ch, psz,
-                       planar ? 1 : 0, y0);
+  // (every image is copied into the context's slab, one channel too: the group kernel addresses all of them from
+  // one base pointer)
+  const size_t img_floats = (size_t)w * h * ch;
+  float* const slab = (float*)c->planes.p;
+  if (y1 > y0)
+    hipLaunchKernelGGL(k_layout, dim3((w + 255) / 256, y1 - y0), dim3(256), 0, c->stream, cur, slab, prev,
+                       slab + img_floats, basic, slab + 2 * img_floats, (uint8_t*)c->rowok.p, acc_zero, w, h, ch, psz,
+                       1, y0);
   if (prev && v1 > v0) {
     if (w % 4 == 0)
       hipLaunchKernelGGL(k_nan_cols4, dim3((w / 4 + 255) / 256, v1 - v0), dim3(256), 0, c->stream,
@@ -490,16 +493,12 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   // ---- layout: planar copies + the row test of the validity map (+ clearing the accumulator of a
   // whole-frame call) in one kernel, the column test in a second
   {
-    const bool planar = ch != 1;  // (one channel: planar == interleaved, the images are used in place)
-    pl.img_cur = cur; pl.img_prev = prev; pl.img_basic = basic;
-    if (planar) {
-      if ((rc = reserve(c, c->pl_cur, sizeof(float) * (size_t)npix * ch))) return rc;
-      if (prev && (rc = reserve(c, c->pl_prev, sizeof(float) * (size_t)npix * ch))) return rc;
-      if (basic && (rc = reserve(c, c->pl_basic, sizeof(float) * (size_t)npix * ch))) return rc;
-      pl.img_cur = (const float*)c->pl_cur.p;
-      if (prev) pl.img_prev = (const float*)c->pl_prev.p;
-      if (basic) pl.img_basic = (const float*)c->pl_basic.p;
-    }
+    // planar copies of the (up to) three images in ONE allocation: [cur | prev | basic]
+    const size_t img_floats = (size_t)npix * ch;
+    if ((rc = reserve(c, c->planes, sizeof(float) * img_floats * (basic ? 3 : (prev ? 2 : 1))))) return rc;
+    pl.img_cur = (const float*)c->planes.p;
+    pl.img_prev = prev ? pl.img_cur + img_floats : nullptr;
+    pl.img_basic = basic ? pl.img_cur + 2 * img_floats : nullptr;
     if (prev && ((rc = reserve(c, c->rowok, npix)) || (rc = reserve(c, c->vmap, npix)))) return rc;
     if (do_layout) {
       int rc2 = layout_rows(c, cur, prev, basic, acc_zero, w, h, ch, g.psz, 0, h, 0, h);

@@ -72,7 +72,8 @@ struct nlk_ctx {
   uint64_t* marks_ext = nullptr;     // strip calls: the matcher writes its mark words straight into the caller's array
   float* strip_acc = nullptr;        // strip calls: accumulator whose rows the layout kernel clears as it lays them out
   char err[512] = "";
-  NlkBuf pl_cur, pl_prev, pl_basic, rowok, vmap, topk, tinfo, gcoords, marks, active, acc, tabs, wide;
+  NlkBuf planes;                  // the planar copies of cur | prev | basic, one allocation (32-bit offsets between them: k_group8m.h)
+  NlkBuf rowok, vmap, topk, tinfo, gcoords, marks, active, acc, tabs, wide;
   NlkBuf skew;                    // mark words in replay-step order (k_marks_skew)
   NlkBuf ms;                      // whole-image DCT: temporary image + the two basis matrices
   NlkBuf tv;                      // TV-L1 pyramids and work images

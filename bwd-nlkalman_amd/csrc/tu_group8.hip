@@ -14,6 +14,14 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
   // psz 8 runs its DCTs on the matrix cores (k_group8m.h); NLK_GROUP_DPP selects the
   // register/DPP kernel (k_group8.h) for comparison
   const bool mfma = !nlk_set(c->sw.group_dpp);
+  // (k_group8m addresses every patch as planes base + a 32-bit byte offset: the call's images must lie in the
+  // context's slab and the slab be smaller than 4 GiB - ~119 Mpixel of RGB; beyond that the packed-lane kernel)
+  if (mfma) {
+    const float* lo = (const float*)c->planes.p;
+    const float* hi = lo + c->planes.cap / sizeof(float);
+    const bool inside = img >= lo && img < hi && cur >= lo && cur < hi && (!prev || (prev >= lo && prev < hi));
+    if (!inside || c->planes.cap >= ((size_t)1 << 32)) return nlk_launch_groupp_a(c, g, img, cur, prev, acc, active);
+  }
   if (c->deterministic && !mfma)
     return fail(c, NLK_EUNSUP, "deterministic aggregation is not available in the NLK_GROUP_DPP variant");
   // Deterministic mode runs a temporal frame's far-reaching (spatial-branch) groups in a second
@@ -22,6 +30,7 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
   // the tiles of a pass: halo, targets per tile, LDS strides
   auto shape = [&](int pass) {
     NlkGTile tl{};
+    tl.pbase = (const float*)c->planes.p;
     tl.split = split;
     tl.far = pass;
     // LDS tile halo = reach of the dominant kind of group; without the split the rare spatial-branch
