@@ -5,10 +5,13 @@
 // In the reference a target is skipped when an EARLIER, non-skipped target's
 // group contained it. Whether a target is skipped therefore depends only on
 // integer records (group coordinates, np0) that the matching kernel already
-// produced for every target, not on any filtered pixel. Four replays, all exact:
+// produced for every target, not on any filtered pixel. Five replays, all exact:
 //   k_mask_commit_rows1   reach 1 (the steady state of the pipelines): one grid ROW per step on bit
 //                         planes, a carry chain per row solved word-parallel (below)
-//   k_mask_commit_wave<R> reach <= 3: anti-diagonal wavefront, lane = grid row, marks handed down by DPP
+//   k_mask_commit_rows<R> reach 2 and 3 (first frames of 8 x 8 patches, 12 x 12 patches): one grid row per step, the
+//                         chain inside the row solved by iteration to its fixed point
+//   k_mask_commit_wave<R> reach <= 3: anti-diagonal wavefront, lane = grid row, marks handed down by DPP (grids wider
+//                         than 2048 targets, NLK_COMMIT_WAVE=1)
 //   k_mask_commit<RPT>    the same wavefront with the mask as an LDS bitmap (first version, kept
 //                         for comparison)
 //   k_mask_commit_lists   any reach, from the group-coordinate lists
@@ -351,6 +354,111 @@ k_mask_commit_rows1(const uint32_t* __restrict__ planes, uint32_t* __restrict__ 
     }
   };
   uint32_t P[PF][4], Q[PF][4];
+  load_batch(P, first);
+  for (int j0 = 0; j0 < nrows; j0 += 2 * PF) {
+    load_batch(Q, first + j0 + PF);
+    run_batch(P, first + j0);
+    if (j0 + PF >= nrows) break;
+    load_batch(P, first + j0 + 2 * PF);
+    run_batch(Q, first + j0 + PF);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Reach 2 and 3 (spatial first frames of 8 x 8 patches, 12 x 12 patches): the same replay by grid ROWS.
+// A target (i, j) is skipped iff an active target of the R rows above marked it (columns i-R .. i+R: whole-row
+// bit-plane ANDs and shifts, accumulated per row below in A[1..R]), or one of its R left neighbours did:
+//   x_i = n_i & !(x_{i-1} & m1_{i-1}) & ... & !(x_{i-R} & mR_{i-R}),   n = not marked from above.
+// The system is triangular (x_i depends on columns to its left only), so the Jacobi iteration
+// x <- n & ~(shl(x & m1, 1) | ... | shl(x & mR, R)) from x = n reaches THE solution, and has reached it when
+// an iteration changes nothing; column i is final after at most i+1 iterations, in practice after the length
+// of the longest chain of left-marking neighbours (about ten at 1080p). 269 row steps of ~36 + 12 per
+// iteration vector instructions instead of 1015 diagonal steps of ~20.
+// planes[(j * NP + p) * 64 + word], NP = R + R (2R+1): p < R: marks (i+p+1, j); then dj = 1..R, di = -R..R.
+// ---------------------------------------------------------------------------
+template <int R>
+__global__ void __launch_bounds__(256)
+k_marks_planes(const uint64_t* __restrict__ marks, uint32_t* __restrict__ planes, int ngx, int j0) {
+  constexpr int side = 2 * R + 1, centre = R * side + R, NP = R + R * side;
+  const int j = j0 + blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t fwd = i < ngx ? (uint32_t)(marks[(size_t)j * ngx + i] >> (centre + 1)) : 0u;
+  const int lane = threadIdx.x & 63, w0 = i >> 5;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const uint64_t b = __ballot((fwd >> p) & 1u);
+    if (lane == 0) *(uint64_t*)(planes + ((size_t)j * NP + p) * 64 + w0) = b;
+  }
+}
+
+template <int R>
+struct NlkCommitRows {
+  static constexpr int side = 2 * R + 1, NP = R + R * side;
+  static constexpr int PF = 48 / NP;  // rows per batch of planes in flight (two register sets)
+};
+
+// astate[(j * R + k) * 64 + word]: the marks rows j-1, j-2, .. have left for row j + k when row j starts.
+template <int R>
+__global__ void __launch_bounds__(64)
+k_mask_commit_rows(const uint32_t* __restrict__ planes, uint32_t* __restrict__ actbits,
+                   uint32_t* __restrict__ astate, int ngx, int first, int nrows) {
+  constexpr int side = 2 * R + 1, NP = R + R * side, PF = NlkCommitRows<R>::PF;
+  const int lane = threadIdx.x;
+  const int nb = ngx - 32 * lane;
+  const uint32_t colmask = nb <= 0 ? 0u : (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u));
+  auto from_prev = [](uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+  };
+  auto from_next = [](uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
+  };
+  // whole-row shifts towards higher / lower columns by 1 <= d <= R bits
+  auto up = [&](uint32_t v, int d) { return __builtin_amdgcn_alignbit(v, from_prev(v), 32 - d); };
+  auto down = [&](uint32_t v, int d) { return __builtin_amdgcn_alignbit(from_next(v), v, d); };
+  const uint32_t* pp = planes + lane;
+  uint32_t* ap = actbits + lane;
+  uint32_t* sp = astate + lane;
+  uint32_t A[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) A[k] = first ? sp[((size_t)first * R + k) * 64] : 0u;
+  auto load_batch = [&](uint32_t (&D)[PF][NP], int jb) {
+    const uint32_t* q = pp + (size_t)jb * NP * 64;
+#pragma unroll
+    for (int r = 0; r < PF; ++r)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) D[r][p] = q[(r * NP + p) * 64];
+  };
+  auto run_batch = [&](const uint32_t (&D)[PF][NP], int jb) {
+    uint32_t* o = ap + (size_t)jb * 64;
+    uint32_t* so = sp + (size_t)(jb + 1) * R * 64;
+#pragma unroll
+    for (int r = 0; r < PF; ++r) {
+      if (jb + r >= first + nrows) break;  // (no row of the next band is replayed from planes not written yet)
+      const uint32_t n = ~A[0] & colmask;
+      uint32_t x = n;
+      for (;;) {
+        uint32_t blocked = 0;
+#pragma unroll
+        for (int d = 1; d <= R; ++d) blocked |= up(x & D[r][d - 1], d);
+        const uint32_t y = n & ~blocked;
+        const bool changed = y != x;
+        x = y;
+        if (!__ballot(changed)) break;
+      }
+      o[r * 64] = x;
+#pragma unroll
+      for (int dj = 1; dj <= R; ++dj) {
+        uint32_t cb = x & D[r][R + (dj - 1) * side + R];  // di = 0
+#pragma unroll
+        for (int di = 1; di <= R; ++di) {
+          cb |= up(x & D[r][R + (dj - 1) * side + R + di], di);
+          cb |= down(x & D[r][R + (dj - 1) * side + R - di], di);
+        }
+        A[dj - 1] = (dj < R ? A[dj] : 0u) | cb;
+        so[(r * R + dj - 1) * 64] = A[dj - 1];
+      }
+    }
+  };
+  uint32_t P[PF][NP], Q[PF][NP];
   load_batch(P, first);
   for (int j0 = 0; j0 < nrows; j0 += 2 * PF) {
     load_batch(Q, first + j0 + PF);

@@ -536,9 +536,10 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   {
     const int halo0 = (g.smoother || g.have_prev) ? g.wsz_t : g.wsz_x;
     const bool tiles84 = tl.tgx == 8 && tl.tgy == 4 && (nlk_set(c->sw.match_block) || !small_grid);  // (the tiles of a full-size frame)
+    // (the launcher's own condition, match_launch.h: blocks of 2 x 2 exist for MAXM 2, and for MAXM 7 at 8 x 8)
+    const int rounds0 = ((2 * halo0 + 1) * (2 * halo0 + 1) + 63) / 64;
     if (nlk_or(c->sw.match_wg8, 0) != 0 && g.psz <= 8 && tiles84) { tl.threads = 512; tl.tgy = 8; }
-    else if (nlk_or(c->sw.match_bx2, 1) != 0 && tiles84 &&
-             ((halo0 <= 6 && g.psz >= 8) || (g.psz == 8 && (2 * halo0 + 1) * (2 * halo0 + 1) <= 448))) {
+    else if (nlk_or(c->sw.match_bx2, 1) != 0 && tiles84 && g.psz >= 8 && (rounds0 <= 2 || (g.psz == 8 && rounds0 <= 7))) {
       // (... and the seven-round blocks of a first frame, 441 candidates: 2 x 2 targets per block need 128 registers
       // instead of 168 + spills, two 8-wavefront workgroups per CU instead of three of 4: match 0.947 -> 0.828)
       tl.threads = 512;
@@ -641,6 +642,29 @@ static int commit_rows(nlk_ctx* c, hipStream_t stream, const uint64_t* marks, ui
     HIPCHK(c, hipGetLastError());
     return NLK_OK;
   }
+  if (R <= 3 && ngx <= 2048 && !nlk_set(c->sw.commit_wave) && !nlk_set(c->sw.commit_lds) && !nlk_set(c->sw.commit_band)) {
+    // reach 2 / 3: the row formulation with the in-row chain solved by iteration (k_commit.h)
+    const int np = R + R * (2 * R + 1), pf = 48 / np;
+    const int rows_pad = (total + pf - 1) / pf * pf + 3 * pf;
+    int rc = reserve(c, c->skew, sizeof(uint32_t) * (size_t)rows_pad * (np + 1 + R) * 64);
+    if (rc) return rc;
+    uint32_t* planes = (uint32_t*)c->skew.p;
+    uint32_t* actbits = planes + (size_t)rows_pad * np * 64;
+    uint32_t* astate = actbits + (size_t)rows_pad * 64;
+    if (R == 2) {
+      hipLaunchKernelGGL(k_marks_planes<2>, dim3(8, nrows), dim3(256), 0, stream, marks, planes, ngx, first);
+      hipLaunchKernelGGL(k_mask_commit_rows<2>, dim3(1), dim3(64), 0, stream, (const uint32_t*)planes, actbits, astate,
+                         ngx, first, nrows);
+    } else {
+      hipLaunchKernelGGL(k_marks_planes<3>, dim3(8, nrows), dim3(256), 0, stream, marks, planes, ngx, first);
+      hipLaunchKernelGGL(k_mask_commit_rows<3>, dim3(1), dim3(64), 0, stream, (const uint32_t*)planes, actbits, astate,
+                         ngx, first, nrows);
+    }
+    hipLaunchKernelGGL(k_active_bytes, dim3((ngx + 255) / 256, nrows), dim3(256), 0, stream, (const uint32_t*)actbits,
+                       active, ngx, first);
+    HIPCHK(c, hipGetLastError());
+    return NLK_OK;
+  }
   if (R <= 3 && (first != 0 || !nlk_set(c->sw.commit_lds))) {
     // one lane per grid row, up to 1024 rows per launch; more rows in pieces that start with the
     // previous piece's last R rows as context (k_commit.h)
@@ -711,9 +735,10 @@ static int group_rows(nlk_ctx* c, hipStream_t stream, float* acc, const uint8_t*
 // gains. Kept as an option (and as the exactness test of banding); profiling always runs one band.
 static int frame_bands(const nlk_ctx* c, const NlkGeom& g) {
   if (c->profiling || c->deterministic || g.R == 0 || g.R > 3) return 1;  // (deterministic mode: one slab set, one sum order)
-  // default: one band where the replay is the row formulation (reach 1: 2 % of a frame); four where it
-  // is the diagonal one (reach 2 / 3, i.e. spatial frames of small patches: 0.28 ms of a 2.6 ms first
-  // frame at 1080p on one compute unit - with four bands 2.36 ms, with two 2.41, profiles/README.md round 3)
+  // default: one band for reach 1 (the replay is 2 % of a frame); four for reach 2 / 3, i.e. spatial frames of
+  // small patches: their replay was the diagonal one until round 4 (0.28 ms of a first frame at 1080p on one
+  // compute unit); as the iterated row replay it takes 0.08 ms, and four bands still win (first frame at 1080p:
+  // 2.09-2.10 ms with one band, 2.04-2.10 with two, 2.01-2.05 with four; 2.13 with the diagonal replay in four)
   int nb = nlk_or(c->sw.bands, g.R >= 2 ? 4 : 1);
   nb = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
   while (nb > 1 && g.ngy / nb < 4 * (g.R + 1) + 8) --nb;  // (thin bands: nothing to gain)

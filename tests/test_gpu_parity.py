@@ -574,12 +574,13 @@ def test_blocks_of_2x2_targets_equal_target_by_target(ctx, built, synth, monkeyp
                 assert np.array_equal(recs[0][f], other[f]), (psz, smo, f)
 
 
-@pytest.mark.parametrize("reach", [1, 2])
+@pytest.mark.parametrize("reach", [1, 2, 3])
 def test_mask_replay_on_synthetic_mark_words(ctx, O, monkeypatch, reach):
     """The processed-mask replay alone, on mark words no image produces: dense marks, rows where every
     target marks its right neighbour (runs of ones that fill whole 32-bit words, the carry fix-up of
-    k_mask_commit_rows1), grid widths around the word and lane limits. Reach 1 runs the row replay on
-    bit planes, NLK_COMMIT_WAVE=1 the diagonal replay; both must equal the oracle's serial loop."""
+    k_mask_commit_rows1; chains as long as the row for the iteration of k_mask_commit_rows<2|3>), grid widths
+    around the word and lane limits. The default is the row replay on bit planes, NLK_COMMIT_WAVE=1 the
+    diagonal replay; both must equal the oracle's serial loop."""
     rng = np.random.default_rng(7 + reach)
     side = 2 * reach + 1
     shapes = [(1, 1), (31, 5), (32, 9), (33, 17), (64, 3), (65, 40), (479, 37), (512, 8), (1000, 13), (2048, 5),

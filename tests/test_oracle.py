@@ -324,6 +324,81 @@ def test_row_formulation_of_the_mask_replay(O):
             assert np.array_equal(got, want), (ngx, ngy, density, right)
 
 
+def _rows_replay_iterated(marks, ngx, ngy, R):
+    """k_mask_commit_rows<R> on numpy uint32 words (k_commit.h): marks from above as plane ANDs and whole-row
+    shifts, the in-row chain by iteration to the fixed point."""
+    side = 2 * R + 1
+    centre = R * side + R
+    nw = (ngx + 31) // 32
+    U = np.uint32
+    fwd = (marks >> np.uint64(centre + 1)).astype(np.uint64).reshape(ngy, ngx)
+
+    def plane(j, p):
+        b = ((fwd[j] >> np.uint64(p)) & np.uint64(1)).astype(np.uint64)
+        out = np.zeros(nw, np.uint64)
+        np.bitwise_or.at(out, np.arange(ngx) >> 5, b << (np.arange(ngx, dtype=np.uint64) & np.uint64(31)))
+        return out.astype(U)
+
+    def up(v, d):
+        prev = np.concatenate(([0], v[:-1])).astype(U)
+        return ((v << U(d)) | (prev >> U(32 - d))).astype(U)
+
+    def down(v, d):
+        nxt = np.concatenate((v[1:], [0])).astype(U)
+        return ((v >> U(d)) | (nxt << U(32 - d))).astype(U)
+
+    colmask = np.array([0xFFFFFFFF if ngx - 32 * k >= 32 else (1 << (ngx - 32 * k)) - 1 for k in range(nw)], U)
+    A = [np.zeros(nw, U) for _ in range(R)]
+    act = np.zeros((ngy, ngx), np.uint8)
+    most = 0
+    for j in range(ngy):
+        D = [plane(j, p) for p in range(R + R * side)]
+        n = ~A[0] & colmask
+        x = n.copy()
+        it = 0
+        while True:
+            blocked = np.zeros(nw, U)
+            for d in range(1, R + 1):
+                blocked |= up(x & D[d - 1], d)
+            y = n & ~blocked
+            it += 1
+            if np.array_equal(x, y):
+                break
+            x = y
+        most = max(most, it)
+        act[j] = (x[np.arange(ngx) >> 5] >> (np.arange(ngx, dtype=U) & U(31))) & 1
+        new = []
+        for dj in range(1, R + 1):
+            cb = x & D[R + (dj - 1) * side + R]
+            for di in range(1, R + 1):
+                cb = cb | up(x & D[R + (dj - 1) * side + R + di], di) | down(x & D[R + (dj - 1) * side + R - di], di)
+            new.append((A[dj] if dj < R else np.zeros(nw, U)) | cb)
+        A = new
+    return act.ravel(), most
+
+
+@pytest.mark.parametrize("reach", [1, 2, 3])
+def test_iterated_row_formulation_of_the_mask_replay(O, reach):
+    """Reach 2 and 3 (spatial first frames, 12 x 12 patches) replay the mask by grid rows with the in-row
+    chain x_i = n_i & !(x_{i-1} & m1_{i-1}) & .. solved by iteration (k_mask_commit_rows<R>): a triangular
+    system, so the fixed point is the serial loop's answer (reference: src/nlkalman.c:597-600, 930-931), reached
+    within ngx + 1 iterations."""
+    rng = np.random.default_rng(50 + reach)
+    side = 2 * reach + 1
+    c = reach * side + reach
+    for ngx, ngy in ((1, 1), (31, 4), (32, 6), (33, 9), (64, 5), (97, 12), (130, 7)):
+        for density, right in ((0.5, 0.5), (0.9, 0.97), (0.15, 1.0), (1.0, 1.0), (0.05, 0.3)):
+            bits = rng.random((ngx * ngy, side * side)) < density
+            bits[:, c + 1] = rng.random(ngx * ngy) < right
+            if right == 1.0 and density < 1.0:
+                bits[:, c + 2:] &= (rng.random((ngx * ngy, 1)) < 0.3)
+            marks = (bits.astype(np.uint64) << np.arange(side * side, dtype=np.uint64)).sum(axis=1).astype(np.uint64)
+            want = O.mask_commit(marks, ngx, ngy, reach)
+            got, most = _rows_replay_iterated(marks, ngx, ngy, reach)
+            assert np.array_equal(got, want), (ngx, ngy, density, right)
+            assert most <= ngx + 1
+
+
 def test_image_smaller_than_a_patch_comes_back_unchanged(O):
     """reference: src/nlkalman.c:586-595 (`px < w - psz + 1`: no target), :939-942 (unaggregated pixels keep the input)"""
     rng = np.random.default_rng(2)
