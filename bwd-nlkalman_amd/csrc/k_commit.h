@@ -27,6 +27,7 @@
 // written to HBM inside the loop.
 #pragma once
 #include "nlk_common.h"
+#include "k_commit_rows.h"
 
 template <int RPT>  // grid rows per thread: row j = threadIdx.x + r * blockDim.x
 __global__ void __launch_bounds__(1024)
@@ -290,78 +291,17 @@ k_marks_planes1(const uint64_t* __restrict__ marks, uint32_t* __restrict__ plane
 // it is, so the loop is written for instruction count: fixed row strides (immediate offsets, no
 // predicates: planes and decisions are padded to whole batches), two register sets for the planes in
 // flight that swap roles (no copies).
-#define NLK_CR_BATCH 16  // rows per batch: the next batch's planes load while this one is replayed
 __global__ void __launch_bounds__(64)
-// Rows [first, first + nrows) of the grid; the only state a row hands to the next - `a`, the columns marked
-// from above - is kept per row in `astate` (row j's input at astate[j]), so that a grid replayed in bands
-// (one call per band, in order) continues where the band before stopped.
 k_mask_commit_rows1(const uint32_t* __restrict__ planes, uint32_t* __restrict__ actbits,
                     uint32_t* __restrict__ astate, int ngx, int first, int nrows) {
-  const int lane = threadIdx.x;
-  // columns of this word that exist
-  const int nb = ngx - 32 * lane;
-  const uint32_t colmask = nb <= 0 ? 0u : (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u));
-  auto from_prev = [](uint32_t v) {  // lane l <- lane l-1 (lane 0 <- 0)
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
-  };
-  auto from_next = [](uint32_t v) {  // lane l <- lane l+1 (lane 63 <- 0)
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
-  };
-  constexpr int PF = NLK_CR_BATCH;
-  const uint32_t* pp = planes + lane;
-  uint32_t* ap = actbits + lane;
-  uint32_t* sp = astate + lane;
-  uint32_t a = first ? sp[(size_t)first * 64] : 0u;  // marked from above
-  auto load_batch = [&](uint32_t (&D)[PF][4], int jb) {
-    const uint32_t* q = pp + (size_t)jb * 256;
-#pragma unroll
-    for (int r = 0; r < PF; ++r)
-#pragma unroll
-      for (int p = 0; p < 4; ++p) D[r][p] = q[(r * 4 + p) * 64];
-  };
-  auto run_batch = [&](const uint32_t (&D)[PF][4], int jb) {
-    uint32_t* o = ap + (size_t)jb * 64;
-    uint32_t* so = sp + (size_t)(jb + 1) * 64;
-#pragma unroll
-    for (int r = 0; r < PF; ++r) {  // (rows past the band in its last batch: decisions and states land in rows the
-                                    //  next band rewrites, or in the padding)
-      const uint32_t g = D[r][0] & ~a;
-      // carries, assuming no carry enters the word
-      const uint32_t sw = g & ~(g << 1);
-      const uint32_t er = g & ~(g + (sw & 0x55555555u));  // runs that start on an even bit
-      const uint32_t c0 = g & ((er & 0x55555555u) | (~er & 0xAAAAAAAAu));
-      uint32_t cout = c0 >> 31;
-      const uint64_t full = __ballot(g == 0xFFFFFFFFu);
-      if (full) {  // a word of ones hands its carry-in on: resolve those in lane order
-        uint64_t m = full;
-        while (m) {
-          const int l = __builtin_ctzll(m);
-          const uint32_t cin_l = l ? (uint32_t)__builtin_amdgcn_readlane((int)cout, l - 1) : 0u;
-          if (lane == l) cout = cin_l;  // (32 ones: the last carry equals the carry-in)
-          m &= m - 1;
-        }
-      }
-      const uint32_t cin = from_prev(cout);
-      const uint32_t low = g & ~(g + 1u);              // the run of ones at bit 0
-      const uint32_t c = c0 ^ (low & (0u - cin));       // an entering carry flips that run's pattern
-      const uint32_t cl = (c << 1) | cin;               // carry INTO every column
-      const uint32_t x = ~(a | cl) & colmask;
-      o[r * 64] = x;
-      // marks for the row below
-      const uint32_t ml = x & D[r][1], md = x & D[r][2], mr = x & D[r][3];
-      a = ((ml >> 1) | (from_next(ml) << 31)) | md | ((mr << 1) | (from_prev(mr) >> 31));
-      so[r * 64] = a;
-    }
-  };
-  uint32_t P[PF][4], Q[PF][4];
-  load_batch(P, first);
-  for (int j0 = 0; j0 < nrows; j0 += 2 * PF) {
-    load_batch(Q, first + j0 + PF);
-    run_batch(P, first + j0);
-    if (j0 + PF >= nrows) break;
-    load_batch(P, first + j0 + 2 * PF);
-    run_batch(Q, first + j0 + PF);
-  }
+  nlk_commit_rows1<NLK_CR_BATCH, false>(planes, actbits, astate, nullptr, 0u, ngx, first, nrows, threadIdx.x);
+}
+
+// the decision bits of tagged words -> the byte per target (records, on request: nlk_ctx_read_records)
+__global__ void __launch_bounds__(256)
+k_active_bytes_tagged(const uint64_t* __restrict__ tagged, uint8_t* __restrict__ active, int ngx) {
+  const int j = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i < ngx) active[(size_t)j * ngx + i] = ((uint32_t)tagged[(size_t)j * 64 + (i >> 5)] >> (i & 31)) & 1u;
 }
 
 // ---------------------------------------------------------------------------

@@ -10,8 +10,10 @@ __global__ void __launch_bounds__(256)
 k_layout(const float* __restrict__ cur, float* __restrict__ pl_cur, const float* __restrict__ prev,
          float* __restrict__ pl_prev, const float* __restrict__ basic, float* __restrict__ pl_basic,
          uint8_t* __restrict__ rowok, float* __restrict__ acc_zero, int w, int h, int ch, int psz, int planar,
-         int y0) {  // (rows y0 .. y0 + gridDim.y - 1: a frame that arrives from the host in row bands)
+         int y0,    // (rows y0 .. y0 + gridDim.y - 1: a frame that arrives from the host in row bands)
+         uint32_t* __restrict__ zero_word) {  // one more word to clear (the wide-window queue's length), or nullptr
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = y0 + blockIdx.y;
+  if (zero_word && x == 0 && blockIdx.y == 0) *zero_word = 0u;
   if (x >= w) return;
   const size_t npix = (size_t)w * h, i = (size_t)y * w + x;
   if (planar) {  // (one channel: planar == interleaved, the images are used in place)

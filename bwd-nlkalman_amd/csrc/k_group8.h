@@ -61,6 +61,13 @@ struct NlkGTile {
   // k_group8m: start of the allocation that holds every planar image of the call (nlk_ctx::planes, < 4 GiB):
   // patches are addressed as this base + a 32-bit byte offset
   const float* pbase;
+  // k_group8m, mask replay inside the launch (chase != 0; whole grids of reach 1): workgroup 0 first replays the
+  // processed mask from the bit planes (k_commit.h, nlk_commit_rows1) and publishes every row's decisions as
+  // generation-tagged words; every workgroup polls the words of its own targets instead of reading `active`
+  int chase;
+  uint32_t chase_gen;
+  const uint32_t* chase_planes;  // [rows][4][64]
+  uint64_t* chase_words;         // [rows][64]: generation << 32 | decision bits
 };
 
 // does this target's group reach beyond the temporal radius? (np0 = its candidates with a valid previous patch)

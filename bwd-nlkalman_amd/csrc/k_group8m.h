@@ -30,6 +30,7 @@
 // tile and its flush).
 #pragma once
 #include "nlk_common.h"
+#include "k_commit_rows.h"
 #include "k_group8.h"
 #include <type_traits>
 
@@ -166,6 +167,13 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   // leaves whole XCDs idle at the end of a launch - the bands differ in skipped targets (2 % of the kernel) -
   // and plain launch order spreads every neighbourhood over all eight L2s (8x the fetched bytes). So: chunks
   // of NLK_G8_CW x NLK_G8_CH tiles, dealt round-robin to the XCDs, each worked through by one XCD.
+  if (tl.chase && blockIdx.x == 0) {
+    // the launch's first workgroup replays the processed mask of the whole grid before its own tile (k_commit.h);
+    // every workgroup, this one included, then waits for the decision words of its targets below
+    __builtin_amdgcn_s_setprio(3);
+    nlk_commit_rows1<8, true>(tl.chase_planes, nullptr, nullptr, tl.chase_words, tl.chase_gen, g.ngx, 0, g.ngy, lane);
+    __builtin_amdgcn_s_setprio(0);
+  }
   int tile_x, tile_y, gx0, gy0, cx, cy;
   if ((int)blockIdx.x < tl.nmain) {
     const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
@@ -203,7 +211,21 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   if (lane < cx * cy) {
     const int ty = lane / cx, tx = lane - ty * cx;
     const size_t t = (size_t)(gy0 + ty) * g.ngx + gx0 + tx;
-    rec_act = active[t];
+    if (tl.chase) {
+      // decisions arrive as generation-tagged words (indivisible 64-bit stores / loads at agent scope: no fence, no
+      // stale line of another XCD's L2). The replay runs ~30x faster than the launch walks through the grid rows:
+      // only the first wave of workgroups ever waits. A launch whose replay never publishes traps instead of hanging.
+      const uint64_t* wp = tl.chase_words + (size_t)(gy0 + ty) * 64 + ((gx0 + tx) >> 5);
+      uint64_t v = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int spin = 0; (uint32_t)(v >> 32) != tl.chase_gen; ++spin) {
+        if (spin > (1 << 22)) __builtin_trap();
+        __builtin_amdgcn_s_sleep(16);
+        v = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      rec_act = ((uint32_t)v >> ((gx0 + tx) & 31)) & 1u;
+    } else {
+      rec_act = active[t];
+    }
     const NlkTarget info = tinfo[t];
     rec_nsel = info.nsel; rec_nagg = info.nagg;
     rec_vb[0] = (uint32_t)info.vbits[0]; rec_vb[1] = (uint32_t)(info.vbits[0] >> 32);

@@ -183,7 +183,7 @@ void nlk_ctx_destroy(nlk_ctx* c) {
   hipStreamSynchronize(c->stream);
   if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
   Buf* bufs[] = {&c->planes, &c->rowok, &c->vmap, &c->topk,
-                 &c->tinfo, &c->gcoords, &c->marks, &c->active, &c->acc, &c->tabs, &c->wide, &c->tv, &c->skew, &c->ms,
+                 &c->tinfo, &c->gcoords, &c->marks, &c->active, &c->acc, &c->tabs, &c->wide, &c->tv, &c->skew, &c->chase, &c->ms,
                  &c->slab, &c->tflag, &c->hw_cur, &c->hw_prev, &c->hw_basic, &c->hw_out};
   for (Buf* b : bufs)
     if (b->p) hipFree(b->base ? b->base : b->p);
@@ -392,6 +392,7 @@ struct NlkPlan {
   size_t lds = 0, lds_w = 0;
   int maxm = 0, maxm_w = 0;
   bool wide = false;
+  bool wide0_zeroed = false;     // the layout kernel has cleared the queue length of band 0 (rows from 0)
   bool generic = false;          // k_bm_generic instead of the tiled kernels
 };
 
@@ -419,7 +420,7 @@ static NlkGeom band_geom(const NlkGeom& g, int r0, int rows) {
 // layout of the pixel rows [y0, y1) (planar copies, row test of the validity map, accumulator rows cleared) and
 // the validity map's column test for the rows [v0, v1) (a row needs the row tests of the psz rows from it on)
 static int layout_rows(nlk_ctx* c, const float* cur, const float* prev, const float* basic, float* acc_zero, int w,
-                       int h, int ch, int psz, int y0, int y1, int v0, int v1) {
+                       int h, int ch, int psz, int y0, int y1, int v0, int v1, uint32_t* zero_word = nullptr) {
   // (every image is copied into the context's slab, one channel too: the group kernel addresses all of them from
   // one base pointer)
   const size_t img_floats = (size_t)w * h * ch;
@@ -427,7 +428,7 @@ static int layout_rows(nlk_ctx* c, const float* cur, const float* prev, const fl
   if (y1 > y0)
     hipLaunchKernelGGL(k_layout, dim3((w + 255) / 256, y1 - y0), dim3(256), 0, c->stream, cur, slab, prev,
                        slab + img_floats, basic, slab + 2 * img_floats, (uint8_t*)c->rowok.p, acc_zero, w, h, ch, psz,
-                       1, y0);
+                       1, y0, zero_word);
   if (prev && v1 > v0) {
     if (w % 4 == 0)
       hipLaunchKernelGGL(k_nan_cols4, dim3((w / 4 + 255) / 256, v1 - v0), dim3(256), 0, c->stream,
@@ -448,6 +449,7 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   if (rc) return rc;
   if (!P) return fail(c, NLK_EINVAL, "null parameters");
   NLK_USE_DEVICE(c);
+  c->lazy_ngx = c->lazy_ngy = 0;  // (whatever replays this call's mask: `active` holds its bytes unless set again)
   NlkGeom& g = pl.g;
   g.w = w; g.h = h; g.ch = ch;
   g.psz = P->patch_sz;
@@ -500,9 +502,12 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
     pl.img_prev = prev ? pl.img_cur + img_floats : nullptr;
     pl.img_basic = basic ? pl.img_cur + 2 * img_floats : nullptr;
     if (prev && ((rc = reserve(c, c->rowok, npix)) || (rc = reserve(c, c->vmap, npix)))) return rc;
+    if ((rc = reserve(c, c->wide, sizeof(uint32_t) * ((size_t)ngrid + nbands)))) return rc;  // per band: queue length + queue
     if (do_layout) {
-      int rc2 = layout_rows(c, cur, prev, basic, acc_zero, w, h, ch, g.psz, 0, h, 0, h);
+      // (the layout kernel also clears the length of the first band's wide-window queue: one 6 us memset less)
+      int rc2 = layout_rows(c, cur, prev, basic, acc_zero, w, h, ch, g.psz, 0, h, 0, h, (uint32_t*)c->wide.p);
       if (rc2) return rc2;
+      pl.wide0_zeroed = true;
     }
   }
   if ((rc = upload_tables(c, g.psz))) return rc;
@@ -510,8 +515,7 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
       (rc = reserve(c, c->tinfo, sizeof(NlkTarget) * (size_t)ngrid)) ||
       (rc = reserve(c, c->gcoords, sizeof(uint32_t) * (size_t)ngrid * ntagg_alloc)) ||
       (rc = reserve(c, c->marks, sizeof(uint64_t) * (size_t)ngrid)) ||
-      (rc = reserve(c, c->active, (size_t)ngrid)) ||
-      (rc = reserve(c, c->wide, sizeof(uint32_t) * ((size_t)ngrid + nbands))))  // per band: queue length + queue
+      (rc = reserve(c, c->active, (size_t)ngrid)))
     return rc;
   mark(c, 1);
 
@@ -602,7 +606,8 @@ static int match_rows(nlk_ctx* c, const NlkPlan& pl, hipStream_t stream, int r0,
   if (pl.generic) return nlk_launch_match_generic(c, gb, pl.img_match);
   NlkTile tl = pl.tl;
   tl.nty = (rows + tl.tgy - 1) / tl.tgy;
-  if (pl.wide) HIPCHK(c, hipMemsetAsync(c->rv.wide, 0, sizeof(uint32_t), stream));
+  if (pl.wide && !(pl.wide0_zeroed && r0 == 0 && band == 0))
+    HIPCHK(c, hipMemsetAsync(c->rv.wide, 0, sizeof(uint32_t), stream));
   int rc = nlk_launch_match(c, gb, tl, pl.lds, pl.img_match, pl.maxm, false);
   if (rc) return rc;
   if (pl.wide) {
@@ -718,11 +723,48 @@ static int commit_rows(nlk_ctx* c, hipStream_t stream, const uint64_t* marks, ui
   return NLK_OK;
 }
 
+// The mask replay inside the group kernel's launch (k_group8m.h, NlkGTile::chase): the replay of a reach-1 grid is
+// a chain of ~270 dependent row steps on ONE wavefront (24 us of a 1.1 ms frame at 1080p, the rest of the chip
+// idle) that stays far ahead of the group kernel's own progress through the rows (88 ns against 2.9 us per grid
+// row) - so workgroup 0 of the group kernel runs it and the others pick their targets' decisions up as they are
+// published. Whole-grid, single-band calls of the default kernels only (NLK_NO_CHASE=1: the separate kernels).
+static bool chase_selected(const nlk_ctx* c, const NlkGeom& g) {
+  return g.R == 1 && g.ngx <= 2048 && g.psz == 8 && (g.ch == 1 || g.ch == 3) && g.kmax <= 128 && g.gstride <= 128 &&
+         !c->deterministic && c->planes.cap < ((size_t)1 << 32) && !nlk_set(c->sw.no_chase) &&
+         !nlk_set(c->sw.commit_wave) && !nlk_set(c->sw.commit_lds) && !nlk_set(c->sw.commit_band) &&
+         !nlk_set(c->sw.generic_group) && !nlk_set(c->sw.group_packed) && !nlk_set(c->sw.group_dpp);
+}
+
+// bit planes of the whole grid + a fresh generation of tagged words; c->rv.chase_* are picked up by nlk_launch_group8
+static int chase_prepare(nlk_ctx* c, hipStream_t stream, const uint64_t* marks, int ngx, int ngy) {
+  const int rows_pad = (ngy + NLK_CR_BATCH - 1) / NLK_CR_BATCH * NLK_CR_BATCH + 3 * NLK_CR_BATCH;
+  int rc = reserve(c, c->skew, sizeof(uint32_t) * (size_t)rows_pad * 6 * 64);
+  if (rc) return rc;
+  const size_t wbytes = sizeof(uint64_t) * (size_t)rows_pad * 64;
+  if (wbytes > c->chase.cap) {
+    if ((rc = reserve(c, c->chase, wbytes))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->chase.p, 0, c->chase.cap, stream));  // (no word of another life carries a generation)
+    c->chase_gen = 0;
+  }
+  if (++c->chase_gen == 0) {  // (wrapped after 2^32 frames: start over from cleared words)
+    HIPCHK(c, hipMemsetAsync(c->chase.p, 0, c->chase.cap, stream));
+    c->chase_gen = 1;
+  }
+  hipLaunchKernelGGL(k_marks_planes1, dim3(8, ngy), dim3(256), 0, stream, marks, (uint32_t*)c->skew.p, ngx, 0);
+  HIPCHK(c, hipGetLastError());
+  return NLK_OK;
+}
+
 // phase 3 for the target rows [r0, r0 + rows) of the last plan (c->last)
 static int group_rows(nlk_ctx* c, hipStream_t stream, float* acc, const uint8_t* active_rows, int r0, int rows,
                       int band) {
   const NlkGeom gb = band_geom(c->last, r0, rows);
   c->rv = view_rows(c, c->last, stream, r0, band);
+  if (c->chase_on) {
+    c->rv.chase_planes = (const uint32_t*)c->skew.p;
+    c->rv.chase_words = (uint64_t*)c->chase.p;
+    c->rv.chase_gen = c->chase_gen;
+  }
   return launch_group(c, gb, c->p_match, c->p_cur, c->p_prev, acc, active_rows);
 }
 
@@ -759,6 +801,17 @@ static int frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const floa
   if (nb == 1) {
     if ((rc = match_rows(c, pl, c->stream, 0, g.ngy, 0))) return rc;
     mark(c, 2);
+    if (chase_selected(c, g)) {
+      if ((rc = chase_prepare(c, c->stream, (const uint64_t*)c->marks.p, g.ngx, g.ngy))) return rc;
+      mark(c, 3);
+      c->chase_on = true;  // (group_rows' view of the records carries the planes / words / generation)
+      rc = group_rows(c, c->stream, acc, active, 0, g.ngy, 0);
+      c->chase_on = false;
+      if (rc) return rc;
+      c->lazy_ngx = g.ngx; c->lazy_ngy = g.ngy;  // (the bytes of `active` only when somebody reads the records)
+      mark(c, 4);
+      return NLK_OK;
+    }
     if ((rc = commit_rows(c, c->stream, (const uint64_t*)c->marks.p, active, g.ngx, 0, g.ngy, g.R))) return rc;
     mark(c, 3);
     if ((rc = group_rows(c, c->stream, acc, active, 0, g.ngy, 0))) return rc;
@@ -1078,6 +1131,13 @@ int nlk_ctx_read_records(nlk_ctx* c, int* ngrid, int* kmax, int* gmax, unsigned 
   if (kmax) *kmax = g.kmax;
   if (gmax) *gmax = g.gstride;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (active && c->lazy_ngx) {  // (the group kernel replayed the mask itself: expand its decision words now)
+    hipLaunchKernelGGL(k_active_bytes_tagged, dim3((c->lazy_ngx + 255) / 256, c->lazy_ngy), dim3(256), 0, c->stream,
+                       (const uint64_t*)c->chase.p, (uint8_t*)c->active.p, c->lazy_ngx);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->lazy_ngx = c->lazy_ngy = 0;
+  }
   if (active) HIPCHK(c, hipMemcpy(active, c->active.p, n, hipMemcpyDeviceToHost));
   if (nsel || np0 || nagg) {
     NlkTarget* t = (NlkTarget*)malloc(sizeof(NlkTarget) * n);

@@ -31,6 +31,10 @@ struct NlkRecView {
   uint32_t* gcoords = nullptr;   // [targets][gstride]
   uint64_t* marks = nullptr;     // [targets]
   uint32_t* wide = nullptr;      // [0] = queue length, then the queued targets (k_bm_wide)
+  // set by the frame call when the group kernel is to replay the processed mask itself (k_group8m, NlkGTile::chase)
+  const uint32_t* chase_planes = nullptr;
+  uint64_t* chase_words = nullptr;
+  uint32_t chase_gen = 0;
 };
 
 // The NLK_* environment switches (variants for comparison tests and experiments, none
@@ -43,7 +47,7 @@ struct NlkRecView {
   X(group_dpp, "NLK_GROUP_DPP") X(generic_match, "NLK_GENERIC_MATCH") X(mtx, "NLK_MTX") X(mty, "NLK_MTY")    \
   X(match_wg8, "NLK_MATCH_WG8") X(match_bx2, "NLK_MATCH_BX2") X(match_block, "NLK_MATCH_BLOCK")              \
   X(match_noblock, "NLK_MATCH_NOBLOCK") X(commit_wave, "NLK_COMMIT_WAVE") X(commit_lds, "NLK_COMMIT_LDS")    \
-  X(commit_band, "NLK_COMMIT_BAND") X(bands, "NLK_BANDS") X(host_bands, "NLK_HOST_BANDS")                    \
+  X(commit_band, "NLK_COMMIT_BAND") X(no_chase, "NLK_NO_CHASE") X(bands, "NLK_BANDS") X(host_bands, "NLK_HOST_BANDS")                    \
   X(host_trace, "NLK_HOST_TRACE") X(gtx, "NLK_GTX") X(gty, "NLK_GTY") X(g8_tail, "NLK_G8_TAIL")              \
   X(g8_single, "NLK_G8_SINGLE") X(tv_wg_pixels, "NLK_TV_WG_PIXELS") X(tv_unblocked, "NLK_TV_UNBLOCKED")      \
   X(tv_batch, "NLK_TV_BATCH") X(tv_mid, "NLK_TV_MID") X(tv_shape, "NLK_TV_SHAPE") X(tv_deep, "NLK_TV_DEEP")  \
@@ -69,12 +73,16 @@ struct nlk_ctx {
   hipStream_t aux_stream = nullptr;  // second stream of the banded frame pipeline (run_frame)
   hipEvent_t sync_ev[8] = {};        // cross-stream dependencies of that pipeline (no timing)
   NlkRecView rv;                     // set by the orchestration before every launcher call
+  bool chase_on = false;             // the group launch being set up replays the mask itself
+  uint32_t chase_gen = 0;            // generation of the last in-launch mask replay (k_group8m, NlkGTile::chase)
+  int lazy_ngx = 0, lazy_ngy = 0;    // != 0: c->active is still to be expanded from the tagged words (read_records)
   uint64_t* marks_ext = nullptr;     // strip calls: the matcher writes its mark words straight into the caller's array
   float* strip_acc = nullptr;        // strip calls: accumulator whose rows the layout kernel clears as it lays them out
   char err[512] = "";
   NlkBuf planes;                  // the planar copies of cur | prev | basic, one allocation (32-bit offsets between them: k_group8m.h)
   NlkBuf rowok, vmap, topk, tinfo, gcoords, marks, active, acc, tabs, wide;
   NlkBuf skew;                    // mark words in replay-step order (k_marks_skew)
+  NlkBuf chase;                   // generation-tagged decision words of the in-launch mask replay (zeroed when allocated)
   NlkBuf ms;                      // whole-image DCT: temporary image + the two basis matrices
   NlkBuf tv;                      // TV-L1 pyramids and work images
   NlkBuf slab, tflag;             // deterministic aggregation: per-tile accumulator slabs + "written" flags (k_gather.h)

@@ -20,8 +20,13 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
     const float* lo = (const float*)c->planes.p;
     const float* hi = lo + c->planes.cap / sizeof(float);
     const bool inside = img >= lo && img < hi && cur >= lo && cur < hi && (!prev || (prev >= lo && prev < hi));
-    if (!inside || c->planes.cap >= ((size_t)1 << 32)) return nlk_launch_groupp_a(c, g, img, cur, prev, acc, active);
+    if (!inside || c->planes.cap >= ((size_t)1 << 32)) {
+      if (c->rv.chase_words) return fail(c, NLK_EINVAL, "internal: mask replay handed to a group kernel that cannot run it");
+      return nlk_launch_groupp_a(c, g, img, cur, prev, acc, active);
+    }
   }
+  if (c->rv.chase_words && (!mfma || c->deterministic))
+    return fail(c, NLK_EINVAL, "internal: mask replay handed to a group kernel that cannot run it");
   if (c->deterministic && !mfma)
     return fail(c, NLK_EUNSUP, "deterministic aggregation is not available in the NLK_GROUP_DPP variant");
   // Deterministic mode runs a temporal frame's far-reaching (spatial-branch) groups in a second
@@ -33,6 +38,10 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
     tl.pbase = (const float*)c->planes.p;
     tl.split = split;
     tl.far = pass;
+    tl.chase = c->rv.chase_words != nullptr;
+    tl.chase_gen = c->rv.chase_gen;
+    tl.chase_planes = c->rv.chase_planes;
+    tl.chase_words = c->rv.chase_words;
     // LDS tile halo = reach of the dominant kind of group; without the split the rare spatial-branch
     // groups of a temporal frame that reach further fall back to HBM atomics
     tl.wmax = (g.smoother || g.have_prev) ? g.wsz_t : g.wsz_x;

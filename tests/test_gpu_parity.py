@@ -609,6 +609,39 @@ def test_mask_replay_on_synthetic_mark_words(ctx, O, monkeypatch, reach):
     monkeypatch.delenv("NLK_COMMIT_WAVE", raising=False)
 
 
+def test_mask_replay_inside_the_group_launch_equals_the_separate_kernels(ctx, built, synth, monkeypatch):
+    """Temporal frames of 8 x 8 patches replay the processed mask INSIDE the group kernel's launch (k_group8m:
+    workgroup 0 runs the row replay, the others poll generation-tagged decision words); NLK_NO_CHASE=1 runs the
+    separate kernels before it. Same decisions for every target, same frame up to the order of the float sums -
+    small and full-size grids, one and three channels, NaN holes, the second iteration and the smoother; and a
+    context that alternates between the two keeps giving them (the generation of the words moves on)."""
+    shapes = [(96, 64, 3, 21), (70, 53, 1, 22), (1000, 560, 3, 23), (1920, 1080, 3, 24)]
+    for w, h, ch, seed in shapes:
+        sigma = 20.0
+        n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, seed)
+        o0, o1 = (built.rgb2opp(n0), built.rgb2opp(n1)) if ch == 3 else (n0, n1)
+        p1, p2, p3 = (built.default_params(sigma, m) for m in (built.FLT1, built.FLT2, built.SMO1))
+        prev, _ = _dev_frame(ctx, False, o0, None, None, sigma, p1)
+        holes = prev.copy()
+        holes[h // 4:h // 3, w // 3:w // 2] = np.nan
+        holes[:, :2] = np.nan
+        calls = [(False, o1, prev, None, p1), (False, o1, holes, None, p1), (False, n1, prev, o1, p2),
+                 (True, o1, holes, None, p3)]
+        for rep in range(2):
+            for smo, cur, pv, basic, p in calls:
+                monkeypatch.delenv("NLK_NO_CHASE", raising=False)
+                fa, ra = _dev_frame(ctx, smo, cur, pv, basic, sigma, p)
+                monkeypatch.setenv("NLK_NO_CHASE", "1")
+                fb, rb = _dev_frame(ctx, smo, cur, pv, basic, sigma, p)
+                for f in ("active", "nsel", "np0", "nagg", "topk", "gcoords"):
+                    assert np.array_equal(ra[f], rb[f]), (w, h, ch, smo, f)
+                if p is p1 and pv is prev and min(w, h) > 100:
+                    assert 0.05 < 1 - ra["active"].mean() < 0.6   # (the skip really is exercised)
+                fa, _ = cases.excuse_flips(fa, fb, cur, f"replay in the launch {w}x{h}x{ch}", most=8)
+                cases.assert_close(fa, fb, f"replay in the launch vs separate kernels {w}x{h}x{ch} smoother={smo}")
+    monkeypatch.delenv("NLK_NO_CHASE", raising=False)
+
+
 def test_group_kernels_agree_matrix_vs_dpp(ctx, built, synth, monkeypatch):
     """The 8x8 group kernel has two implementations: k_group8m (DCTs on the f32
     matrix cores, the default) and k_group8 (registers + DPP, NLK_GROUP_DPP=1).
