@@ -331,82 +331,10 @@ k_marks_planes(const uint64_t* __restrict__ marks, uint32_t* __restrict__ planes
 }
 
 template <int R>
-struct NlkCommitRows {
-  static constexpr int side = 2 * R + 1, NP = R + R * side;
-  static constexpr int PF = 48 / NP;  // rows per batch of planes in flight (two register sets)
-};
-
-// astate[(j * R + k) * 64 + word]: the marks rows j-1, j-2, .. have left for row j + k when row j starts.
-template <int R>
 __global__ void __launch_bounds__(64)
 k_mask_commit_rows(const uint32_t* __restrict__ planes, uint32_t* __restrict__ actbits,
                    uint32_t* __restrict__ astate, int ngx, int first, int nrows) {
-  constexpr int side = 2 * R + 1, NP = R + R * side, PF = NlkCommitRows<R>::PF;
-  const int lane = threadIdx.x;
-  const int nb = ngx - 32 * lane;
-  const uint32_t colmask = nb <= 0 ? 0u : (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u));
-  auto from_prev = [](uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
-  };
-  auto from_next = [](uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
-  };
-  // whole-row shifts towards higher / lower columns by 1 <= d <= R bits
-  auto up = [&](uint32_t v, int d) { return __builtin_amdgcn_alignbit(v, from_prev(v), 32 - d); };
-  auto down = [&](uint32_t v, int d) { return __builtin_amdgcn_alignbit(from_next(v), v, d); };
-  const uint32_t* pp = planes + lane;
-  uint32_t* ap = actbits + lane;
-  uint32_t* sp = astate + lane;
-  uint32_t A[R];
-#pragma unroll
-  for (int k = 0; k < R; ++k) A[k] = first ? sp[((size_t)first * R + k) * 64] : 0u;
-  auto load_batch = [&](uint32_t (&D)[PF][NP], int jb) {
-    const uint32_t* q = pp + (size_t)jb * NP * 64;
-#pragma unroll
-    for (int r = 0; r < PF; ++r)
-#pragma unroll
-      for (int p = 0; p < NP; ++p) D[r][p] = q[(r * NP + p) * 64];
-  };
-  auto run_batch = [&](const uint32_t (&D)[PF][NP], int jb) {
-    uint32_t* o = ap + (size_t)jb * 64;
-    uint32_t* so = sp + (size_t)(jb + 1) * R * 64;
-#pragma unroll
-    for (int r = 0; r < PF; ++r) {
-      if (jb + r >= first + nrows) break;  // (no row of the next band is replayed from planes not written yet)
-      const uint32_t n = ~A[0] & colmask;
-      uint32_t x = n;
-      for (;;) {
-        uint32_t blocked = 0;
-#pragma unroll
-        for (int d = 1; d <= R; ++d) blocked |= up(x & D[r][d - 1], d);
-        const uint32_t y = n & ~blocked;
-        const bool changed = y != x;
-        x = y;
-        if (!__ballot(changed)) break;
-      }
-      o[r * 64] = x;
-#pragma unroll
-      for (int dj = 1; dj <= R; ++dj) {
-        uint32_t cb = x & D[r][R + (dj - 1) * side + R];  // di = 0
-#pragma unroll
-        for (int di = 1; di <= R; ++di) {
-          cb |= up(x & D[r][R + (dj - 1) * side + R + di], di);
-          cb |= down(x & D[r][R + (dj - 1) * side + R - di], di);
-        }
-        A[dj - 1] = (dj < R ? A[dj] : 0u) | cb;
-        so[(r * R + dj - 1) * 64] = A[dj - 1];
-      }
-    }
-  };
-  uint32_t P[PF][NP], Q[PF][NP];
-  load_batch(P, first);
-  for (int j0 = 0; j0 < nrows; j0 += 2 * PF) {
-    load_batch(Q, first + j0 + PF);
-    run_batch(P, first + j0);
-    if (j0 + PF >= nrows) break;
-    load_batch(P, first + j0 + 2 * PF);
-    run_batch(Q, first + j0 + PF);
-  }
+  nlk_commit_rows<R, false>(planes, actbits, astate, nullptr, 0u, ngx, first, nrows, threadIdx.x);
 }
 
 // bits -> the byte per target the group kernels read

@@ -64,9 +64,9 @@ struct NlkGTile {
   // k_group8m, mask replay inside the launch (chase != 0; whole grids of reach 1): workgroup 0 first replays the
   // processed mask from the bit planes (k_commit.h, nlk_commit_rows1) and publishes every row's decisions as
   // generation-tagged words; every workgroup polls the words of its own targets instead of reading `active`
-  int chase;
+  int chase;                     // 0, or the reach (1..3) of the grid whose replay this launch runs
   uint32_t chase_gen;
-  const uint32_t* chase_planes;  // [rows][4][64]
+  const uint32_t* chase_planes;  // [rows][planes of that reach][64]
   uint64_t* chase_words;         // [rows][64]: generation << 32 | decision bits
 };
 

@@ -171,7 +171,12 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     // the launch's first workgroup replays the processed mask of the whole grid before its own tile (k_commit.h);
     // every workgroup, this one included, then waits for the decision words of its targets below
     __builtin_amdgcn_s_setprio(3);
-    nlk_commit_rows1<8, true>(tl.chase_planes, nullptr, nullptr, tl.chase_words, tl.chase_gen, g.ngx, 0, g.ngy, lane);
+    if (tl.chase == 1)
+      nlk_commit_rows1<8, true>(tl.chase_planes, nullptr, nullptr, tl.chase_words, tl.chase_gen, g.ngx, 0, g.ngy, lane);
+    else if (tl.chase == 2)
+      nlk_commit_rows<2, true>(tl.chase_planes, nullptr, nullptr, tl.chase_words, tl.chase_gen, g.ngx, 0, g.ngy, lane);
+    else
+      nlk_commit_rows<3, true>(tl.chase_planes, nullptr, nullptr, tl.chase_words, tl.chase_gen, g.ngx, 0, g.ngy, lane);
     __builtin_amdgcn_s_setprio(0);
   }
   int tile_x, tile_y, gx0, gy0, cx, cy;

@@ -723,24 +723,26 @@ static int commit_rows(nlk_ctx* c, hipStream_t stream, const uint64_t* marks, ui
   return NLK_OK;
 }
 
-// The mask replay inside the group kernel's launch (k_group8m.h, NlkGTile::chase): the replay of a reach-1 grid is
-// a chain of ~270 dependent row steps on ONE wavefront (24 us of a 1.1 ms frame at 1080p, the rest of the chip
-// idle) that stays far ahead of the group kernel's own progress through the rows (88 ns against 2.9 us per grid
-// row) - so workgroup 0 of the group kernel runs it and the others pick their targets' decisions up as they are
-// published. Whole-grid, single-band calls of the default kernels only (NLK_NO_CHASE=1: the separate kernels).
+// The mask replay inside the group kernel's launch (k_group8m.h, NlkGTile::chase): the replay of a grid is a chain
+// of ~270 dependent row steps on ONE wavefront (reach 1: 24 us of a 1.1 ms frame at 1080p, reach 2: 80 us of a 2 ms
+// first frame, the rest of the chip idle) that stays far ahead of the group kernel's own progress through the rows
+// (88 / 300 ns against 2.9 / 3.8 us per grid row) - so workgroup 0 of the group kernel runs it and the others pick
+// their targets' decisions up as they are published. Whole-grid, single-band calls of the default kernels only
+// (NLK_NO_CHASE=1: the separate kernels; first frames then go back to four bands).
 static bool chase_selected(const nlk_ctx* c, const NlkGeom& g) {
-  return g.R == 1 && g.ngx <= 2048 && g.psz == 8 && (g.ch == 1 || g.ch == 3) && g.kmax <= 128 && g.gstride <= 128 &&
+  return g.R >= 1 && g.R <= 3 && g.ngx <= 2048 && g.psz == 8 && (g.ch == 1 || g.ch == 3) && g.kmax <= 128 && g.gstride <= 128 &&
          !c->deterministic && c->planes.cap < ((size_t)1 << 32) && !nlk_set(c->sw.no_chase) &&
          !nlk_set(c->sw.commit_wave) && !nlk_set(c->sw.commit_lds) && !nlk_set(c->sw.commit_band) &&
          !nlk_set(c->sw.generic_group) && !nlk_set(c->sw.group_packed) && !nlk_set(c->sw.group_dpp);
 }
 
 // bit planes of the whole grid + a fresh generation of tagged words; c->rv.chase_* are picked up by nlk_launch_group8
-static int chase_prepare(nlk_ctx* c, hipStream_t stream, const uint64_t* marks, int ngx, int ngy) {
-  const int rows_pad = (ngy + NLK_CR_BATCH - 1) / NLK_CR_BATCH * NLK_CR_BATCH + 3 * NLK_CR_BATCH;
-  int rc = reserve(c, c->skew, sizeof(uint32_t) * (size_t)rows_pad * 6 * 64);
+static int chase_prepare(nlk_ctx* c, hipStream_t stream, const uint64_t* marks, int ngx, int ngy, int R) {
+  const int np = R == 1 ? 4 : R + R * (2 * R + 1), pf = R == 1 ? NLK_CR_BATCH : 48 / np;
+  const int rows_pad = (ngy + pf - 1) / pf * pf + 3 * pf;
+  int rc = reserve(c, c->skew, sizeof(uint32_t) * (size_t)rows_pad * np * 64);
   if (rc) return rc;
-  const size_t wbytes = sizeof(uint64_t) * (size_t)rows_pad * 64;
+  const size_t wbytes = sizeof(uint64_t) * (size_t)(ngy + 4 * NLK_CR_BATCH) * 64;
   if (wbytes > c->chase.cap) {
     if ((rc = reserve(c, c->chase, wbytes))) return rc;
     HIPCHK(c, hipMemsetAsync(c->chase.p, 0, c->chase.cap, stream));  // (no word of another life carries a generation)
@@ -750,7 +752,10 @@ static int chase_prepare(nlk_ctx* c, hipStream_t stream, const uint64_t* marks, 
     HIPCHK(c, hipMemsetAsync(c->chase.p, 0, c->chase.cap, stream));
     c->chase_gen = 1;
   }
-  hipLaunchKernelGGL(k_marks_planes1, dim3(8, ngy), dim3(256), 0, stream, marks, (uint32_t*)c->skew.p, ngx, 0);
+  uint32_t* planes = (uint32_t*)c->skew.p;
+  if (R == 1) hipLaunchKernelGGL(k_marks_planes1, dim3(8, ngy), dim3(256), 0, stream, marks, planes, ngx, 0);
+  else if (R == 2) hipLaunchKernelGGL(k_marks_planes<2>, dim3(8, ngy), dim3(256), 0, stream, marks, planes, ngx, 0);
+  else hipLaunchKernelGGL(k_marks_planes<3>, dim3(8, ngy), dim3(256), 0, stream, marks, planes, ngx, 0);
   HIPCHK(c, hipGetLastError());
   return NLK_OK;
 }
@@ -764,6 +769,7 @@ static int group_rows(nlk_ctx* c, hipStream_t stream, float* acc, const uint8_t*
     c->rv.chase_planes = (const uint32_t*)c->skew.p;
     c->rv.chase_words = (uint64_t*)c->chase.p;
     c->rv.chase_gen = c->chase_gen;
+    c->rv.chase_reach = c->last.R;
   }
   return launch_group(c, gb, c->p_match, c->p_cur, c->p_prev, acc, active_rows);
 }
@@ -796,13 +802,14 @@ static int frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const floa
   int rc = plan_frame(c, pl, cur, prev, basic, w, h, ch, sigma, P, oy, ngy, smoother, 8, clear ? acc : nullptr);
   if (rc) return rc;
   const NlkGeom& g = pl.g;
-  const int nb = frame_bands(c, g);
+  // (a replay that rides inside the group launch needs no bands to hide behind)
+  const int nb = (chase_selected(c, g) && !nlk_set(c->sw.bands)) ? 1 : frame_bands(c, g);
   uint8_t* active = (uint8_t*)c->active.p;
   if (nb == 1) {
     if ((rc = match_rows(c, pl, c->stream, 0, g.ngy, 0))) return rc;
     mark(c, 2);
     if (chase_selected(c, g)) {
-      if ((rc = chase_prepare(c, c->stream, (const uint64_t*)c->marks.p, g.ngx, g.ngy))) return rc;
+      if ((rc = chase_prepare(c, c->stream, (const uint64_t*)c->marks.p, g.ngx, g.ngy, g.R))) return rc;
       mark(c, 3);
       c->chase_on = true;  // (group_rows' view of the records carries the planes / words / generation)
       rc = group_rows(c, c->stream, acc, active, 0, g.ngy, 0);

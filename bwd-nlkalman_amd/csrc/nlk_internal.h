@@ -35,6 +35,7 @@ struct NlkRecView {
   const uint32_t* chase_planes = nullptr;
   uint64_t* chase_words = nullptr;
   uint32_t chase_gen = 0;
+  int chase_reach = 0;
 };
 
 // The NLK_* environment switches (variants for comparison tests and experiments, none

@@ -38,7 +38,7 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
     tl.pbase = (const float*)c->planes.p;
     tl.split = split;
     tl.far = pass;
-    tl.chase = c->rv.chase_words != nullptr;
+    tl.chase = c->rv.chase_words ? c->rv.chase_reach : 0;
     tl.chase_gen = c->rv.chase_gen;
     tl.chase_planes = c->rv.chase_planes;
     tl.chase_words = c->rv.chase_words;
@@ -54,11 +54,15 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
     // tile would leave LDS room for ~1 wavefront per SIMD: 2 x 1 at most then.
     auto tiles_with = [&](int t) { return (size_t)((g.ngx + t - 1) / t) * g.ngy; };
     const int tgx_fill = tiles_with(3) >= 30000 ? 3 : (tiles_with(2) >= 2560 ? 2 : 1);
-    tl.tgx = nlk_or(c->sw.gtx, min(tgx_fill, tl.wmax > 6 ? 2 : 4));
+    // (round 4, first frames at 1080p - the spatial halo, 2 wavefronts per SIMD whatever the tile: 1 x 2 targets
+    // 1.029 ms, 3 x 1 1.043, 3 x 2 1.042, 1 x 3 1.052, 2 x 2 1.090, 2 x 1 1.113 (the default until then), 1 x 4 1.113,
+    // 1 x 1 1.143, 4 x 1 1.164, 1 x 6 1.185)
+    const bool wide_full = mfma && tl.wmax > 6 && tgx_fill == 3 && pass == 0;
+    tl.tgx = nlk_or(c->sw.gtx, wide_full ? 1 : min(tgx_fill, tl.wmax > 6 ? 2 : 4));
     // (round 3, matrix-core kernel with the leaner pass A, 1080p: 3 x 2 targets 0.957 ms, 2 x 2 0.970, 3 x 1 0.976,
     // 4 x 2 1.10, 2 x 3 1.05, 3 x 3 1.04 - two target rows share the tile's vertical halo: 40 % fewer flushed bytes;
     // round 4, straight-line aggregation: 3 x 2 0.831, 2 x 2 0.851, 3 x 1 0.869, 3 x 3 0.891, 4 x 2 0.993)
-    tl.tgy = nlk_or(c->sw.gty, (mfma && tgx_fill == 3 && tl.wmax <= 6) ? 2 : 1);
+    tl.tgy = nlk_or(c->sw.gty, (mfma && tgx_fill == 3 && tl.wmax <= 6) || wide_full ? 2 : 1);
     tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
     tl.nty = (g.ngy + tl.tgy - 1) / tl.tgy;
     tl.nty_full = tl.nty;
