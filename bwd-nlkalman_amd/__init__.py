@@ -34,6 +34,7 @@ HIP_SYMBOLS = [
     "nlk_strips_create", "nlk_strips_destroy", "nlk_strips_last_error", "nlk_rccl_unique_id", "nlk_strips_rccl_init",
     "nlk_strips_transport", "nlk_strips_load", "nlk_strips_set_options", "nlk_strips_step", "nlk_strips_sync",
     "nlk_strips_own_rows", "nlk_strips_ctx", "nlk_strips_geometry", "nlk_strips_stats", "nlk_strips_set_dry_run",
+    "nlk_dev_strip_commit_group", "nlk_ctx_flush_active",
 ]
 API_SYMBOLS = [
     "rgb2opp", "opp2rgb", "warp_bicubic", "nlkalman_default_params",
@@ -126,6 +127,7 @@ def hip():
                                                vp, C.POINTER(i)]
         L.nlk_dev_mask_commit.argtypes = [vp, vp, i, i, i, vp]
         L.nlk_dev_strip_group.argtypes = [vp, fp, vp]
+        L.nlk_dev_strip_commit_group.argtypes = [vp, fp, vp, i, i, i, i, vp]
         L.nlk_ctx_read_records.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i),
                                            vp, vp, vp, vp, vp, vp]
         L.nlk_tvl1_default_params.argtypes = [C.POINTER(Tvl1Params)]
@@ -429,6 +431,11 @@ class Context:
 
     def strip_group(self, d_acc, d_active):
         self._chk(self.L.nlk_dev_strip_group(self.h, d_acc, d_active))
+
+    def strip_commit_group(self, d_acc, d_marks, ngx, ngy, reach, gy0, d_active):
+        """mask_commit over the whole grid + strip_group of the strip starting at grid row gy0, as one call (the
+        replay inside the group kernel's launch where it can: include/nlk_hip.h)."""
+        self._chk(self.L.nlk_dev_strip_commit_group(self.h, d_acc, d_marks, ngx, ngy, reach, gy0, d_active))
 
     def frame_normalize(self, d_out, d_acc, d_cur, w, h, ch, y0, y1):
         self._chk(self.L.nlk_dev_frame_normalize(self.h, d_out, d_acc, d_cur, w, h, ch, y0, y1))

@@ -275,8 +275,13 @@ k_mask_commit_wave(const uint32_t* __restrict__ skewed, uint8_t* __restrict__ ac
 // 1..3: marks (i-1, j+1), (i, j+1), (i+1, j+1); bit b of word w = column 32 w + b. All 64 words of a row
 // are written (zeros past the grid), launched over 2048 columns.
 __global__ void __launch_bounds__(256)
-k_marks_planes1(const uint64_t* __restrict__ marks, uint32_t* __restrict__ planes, int ngx, int j0) {
+k_marks_planes1(const uint64_t* __restrict__ marks, uint32_t* __restrict__ planes, int ngx, int j0,
+                uint32_t* __restrict__ generation = nullptr) {  // (the in-launch replay's counter: advanced here, never 0)
   constexpr int R = 1, side = 3, centre = R * side + R;
+  if (generation && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    const uint32_t v = *generation + 1u;
+    *generation = v ? v : 1u;
+  }
   const int j = j0 + blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;  // (rows j0 .. : a band of the grid)
   const uint32_t fwd = i < ngx ? (uint32_t)(marks[(size_t)j * ngx + i] >> (centre + 1)) : 0u;
   const int lane = threadIdx.x & 63, w0 = i >> 5;  // (i of lane 0 of the wavefront is a multiple of 64)
@@ -318,8 +323,13 @@ k_active_bytes_tagged(const uint64_t* __restrict__ tagged, uint8_t* __restrict__
 // ---------------------------------------------------------------------------
 template <int R>
 __global__ void __launch_bounds__(256)
-k_marks_planes(const uint64_t* __restrict__ marks, uint32_t* __restrict__ planes, int ngx, int j0) {
+k_marks_planes(const uint64_t* __restrict__ marks, uint32_t* __restrict__ planes, int ngx, int j0,
+               uint32_t* __restrict__ generation = nullptr) {
   constexpr int side = 2 * R + 1, centre = R * side + R, NP = R + R * side;
+  if (generation && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    const uint32_t v = *generation + 1u;
+    *generation = v ? v : 1u;
+  }
   const int j = j0 + blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
   const uint32_t fwd = i < ngx ? (uint32_t)(marks[(size_t)j * ngx + i] >> (centre + 1)) : 0u;
   const int lane = threadIdx.x & 63, w0 = i >> 5;

@@ -61,11 +61,14 @@ struct NlkGTile {
   // k_group8m: start of the allocation that holds every planar image of the call (nlk_ctx::planes, < 4 GiB):
   // patches are addressed as this base + a 32-bit byte offset
   const float* pbase;
-  // k_group8m, mask replay inside the launch (chase != 0; whole grids of reach 1): workgroup 0 first replays the
-  // processed mask from the bit planes (k_commit.h, nlk_commit_rows1) and publishes every row's decisions as
-  // generation-tagged words; every workgroup polls the words of its own targets instead of reading `active`
+  // k_group8m, mask replay inside the launch (chase != 0): workgroup 0 first replays the processed mask of the grid
+  // rows [0, chase_rows) from the bit planes (k_commit_rows.h) and publishes every row's decisions as
+  // generation-tagged words; every workgroup polls the words of its own targets instead of reading `active`.
+  // The launch's own first grid row is row chase_row0 of that grid (0 for a whole-frame call, a strip's first row).
   int chase;                     // 0, or the reach (1..3) of the grid whose replay this launch runs
-  uint32_t chase_gen;
+  int chase_row0, chase_rows;
+  const uint32_t* chase_gen;     // the generation of this launch: a device word the bit-plane kernel has just advanced
+                                 // (a kernel argument would be frozen into a captured HIP graph)
   const uint32_t* chase_planes;  // [rows][planes of that reach][64]
   uint64_t* chase_words;         // [rows][64]: generation << 32 | decision bits
 };

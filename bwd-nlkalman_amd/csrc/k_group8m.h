@@ -167,16 +167,19 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   // leaves whole XCDs idle at the end of a launch - the bands differ in skipped targets (2 % of the kernel) -
   // and plain launch order spreads every neighbourhood over all eight L2s (8x the fetched bytes). So: chunks
   // of NLK_G8_CW x NLK_G8_CH tiles, dealt round-robin to the XCDs, each worked through by one XCD.
+  uint32_t chase_gen = 0;
+  if (tl.chase) chase_gen = *tl.chase_gen;  // (advanced by the bit-plane kernel in front of this launch)
   if (tl.chase && blockIdx.x == 0) {
-    // the launch's first workgroup replays the processed mask of the whole grid before its own tile (k_commit.h);
-    // every workgroup, this one included, then waits for the decision words of its targets below
+    // the launch's first workgroup replays the processed mask of the grid rows down to the launch's last one before
+    // its own tile (k_commit_rows.h); every workgroup, this one included, then waits for the decision words of its
+    // targets below
     __builtin_amdgcn_s_setprio(3);
     if (tl.chase == 1)
-      nlk_commit_rows1<8, true>(tl.chase_planes, nullptr, nullptr, tl.chase_words, tl.chase_gen, g.ngx, 0, g.ngy, lane);
+      nlk_commit_rows1<8, true>(tl.chase_planes, nullptr, nullptr, tl.chase_words, chase_gen, g.ngx, 0, tl.chase_rows, lane);
     else if (tl.chase == 2)
-      nlk_commit_rows<2, true>(tl.chase_planes, nullptr, nullptr, tl.chase_words, tl.chase_gen, g.ngx, 0, g.ngy, lane);
+      nlk_commit_rows<2, true>(tl.chase_planes, nullptr, nullptr, tl.chase_words, chase_gen, g.ngx, 0, tl.chase_rows, lane);
     else
-      nlk_commit_rows<3, true>(tl.chase_planes, nullptr, nullptr, tl.chase_words, tl.chase_gen, g.ngx, 0, g.ngy, lane);
+      nlk_commit_rows<3, true>(tl.chase_planes, nullptr, nullptr, tl.chase_words, chase_gen, g.ngx, 0, tl.chase_rows, lane);
     __builtin_amdgcn_s_setprio(0);
   }
   int tile_x, tile_y, gx0, gy0, cx, cy;
@@ -220,9 +223,9 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       // decisions arrive as generation-tagged words (indivisible 64-bit stores / loads at agent scope: no fence, no
       // stale line of another XCD's L2). The replay runs ~30x faster than the launch walks through the grid rows:
       // only the first wave of workgroups ever waits. A launch whose replay never publishes traps instead of hanging.
-      const uint64_t* wp = tl.chase_words + (size_t)(gy0 + ty) * 64 + ((gx0 + tx) >> 5);
+      const uint64_t* wp = tl.chase_words + (size_t)(tl.chase_row0 + gy0 + ty) * 64 + ((gx0 + tx) >> 5);
       uint64_t v = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int spin = 0; (uint32_t)(v >> 32) != tl.chase_gen; ++spin) {
+      for (int spin = 0; (uint32_t)(v >> 32) != chase_gen; ++spin) {
         if (spin > (1 << 22)) __builtin_trap();
         __builtin_amdgcn_s_sleep(16);
         v = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

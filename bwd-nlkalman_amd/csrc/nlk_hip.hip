@@ -450,6 +450,7 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   if (!P) return fail(c, NLK_EINVAL, "null parameters");
   NLK_USE_DEVICE(c);
   c->lazy_ngx = c->lazy_ngy = 0;  // (whatever replays this call's mask: `active` holds its bytes unless set again)
+  c->lazy_dst = nullptr;
   NlkGeom& g = pl.g;
   g.w = w; g.h = h; g.ch = ch;
   g.psz = P->patch_sz;
@@ -639,7 +640,7 @@ static int commit_rows(nlk_ctx* c, hipStream_t stream, const uint64_t* marks, ui
     uint32_t* planes = (uint32_t*)c->skew.p;
     uint32_t* actbits = planes + (size_t)rows_pad * 4 * 64;
     uint32_t* astate = actbits + (size_t)rows_pad * 64;
-    hipLaunchKernelGGL(k_marks_planes1, dim3(8, nrows), dim3(256), 0, stream, marks, planes, ngx, first);
+    hipLaunchKernelGGL(k_marks_planes1, dim3(8, nrows), dim3(256), 0, stream, marks, planes, ngx, first, (uint32_t*)nullptr);
     hipLaunchKernelGGL(k_mask_commit_rows1, dim3(1), dim3(64), 0, stream, (const uint32_t*)planes, actbits, astate, ngx,
                        first, nrows);
     hipLaunchKernelGGL(k_active_bytes, dim3((ngx + 255) / 256, nrows), dim3(256), 0, stream, (const uint32_t*)actbits,
@@ -657,11 +658,11 @@ static int commit_rows(nlk_ctx* c, hipStream_t stream, const uint64_t* marks, ui
     uint32_t* actbits = planes + (size_t)rows_pad * np * 64;
     uint32_t* astate = actbits + (size_t)rows_pad * 64;
     if (R == 2) {
-      hipLaunchKernelGGL(k_marks_planes<2>, dim3(8, nrows), dim3(256), 0, stream, marks, planes, ngx, first);
+      hipLaunchKernelGGL(k_marks_planes<2>, dim3(8, nrows), dim3(256), 0, stream, marks, planes, ngx, first, (uint32_t*)nullptr);
       hipLaunchKernelGGL(k_mask_commit_rows<2>, dim3(1), dim3(64), 0, stream, (const uint32_t*)planes, actbits, astate,
                          ngx, first, nrows);
     } else {
-      hipLaunchKernelGGL(k_marks_planes<3>, dim3(8, nrows), dim3(256), 0, stream, marks, planes, ngx, first);
+      hipLaunchKernelGGL(k_marks_planes<3>, dim3(8, nrows), dim3(256), 0, stream, marks, planes, ngx, first, (uint32_t*)nullptr);
       hipLaunchKernelGGL(k_mask_commit_rows<3>, dim3(1), dim3(64), 0, stream, (const uint32_t*)planes, actbits, astate,
                          ngx, first, nrows);
     }
@@ -736,26 +737,23 @@ static bool chase_selected(const nlk_ctx* c, const NlkGeom& g) {
          !nlk_set(c->sw.generic_group) && !nlk_set(c->sw.group_packed) && !nlk_set(c->sw.group_dpp);
 }
 
-// bit planes of the whole grid + a fresh generation of tagged words; c->rv.chase_* are picked up by nlk_launch_group8
-static int chase_prepare(nlk_ctx* c, hipStream_t stream, const uint64_t* marks, int ngx, int ngy, int R) {
+// bit planes of the grid rows [0, nrows) + a fresh generation of tagged words (the counter lives on the device and
+// is advanced by the bit-plane kernel: a step captured into a HIP graph gets a new generation at every replay)
+static int chase_prepare(nlk_ctx* c, hipStream_t stream, const uint64_t* marks, int ngx, int nrows, int R) {
   const int np = R == 1 ? 4 : R + R * (2 * R + 1), pf = R == 1 ? NLK_CR_BATCH : 48 / np;
-  const int rows_pad = (ngy + pf - 1) / pf * pf + 3 * pf;
+  const int rows_pad = (nrows + pf - 1) / pf * pf + 3 * pf;
   int rc = reserve(c, c->skew, sizeof(uint32_t) * (size_t)rows_pad * np * 64);
   if (rc) return rc;
-  const size_t wbytes = sizeof(uint64_t) * (size_t)(ngy + 4 * NLK_CR_BATCH) * 64;
+  const size_t wbytes = sizeof(uint64_t) * (size_t)(nrows + 4 * NLK_CR_BATCH + 1) * 64;
   if (wbytes > c->chase.cap) {
     if ((rc = reserve(c, c->chase, wbytes))) return rc;
-    HIPCHK(c, hipMemsetAsync(c->chase.p, 0, c->chase.cap, stream));  // (no word of another life carries a generation)
-    c->chase_gen = 0;
-  }
-  if (++c->chase_gen == 0) {  // (wrapped after 2^32 frames: start over from cleared words)
-    HIPCHK(c, hipMemsetAsync(c->chase.p, 0, c->chase.cap, stream));
-    c->chase_gen = 1;
+    HIPCHK(c, hipMemsetAsync(c->chase.p, 0, c->chase.cap, stream));  // (generation 0; no word of another life carries one)
   }
   uint32_t* planes = (uint32_t*)c->skew.p;
-  if (R == 1) hipLaunchKernelGGL(k_marks_planes1, dim3(8, ngy), dim3(256), 0, stream, marks, planes, ngx, 0);
-  else if (R == 2) hipLaunchKernelGGL(k_marks_planes<2>, dim3(8, ngy), dim3(256), 0, stream, marks, planes, ngx, 0);
-  else hipLaunchKernelGGL(k_marks_planes<3>, dim3(8, ngy), dim3(256), 0, stream, marks, planes, ngx, 0);
+  uint32_t* gen = (uint32_t*)c->chase.p;
+  if (R == 1) hipLaunchKernelGGL(k_marks_planes1, dim3(8, nrows), dim3(256), 0, stream, marks, planes, ngx, 0, gen);
+  else if (R == 2) hipLaunchKernelGGL(k_marks_planes<2>, dim3(8, nrows), dim3(256), 0, stream, marks, planes, ngx, 0, gen);
+  else hipLaunchKernelGGL(k_marks_planes<3>, dim3(8, nrows), dim3(256), 0, stream, marks, planes, ngx, 0, gen);
   HIPCHK(c, hipGetLastError());
   return NLK_OK;
 }
@@ -767,9 +765,11 @@ static int group_rows(nlk_ctx* c, hipStream_t stream, float* acc, const uint8_t*
   c->rv = view_rows(c, c->last, stream, r0, band);
   if (c->chase_on) {
     c->rv.chase_planes = (const uint32_t*)c->skew.p;
-    c->rv.chase_words = (uint64_t*)c->chase.p;
-    c->rv.chase_gen = c->chase_gen;
+    c->rv.chase_words = (uint64_t*)c->chase.p + 64;
+    c->rv.chase_gen = (const uint32_t*)c->chase.p;
     c->rv.chase_reach = c->last.R;
+    c->rv.chase_row0 = c->chase_row0;
+    c->rv.chase_rows = c->chase_rows;
   }
   return launch_group(c, gb, c->p_match, c->p_cur, c->p_prev, acc, active_rows);
 }
@@ -812,6 +812,7 @@ static int frame_accumulate(nlk_ctx* c, float* acc, const float* cur, const floa
       if ((rc = chase_prepare(c, c->stream, (const uint64_t*)c->marks.p, g.ngx, g.ngy, g.R))) return rc;
       mark(c, 3);
       c->chase_on = true;  // (group_rows' view of the records carries the planes / words / generation)
+      c->chase_row0 = 0; c->chase_rows = g.ngy;
       rc = group_rows(c, c->stream, acc, active, 0, g.ngy, 0);
       c->chase_on = false;
       if (rc) return rc;
@@ -925,6 +926,37 @@ int nlk_dev_strip_group(nlk_ctx* c, float* acc, const unsigned char* active) {
   if (!acc || !active) return fail(c, NLK_EINVAL, "null accumulator / active flags");
   NLK_USE_DEVICE(c);
   int rc = group_rows(c, c->stream, acc, active, 0, c->last.ngy, 0);
+  mark(c, 4);
+  return rc;
+}
+
+// Phases 2 + 3 of a strip in one call: the mask replay over the whole grid's mark words and the strip's groups. Where
+// the group kernel can run the replay inside its own launch (chase_selected) only the grid rows down to the strip's
+// last one are replayed, by its workgroup 0, and `active` is not written; otherwise exactly nlk_dev_mask_commit +
+// nlk_dev_strip_group on `active + gy0 * ngx`.
+int nlk_dev_strip_commit_group(nlk_ctx* c, float* acc, const void* marks, int ngx, int ngy, int reach, int gy0,
+                               unsigned char* active) {
+  if (!c || !c->have_last) return fail(c, NLK_EINVAL, "nlk_dev_strip_match has not run");
+  if (!acc || !marks || !active || ngx < 1 || ngy < 1 || reach < 0 || gy0 < 0 || gy0 + c->last.ngy > ngy ||
+      ngx != c->last.ngx)
+    return fail(c, NLK_EINVAL, "bad strip commit / group arguments");
+  NLK_USE_DEVICE(c);
+  int rc;
+  if (reach == c->last.R && chase_selected(c, c->last)) {
+    const int rows = gy0 + c->last.ngy;
+    if ((rc = chase_prepare(c, c->stream, (const uint64_t*)marks, ngx, rows, reach))) return rc;
+    mark(c, 3);
+    c->chase_on = true;
+    c->chase_row0 = gy0; c->chase_rows = rows;
+    rc = group_rows(c, c->stream, acc, active + (size_t)gy0 * ngx, 0, c->last.ngy, 0);
+    c->chase_on = false;
+    c->lazy_ngx = ngx; c->lazy_ngy = rows; c->lazy_dst = active;  // (nlk_ctx_flush_active: rows [0, rows) of `active`)
+    mark(c, 4);
+    return rc;
+  }
+  if ((rc = commit_rows(c, c->stream, (const uint64_t*)marks, active, ngx, 0, ngy, reach))) return rc;
+  mark(c, 3);
+  rc = group_rows(c, c->stream, acc, active + (size_t)gy0 * ngx, 0, c->last.ngy, 0);
   mark(c, 4);
   return rc;
 }
@@ -1127,6 +1159,22 @@ int nlk_host_tables(int psz, float* basis, float* window, float* basis12_regs) {
   return NLK_OK;
 }
 
+// Where a group kernel replayed the processed mask inside its own launch the decisions exist as tagged words only;
+// this writes the byte per target of the replayed grid rows into the array the call was given (frame calls: the
+// context's own, read by nlk_ctx_read_records) and waits for it. No-op otherwise.
+int nlk_ctx_flush_active(nlk_ctx* c) {
+  if (!c) return fail(nullptr, NLK_EINVAL, "null context");
+  if (!c->lazy_ngx) return NLK_OK;
+  NLK_USE_DEVICE(c);
+  hipLaunchKernelGGL(k_active_bytes_tagged, dim3((c->lazy_ngx + 255) / 256, c->lazy_ngy), dim3(256), 0, c->stream,
+                     (const uint64_t*)c->chase.p + 64, c->lazy_dst ? c->lazy_dst : (uint8_t*)c->active.p, c->lazy_ngx);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->lazy_ngx = c->lazy_ngy = 0;
+  c->lazy_dst = nullptr;
+  return NLK_OK;
+}
+
 int nlk_ctx_read_records(nlk_ctx* c, int* ngrid, int* kmax, int* gmax, unsigned char* active,
                          int* nsel, int* np0, int* nagg, unsigned int* topk,
                          unsigned int* gcoords) {
@@ -1138,12 +1186,9 @@ int nlk_ctx_read_records(nlk_ctx* c, int* ngrid, int* kmax, int* gmax, unsigned 
   if (kmax) *kmax = g.kmax;
   if (gmax) *gmax = g.gstride;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (active && c->lazy_ngx) {  // (the group kernel replayed the mask itself: expand its decision words now)
-    hipLaunchKernelGGL(k_active_bytes_tagged, dim3((c->lazy_ngx + 255) / 256, c->lazy_ngy), dim3(256), 0, c->stream,
-                       (const uint64_t*)c->chase.p, (uint8_t*)c->active.p, c->lazy_ngx);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->lazy_ngx = c->lazy_ngy = 0;
+  if (active) {  // (the group kernel replayed the mask itself: expand its decision words now)
+    int rc = nlk_ctx_flush_active(c);
+    if (rc) return rc;
   }
   if (active) HIPCHK(c, hipMemcpy(active, c->active.p, n, hipMemcpyDeviceToHost));
   if (nsel || np0 || nagg) {

@@ -34,8 +34,8 @@ struct NlkRecView {
   // set by the frame call when the group kernel is to replay the processed mask itself (k_group8m, NlkGTile::chase)
   const uint32_t* chase_planes = nullptr;
   uint64_t* chase_words = nullptr;
-  uint32_t chase_gen = 0;
-  int chase_reach = 0;
+  const uint32_t* chase_gen = nullptr;
+  int chase_reach = 0, chase_row0 = 0, chase_rows = 0;
 };
 
 // The NLK_* environment switches (variants for comparison tests and experiments, none
@@ -74,16 +74,18 @@ struct nlk_ctx {
   hipStream_t aux_stream = nullptr;  // second stream of the banded frame pipeline (run_frame)
   hipEvent_t sync_ev[8] = {};        // cross-stream dependencies of that pipeline (no timing)
   NlkRecView rv;                     // set by the orchestration before every launcher call
-  bool chase_on = false;             // the group launch being set up replays the mask itself
-  uint32_t chase_gen = 0;            // generation of the last in-launch mask replay (k_group8m, NlkGTile::chase)
-  int lazy_ngx = 0, lazy_ngy = 0;    // != 0: c->active is still to be expanded from the tagged words (read_records)
+  bool chase_on = false;             // the group launch being set up replays the mask itself ...
+  int chase_row0 = 0, chase_rows = 0;  // ... over the grid rows [0, chase_rows); the launch's first row is chase_row0
+  int lazy_ngx = 0, lazy_ngy = 0;    // != 0: the decision bytes of the grid rows [0, lazy_ngy) are still to be expanded
+  unsigned char* lazy_dst = nullptr; //        from the tagged words into this array (nlk_ctx_flush_active; read_records)
   uint64_t* marks_ext = nullptr;     // strip calls: the matcher writes its mark words straight into the caller's array
   float* strip_acc = nullptr;        // strip calls: accumulator whose rows the layout kernel clears as it lays them out
   char err[512] = "";
   NlkBuf planes;                  // the planar copies of cur | prev | basic, one allocation (32-bit offsets between them: k_group8m.h)
   NlkBuf rowok, vmap, topk, tinfo, gcoords, marks, active, acc, tabs, wide;
   NlkBuf skew;                    // mark words in replay-step order (k_marks_skew)
-  NlkBuf chase;                   // generation-tagged decision words of the in-launch mask replay (zeroed when allocated)
+  NlkBuf chase;                   // in-launch mask replay: [0] the generation counter, from word 64 on the tagged decision
+                                  // words (zeroed when allocated)
   NlkBuf ms;                      // whole-image DCT: temporary image + the two basis matrices
   NlkBuf tv;                      // TV-L1 pyramids and work images
   NlkBuf slab, tflag;             // deterministic aggregation: per-tile accumulator slabs + "written" flags (k_gather.h)

@@ -106,6 +106,7 @@ struct Strip {
   float *snd_top = nullptr, *snd_bot = nullptr, *rcv_top = nullptr, *rcv_bot = nullptr;
   unsigned long long* marks_full = nullptr;
   unsigned char* active_full = nullptr;
+  bool chased = false;  // the last step's group kernel replayed the mask itself (active_full: on request, own_rows)
   hipStream_t comm = nullptr;                         // the halo exchange runs beside the interior's matching
   hipEvent_t ev_start = nullptr, ev_prev = nullptr, ev_match = nullptr, ev_group = nullptr, ev_packed = nullptr;
   hipEvent_t ph[PH_N + 1] = {};                       // phase boundaries on the main stream (timing)
@@ -271,9 +272,11 @@ int enqueue_step(nlk_strips* S) {
     HIPCHK(T.c, hipSetDevice(T.device));
     int rc = tick(T, PH_COMMIT);
     if (rc) return rc;
-    SCHK(S, T.c, nlk_dev_mask_commit(T.c, T.marks_full, ngx, S->ngy, S->reach, T.active_full));
     if ((rc = tick(T, PH_GROUP))) return rc;
-    SCHK(S, T.c, nlk_dev_strip_group(T.c, T.acc, T.active_full + (size_t)T.p.gy0 * ngx));
+    // (one call: where the group kernel can, it replays the mask rows down to the strip's last one inside its own
+    // launch - the commit phase then reads as zero, its bit-plane kernel is counted with the groups)
+    SCHK(S, T.c, nlk_dev_strip_commit_group(T.c, T.acc, T.marks_full, ngx, S->ngy, S->reach, T.p.gy0, T.active_full));
+    T.chased = T.c->lazy_ngx != 0;
     if ((rc = tick(T, PH_ACC))) return rc;
     // the accumulator rows written outside my own rows, packed for their owners
     if (T.h_top + T.h_bot > 0) {
@@ -592,7 +595,18 @@ int nlk_strips_own_rows(nlk_strips* S, int local, int* y0, int* y1, float** rows
   if (y1) *y1 = T.p.own1;
   if (rows) *rows = T.out + (size_t)(T.p.own0 - T.p.Y0) * S->w * S->ch;
   if (marks_full) *marks_full = T.marks_full;
-  if (active_full) *active_full = T.active_full;
+  if (active_full) {
+    // (a strip whose group kernel replays the mask itself holds the decisions as tagged words: the bytes of the grid
+    // rows [0, its last row) are written now - the whole grid for the last strip; a replayed HIP graph never came
+    // through the call that would have noted it, hence from the strip's own flag)
+    if (T.chased) {
+      T.c->lazy_ngx = S->ngx; T.c->lazy_ngy = T.p.gy0 + T.rows; T.c->lazy_dst = T.active_full;
+      HIPCHK(T.c, hipSetDevice(T.device));
+      int rc = nlk_ctx_flush_active(T.c);
+      if (rc) return rc;
+    }
+    *active_full = T.active_full;
+  }
   return NLK_OK;
 }
 

@@ -40,6 +40,8 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
     tl.far = pass;
     tl.chase = c->rv.chase_words ? c->rv.chase_reach : 0;
     tl.chase_gen = c->rv.chase_gen;
+    tl.chase_row0 = c->rv.chase_row0;
+    tl.chase_rows = c->rv.chase_rows;
     tl.chase_planes = c->rv.chase_planes;
     tl.chase_words = c->rv.chase_words;
     // LDS tile halo = reach of the dominant kind of group; without the split the rare spatial-branch

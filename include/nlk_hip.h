@@ -215,6 +215,19 @@ int nlk_ctx_set_strip_accumulator(nlk_ctx *ctx, float *acc);
 int nlk_dev_mask_commit(nlk_ctx *ctx, const void *marks, int ngx, int ngy, int reach,
                         unsigned char *active);
 int nlk_dev_strip_group(nlk_ctx *ctx, float *acc, const unsigned char *active);
+/* nlk_dev_mask_commit over the whole grid (`marks`, `active`: ngx * ngy entries) + nlk_dev_strip_group on the strip
+ * whose first grid row is gy0, as one call: where the group kernel can replay the mask inside its own launch
+ * (8 x 8 patches, reach <= 3, grids up to 2048 targets wide; NLK_NO_CHASE=1 switches it off) only the grid rows down
+ * to the strip's last one are replayed, by the launch's first workgroup, while the others already work (`active` is
+ * then not written); otherwise exactly the two calls. Same decisions, same sums (reference: src/nlkalman.c:597-600,
+ * 930-931). */
+int nlk_dev_strip_commit_group(nlk_ctx *ctx, float *acc, const void *marks, int ngx, int ngy, int reach, int gy0,
+                               unsigned char *active);
+/* After a call whose group kernel replayed the mask itself (whole-frame calls of 8 x 8 patches,
+ * nlk_dev_strip_commit_group): write the decision bytes of the replayed grid rows - all of them for a frame call
+ * (into the context's records, what nlk_ctx_read_records does first), rows [0, gy0 + the strip's rows) of `active`
+ * for a strip - and wait. No-op otherwise. */
+int nlk_ctx_flush_active(nlk_ctx *ctx);
 
 /* per-target records of the last frame call, copied to host (tests only):
  * active[ngrid] (1 = processed), nsel/np0/nagg[ngrid], topk[ngrid*kmax] and
@@ -259,7 +272,9 @@ int nlk_strips_set_dry_run(nlk_strips *s, int on);
 int nlk_strips_step(nlk_strips *s);
 int nlk_strips_sync(nlk_strips *s);
 /* own rows [*y0, *y1) of the output of local strip `local` (device pointer, valid until the next step); the
- * whole-grid mark words and decisions it used (any pointer may be NULL) */
+ * whole-grid mark words, and the decisions it used: one byte per target of the grid rows from 0 down to the strip's
+ * own last row (a strip needs no later ones: the whole grid for the last strip; the rows after them are not
+ * defined). Any pointer may be NULL. Call after nlk_strips_sync. */
 int nlk_strips_own_rows(nlk_strips *s, int local, int *y0, int *y1, float **rows, void **marks_full,
                         unsigned char **active_full);
 nlk_ctx *nlk_strips_ctx(nlk_strips *s, int local);

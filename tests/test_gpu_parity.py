@@ -292,11 +292,14 @@ def test_gpu_strips_match_oracle_strips(ctx, built, O, synth, world):
     cases.assert_close(got, want, f"{world} strips on the GPU vs on the oracle")
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("world", [2, 4])
-def test_gpu_exact_strips_equal_whole_frame(ctx, built, O, synth, world):
+def test_gpu_exact_strips_equal_whole_frame(ctx, built, O, synth, world, fused):
     """The three-phase strip form (match per strip -> concatenated mark words ->
     whole-grid mask replay -> group per strip), i.e. what N ranks do in exact
-    mode, run sequentially on one GPU: must equal the whole-frame call."""
+    mode, run sequentially on one GPU: must equal the whole-frame call. `fused`: phases 2 + 3 of a strip as
+    one call (nlk_dev_strip_commit_group: the replay of the rows down to the strip's last one inside the group
+    kernel's launch, what csrc/strips.hip enqueues) instead of mask_commit + strip_group."""
     import importlib
     strips = importlib.import_module("bwd-nlkalman_amd.strips")
     w, h, ch, sigma = 96, 128, 3, 20.0
@@ -325,7 +328,12 @@ def test_gpu_exact_strips_equal_whole_frame(ctx, built, O, synth, world):
     for s, (d_cur, d_prev, hl, oy, ngy_l) in zip(plan, bufs):  # phase 3 per strip
         ctx.strip_match(None, d_cur, d_prev, None, w, hl, ch, sigma, p, oy, ngy_l)  # restore the strip state
         d_acc = ctx.upload(np.zeros((ch + 1, hl, w), np.float32))
-        ctx.strip_group(d_acc, d_active + s["gy0"] * ngx)
+        if fused:
+            d_scratch = ctx.upload(np.full(ngx * ngy, 7, np.uint8))   # (not read: the launch replays the mask itself)
+            ctx.strip_commit_group(d_acc, d_marks, ngx, ngy, reach, s["gy0"], d_scratch)
+            ctx.free(d_scratch)
+        else:
+            ctx.strip_group(d_acc, d_active + s["gy0"] * ngx)
         acc[:, s["Y0"]:s["Y1"]] += ctx.download(d_acc, (ch + 1, hl, w))
         for x in (d_cur, d_prev, d_acc):
             ctx.free(x)
@@ -334,7 +342,7 @@ def test_gpu_exact_strips_equal_whole_frame(ctx, built, O, synth, world):
     got = ctx.download(d_out, o1.shape)
     for x in (d_acc, d_cur, d_out, d_marks, d_active):
         ctx.free(x)
-    cases.assert_close(got, whole, f"exact strips x{world} vs whole frame", maxabs=5e-4, rmse=5e-5)
+    cases.assert_close(got, whole, f"exact strips x{world} vs whole frame (fused {fused})", maxabs=5e-4, rmse=5e-5)
 
 
 def _two_rank_worker(rank, world, port, q, backend="gloo"):

@@ -34,7 +34,7 @@ def _run_strips(built, ctx, world, o1, prev, sigma, p, smoother=False, overlap=T
         for i in range(S.nlocal):
             y0, y1, rows = S.download_rows(i)
             out[y0:y1] = rows
-        _, _, _, act = S.own_rows(0)
+        _, _, _, act = S.own_rows(S.nlocal - 1)   # (the last strip's decisions cover the whole grid)
         g = S.geometry(0)
         ngx, ngy = (w - p.patch_sz) // (p.patch_sz // 2) + 1, (h - p.patch_sz) // (p.patch_sz // 2) + 1
         active = ctx.download(act, (ngx * ngy,), np.uint8)
