@@ -30,6 +30,16 @@ $T python3 $ROOT/tools/startup_times.py > $OUT/startup_times.txt 2>&1
 $T python3 $ROOT/tools/power_probe.py --steps 3000 --warmup 50 --no-cpu > $OUT/power_probe.txt 2>&1
 $T python3 $ROOT/tools/mode_times.py > $OUT/mode_times_1080p.txt 2>&1
 NLK_HOST_TRACE=1 $T python3 $ROOT/tools/api_wall.py > $OUT/api_wall.txt 2>&1
+# the one-rank-of-N model (exchanges skipped) and where its step goes
+for W in C2 C3; do
+  $T python3 $ROOT/bench.py --no-cpu --workload $W --strip-model > $OUT/bench_${W}_strip_model.json 2>/dev/null
+done
+$T python3 $ROOT/tools/strip_model_phases.py 1 2 4 8 > $OUT/strip_model_phases.txt 2>&1
+(cd $ROOT && bash tools/ab_env.sh NLK_NO_CHASE=1 C2 3) > $OUT/ab_no_chase.txt 2>&1
+(cd $ROOT && bash tools/first_frame_bands.sh) > $OUT/first_frame_bands.txt 2>&1
+# LINES_ONLY=1: stop here (the counters were collected before, tools/profile_pmc_only.sh, so that these lines
+# could carry roofline.traffic of the same sources)
+[ -n "${LINES_ONLY:-}" ] && exit 0
 for W in C2 C3; do
   $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -o s -- python3 $ROOT/bench.py --no-cpu --no-extras --workload $W > $OUT/bench_${W}_under_rocprof.json 2>/dev/null
   i=0
