@@ -54,6 +54,21 @@ __device__ inline uint64_t nlk_wave_or(uint64_t v) {
   return v;
 }
 
+// bitwise OR (AND) over the 64 lanes, in every lane, without LDS: butterfly steps by DPP inside the rows of 16
+// lanes, then the two row-swap instructions
+template <bool AND>
+__device__ __forceinline__ uint32_t nlk_wave_bits(uint32_t v) {
+  auto op = [](uint32_t a, uint32_t b) { return AND ? (a & b) : (a | b); };
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, true));
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141 /* row_half_mirror */, 0xF, 0xF, true));
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140 /* row_mirror */, 0xF, 0xF, true));
+  const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = op(a[0], a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return op(b[0], b[1]);
+}
+
 // Selection for one target whose window holds n <= 64*M candidates and whose sums of squared
 // differences are in acc[] (candidate lane + 64*m in acc[m]). Leaves the k kept candidates, sorted, in
 // sel[0..k).
@@ -86,9 +101,20 @@ __device__ __forceinline__ void nlk_match_select(const float (&acc)[M], const ui
     nalive += __popcll(alive[m]);
   }
   // walk the key bits from the top; stop as soon as exactly kk candidates are undecided
-  // (they are then all kept) — typically after ~16 of the 32 bits
+  // (they are then all kept) — typically after ~16 of the 32 bits. The bits above the first one in which two
+  // candidates differ (sign, most of the exponent) decide nothing - every candidate has the same value there, a
+  // round would leave `alive`, `less` and kk as they are - so the walk starts below them: OR and AND of the keys over
+  // the wavefront, 16 vector instructions for ~10 rounds of ~20 dependent scalar ones each.
+  uint32_t k_or = 0u, k_and = ~0u;
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    k_or |= ok[m] ? key[m] : 0u;
+    k_and &= ok[m] ? key[m] : ~0u;
+  }
+  const uint32_t differ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nlk_wave_bits<false>(k_or) ^ nlk_wave_bits<true>(k_and)));
+  const int btop = differ ? 31 - __builtin_clz(differ) : -1;
 #pragma unroll 1
-  for (int b = 31; b >= 0 && nalive != kk; --b) {
+  for (int b = btop; b >= 0 && nalive != kk; --b) {
     uint64_t one[M];
     int cnt0 = 0;
 #pragma unroll
@@ -209,19 +235,38 @@ __device__ __forceinline__ void nlk_match_target(const float* __restrict__ tile,
 // ascending, columns ascending inside a row, channels innermost: every target still receives its terms
 // in the reference's (hy, hx, c) order with one rounding per subtract, multiply and add, i.e. the sums
 // are bit-identical to nlk_match_target's; subtractions and multiplications drop by 2.1x (4 x 2 blocks).
+// The targets' own pixels are the same for every lane: they come from the image through the SCALAR cache (timg =
+// the union region's first pixel in plane 0, row stride w, plane stride npix) instead of as broadcast LDS reads -
+// the LDS array, not the vector ALU, is what the row loops keep busiest (54 LDS instructions per row of a 2 x 2
+// block, a third of their cycles for values that need no lane), and a vector instruction takes one scalar operand.
+#ifndef NLK_BM_SCALAR_TARGET
+#define NLK_BM_SCALAR_TARGET 1
+#endif
 template <int PSZ, int CH, int BX, int M, bool B0, bool B1>
 __device__ __forceinline__ void nlk_block_rows(const float* __restrict__ tile, int plane, int rwp, int tbase,
-                                               const int (&cq)[M], int ry0, int ry1, float (&acc)[2][BX][M]) {
+                                               const int (&cq)[M], int ry0, int ry1, float (&acc)[2][BX][M],
+                                               const float* __restrict__ timg, int w, size_t npix) {
   constexpr int step = PSZ / 2, UW = (BX - 1) * step + PSZ;
+  const float* splane[CH];  // (one base per plane, set once; a row is a 32-bit offset from it)
+#pragma unroll
+  for (int c = 0; c < CH; ++c) splane[c] = timg + c * npix;
 #pragma unroll 1
   for (int ry = ry0; ry < ry1; ++ry) {
 #pragma clang fp contract(off)
     const float* trow = tile + tbase + ry * rwp;
+    const int soff = ry * w;
+    float tvs[CH][UW];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const float* srow = splane[c] + soff;
+#pragma unroll
+      for (int rx = 0; rx < UW; ++rx) tvs[c][rx] = NLK_BM_SCALAR_TARGET ? srow[rx] : trow[c * plane + rx];
+    }
 #pragma unroll
     for (int rx = 0; rx < UW; ++rx)
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
-        const float tv = trow[c * plane + rx];
+        const float tv = tvs[c][rx];
 #pragma unroll
         for (int m = 0; m < M; ++m) {
           const float e = tile[c * plane + cq[m] + ry * rwp + rx] - tv;
@@ -249,7 +294,8 @@ __device__ __forceinline__ void nlk_window_xy(int wsz, int n, int lane, uint32_t
 }
 template <int PSZ, int CH, int BX, int M>
 __device__ __forceinline__ void nlk_match_block(const float* __restrict__ tile, int plane, int rwp, int tbase,
-                                                int wsz, int n, int lane, float (&acc)[2][BX][M]) {
+                                                int wsz, int n, int lane, float (&acc)[2][BX][M],
+                                                const float* __restrict__ timg, int w, size_t npix) {
   constexpr int step = PSZ / 2;
   const int nwx = 2 * wsz + 1;
   int cq[M];
@@ -264,9 +310,9 @@ __device__ __forceinline__ void nlk_match_block(const float* __restrict__ tile, 
       for (int bx = 0; bx < BX; ++bx) acc[by][bx][m] = 0.f;
   }
   // (rows of the upper targets only, of both, of the lower targets only)
-  nlk_block_rows<PSZ, CH, BX, M, true, false>(tile, plane, rwp, tbase, cq, 0, step, acc);
-  nlk_block_rows<PSZ, CH, BX, M, true, true>(tile, plane, rwp, tbase, cq, step, PSZ, acc);
-  nlk_block_rows<PSZ, CH, BX, M, false, true>(tile, plane, rwp, tbase, cq, PSZ, PSZ + step, acc);
+  nlk_block_rows<PSZ, CH, BX, M, true, false>(tile, plane, rwp, tbase, cq, 0, step, acc, timg, w, npix);
+  nlk_block_rows<PSZ, CH, BX, M, true, true>(tile, plane, rwp, tbase, cq, step, PSZ, acc, timg, w, npix);
+  nlk_block_rows<PSZ, CH, BX, M, false, true>(tile, plane, rwp, tbase, cq, PSZ, PSZ + step, acc, timg, w, npix);
 }
 
 // Group membership, records and mark word of one target whose sorted k-NN list is in sel[0..k)
@@ -390,7 +436,10 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int r = min(r0 + nwaves * j, nrows - 1);
-        const int c = r / rh, y = r - c * rh;
+        int c = 0, y = r;  // (r / rh by comparison: an integer division is ~35 scalar instructions, 16 per wavefront here)
+#pragma unroll
+        for (int cc = 1; cc < CH; ++cc)
+          if (r >= cc * rh) { c = cc; y = r - cc * rh; }
         const float* src = img + c * npix + (size_t)(ry0 + y) * g.w + rx0;
         v0[j] = lane < rw ? src[lane] : 0.f;
         v1[j] = lane + 64 < rw ? src[lane + 64] : 0.f;
@@ -399,7 +448,10 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
       for (int j = 0; j < 8; ++j) {
         const int r = r0 + nwaves * j;
         if (r < nrows) {
-          const int c = r / rh, y = r - c * rh;
+          int c = 0, y = r;
+#pragma unroll
+          for (int cc = 1; cc < CH; ++cc)
+            if (r >= cc * rh) { c = cc; y = r - cc * rh; }
           float* dst = tile + c * plane + y * rwp;
           if (lane < rw) dst[lane] = v0[j];
           if (lane + 64 < rw) dst[lane + 64] = v1[j];
@@ -508,7 +560,8 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
     auto run_block = [&](auto mtag) {
       constexpr int M = decltype(mtag)::value;
       float acc[2][BX][M];
-      nlk_match_block<PSZ, CH, BX, M>(tile, plane, rwp, (py0 - ry0) * rwp + (px0 - rx0), wsz, n, lane, acc);
+      nlk_match_block<PSZ, CH, BX, M>(tile, plane, rwp, (py0 - ry0) * rwp + (px0 - rx0), wsz, n, lane, acc,
+                                      img + (size_t)py0 * g.w + px0, g.w, (size_t)g.w * g.h);
       // (the window positions are only needed by the selection: worked out AFTER the row loops - carried through
       // them they were spilled to scratch at the 64-register budget, 85 MB of traffic per 1080p launch in round 3;
       // the asm keeps the compiler from hoisting the division back in front of the loops)
