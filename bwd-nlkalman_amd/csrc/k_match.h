@@ -54,21 +54,6 @@ __device__ inline uint64_t nlk_wave_or(uint64_t v) {
   return v;
 }
 
-// bitwise OR (AND) over the 64 lanes, in every lane, without LDS: butterfly steps by DPP inside the rows of 16
-// lanes, then the two row-swap instructions
-template <bool AND>
-__device__ __forceinline__ uint32_t nlk_wave_bits(uint32_t v) {
-  auto op = [](uint32_t a, uint32_t b) { return AND ? (a & b) : (a | b); };
-  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
-  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, true));
-  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141 /* row_half_mirror */, 0xF, 0xF, true));
-  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140 /* row_mirror */, 0xF, 0xF, true));
-  const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-  v = op(a[0], a[1]);
-  const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-  return op(b[0], b[1]);
-}
-
 // Selection for one target whose window holds n <= 64*M candidates and whose sums of squared
 // differences are in acc[] (candidate lane + 64*m in acc[m]). Leaves the k kept candidates, sorted, in
 // sel[0..k).
@@ -101,20 +86,11 @@ __device__ __forceinline__ void nlk_match_select(const float (&acc)[M], const ui
     nalive += __popcll(alive[m]);
   }
   // walk the key bits from the top; stop as soon as exactly kk candidates are undecided
-  // (they are then all kept) — typically after ~16 of the 32 bits. The bits above the first one in which two
-  // candidates differ (sign, most of the exponent) decide nothing - every candidate has the same value there, a
-  // round would leave `alive`, `less` and kk as they are - so the walk starts below them: OR and AND of the keys over
-  // the wavefront, 16 vector instructions for ~10 rounds of ~20 dependent scalar ones each.
-  uint32_t k_or = 0u, k_and = ~0u;
-#pragma unroll
-  for (int m = 0; m < M; ++m) {
-    k_or |= ok[m] ? key[m] : 0u;
-    k_and &= ok[m] ? key[m] : ~0u;
-  }
-  const uint32_t differ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nlk_wave_bits<false>(k_or) ^ nlk_wave_bits<true>(k_and)));
-  const int btop = differ ? 31 - __builtin_clz(differ) : -1;
+  // (they are then all kept) — typically after ~16 of the 32 bits. (Round 4 tried starting below the keys' common
+  // prefix - OR and AND over the wavefront, ~10 rounds of ~20 dependent scalar instructions saved per target: exact,
+  // and no change in the launch time: the selection is not what the kernel waits for.)
 #pragma unroll 1
-  for (int b = btop; b >= 0 && nalive != kk; --b) {
+  for (int b = 31; b >= 0 && nalive != kk; --b) {
     uint64_t one[M];
     int cnt0 = 0;
 #pragma unroll
