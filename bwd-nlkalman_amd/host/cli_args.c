@@ -1,5 +1,6 @@
 /* cli_args.c — see cli_args.h. */
 #include "cli_args.h"
+#include "cli_server.h" /* cli_exit: leaves the process, or goes back to the resident server's loop */
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -8,7 +9,7 @@
 static void die_opt(const struct cli_option *o, int is_long, const char *reason) {
   if (is_long) fprintf(stderr, "error: option `--%s` %s\n", o->long_name, reason);
   else fprintf(stderr, "error: option `-%c` %s\n", o->short_name, reason);
-  exit(1);
+  cli_exit(1);
 }
 
 /* `inl` = value glued to the option (--x=v, -xv) or NULL: then the next argv is used */
@@ -66,7 +67,7 @@ void cli_parse(const struct cli_option *opts, const char *prog, const char *desc
     if (a[1] != '-') {                  /* short option, value glued or next */
       if (a[1] == 'h' && !a[2]) {
         cli_usage(opts, prog, description);
-        exit(0);
+        cli_exit(0);
       }
       const struct cli_option *o = opts;
       for (; o->type != CLI_END; ++o)
@@ -78,7 +79,7 @@ void cli_parse(const struct cli_option *opts, const char *prog, const char *desc
     if (!a[2]) break; /* `--` */
     if (!strcmp(a + 2, "help")) {
       cli_usage(opts, prog, description);
-      exit(0);
+      cli_exit(0);
     }
     {
       const struct cli_option *o = opts;
@@ -97,7 +98,7 @@ void cli_parse(const struct cli_option *opts, const char *prog, const char *desc
   unknown:
     fprintf(stderr, "error: unknown option `%s`\n", a);
     cli_usage(opts, prog, description);
-    exit(1);
+    cli_exit(1);
   }
 }
 

@@ -1,0 +1,246 @@
+/* cli_server.c — see cli_server.h. Wire format of a request, client -> server on a unix stream socket:
+ *   [u32 payload bytes] with the client's stdout and stderr attached (SCM_RIGHTS), then the payload:
+ *   "NLK1" 0, tool 0, working directory 0, argc (decimal) 0, argv[0] 0 ... argv[argc-1] 0
+ * and the answer: [i32 exit status]. */
+#include "cli_server.h"
+
+#include <errno.h>
+#include <limits.h>
+#include <setjmp.h>
+#include <signal.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/socket.h>
+#include <sys/un.h>
+#include <unistd.h>
+
+#include "nlk_hip.h"
+
+/* ---- what a tool may not do by itself inside a resident process */
+static jmp_buf g_back;
+static int g_serving = 0;
+static volatile int g_status = 0;
+
+void cli_exit(int status) {
+  if (!g_serving) exit(status);
+  g_status = status;
+  longjmp(g_back, 1);
+}
+
+#define CLI_MAX_DEV 64
+static struct { struct nlk_ctx *c; void *p; } g_dev[CLI_MAX_DEV];
+static int g_ndev = 0;
+
+int cli_dev_alloc(struct nlk_ctx *c, void **p, size_t bytes) {
+  const int rc = nlk_dev_alloc(c, p, bytes);
+  if (rc == NLK_OK && g_serving && g_ndev < CLI_MAX_DEV) {
+    g_dev[g_ndev].c = c;
+    g_dev[g_ndev++].p = *p;
+  }
+  return rc;
+}
+
+void cli_dev_release(void) {
+  for (int i = 0; i < g_ndev; ++i) {
+    (void)nlk_sync(g_dev[i].c);
+    (void)nlk_dev_free(g_dev[i].c, g_dev[i].p);
+  }
+  g_ndev = 0;
+}
+
+/* ---- both ends of the socket */
+static int write_all(int fd, const void *buf, size_t n) {
+  const char *p = (const char *)buf;
+  while (n) {
+    const ssize_t k = write(fd, p, n);
+    if (k < 0 && errno == EINTR) continue;
+    if (k <= 0) return -1;
+    p += k;
+    n -= (size_t)k;
+  }
+  return 0;
+}
+
+static int read_all(int fd, void *buf, size_t n) {
+  char *p = (char *)buf;
+  while (n) {
+    const ssize_t k = read(fd, p, n);
+    if (k < 0 && errno == EINTR) continue;
+    if (k <= 0) return -1;
+    p += k;
+    n -= (size_t)k;
+  }
+  return 0;
+}
+
+static int unix_address(const char *path, struct sockaddr_un *a) {
+  memset(a, 0, sizeof *a);
+  a->sun_family = AF_UNIX;
+  if (strlen(path) >= sizeof a->sun_path) return -1;
+  strcpy(a->sun_path, path);
+  return 0;
+}
+
+int cli_remote(const char *tool, int argc, const char **argv) {
+  const char *path = getenv("NLK_SERVER");
+  struct sockaddr_un a;
+  if (!path || !path[0] || unix_address(path, &a)) return -1;
+  const int s = socket(AF_UNIX, SOCK_STREAM, 0);
+  if (s < 0) return -1;
+  if (connect(s, (struct sockaddr *)&a, sizeof a)) {
+    close(s);
+    return -1; /* nobody listening: the caller does the work itself */
+  }
+  char cwd[PATH_MAX];
+  if (!getcwd(cwd, sizeof cwd)) strcpy(cwd, ".");
+  size_t n = 5 + strlen(tool) + 1 + strlen(cwd) + 1 + 16;
+  for (int i = 0; i < argc; ++i) n += strlen(argv[i]) + 1;
+  char *buf = (char *)malloc(n), *q = buf;
+  if (!buf) { close(s); return -1; }
+  q += sprintf(q, "NLK1") + 1;
+  q += sprintf(q, "%s", tool) + 1;
+  q += sprintf(q, "%s", cwd) + 1;
+  q += sprintf(q, "%d", argc) + 1;
+  for (int i = 0; i < argc; ++i) q += sprintf(q, "%s", argv[i]) + 1;
+  const uint32_t len = (uint32_t)(q - buf);
+
+  /* the length word travels with this process's stdout and stderr */
+  fflush(stdout);
+  fflush(stderr);
+  struct msghdr m;
+  struct iovec io = {(void *)&len, sizeof len};
+  union { char b[CMSG_SPACE(2 * sizeof(int))]; struct cmsghdr align; } ctl;
+  memset(&m, 0, sizeof m);
+  memset(&ctl, 0, sizeof ctl);
+  m.msg_iov = &io;
+  m.msg_iovlen = 1;
+  m.msg_control = ctl.b;
+  m.msg_controllen = sizeof ctl.b;
+  struct cmsghdr *cm = CMSG_FIRSTHDR(&m);
+  cm->cmsg_level = SOL_SOCKET;
+  cm->cmsg_type = SCM_RIGHTS;
+  cm->cmsg_len = CMSG_LEN(2 * sizeof(int));
+  const int fds[2] = {1, 2};
+  memcpy(CMSG_DATA(cm), fds, sizeof fds);
+  int32_t status = -1;
+  const int sent = sendmsg(s, &m, 0) == (ssize_t)sizeof len && !write_all(s, buf, len);
+  free(buf);
+  if (!sent || read_all(s, &status, sizeof status)) {
+    /* the request was (perhaps) taken and the answer never came: running the tool again here could write the
+       outputs twice - report instead */
+    fprintf(stderr, "%s: the server at %s went away\n", tool, path);
+    close(s);
+    return 1;
+  }
+  close(s);
+  return (int)(status & 0xFF);
+}
+
+int cli_serve(const char *path, const struct cli_tool *tools) {
+  struct sockaddr_un a;
+  if (unix_address(path, &a)) return fprintf(stderr, "nlk-server: socket path too long\n"), 1;
+  const int ls = socket(AF_UNIX, SOCK_STREAM, 0);
+  if (ls < 0) return perror("nlk-server: socket"), 1;
+  unlink(path);
+  if (bind(ls, (struct sockaddr *)&a, sizeof a) || listen(ls, 64)) return perror("nlk-server: bind / listen"), 1;
+  signal(SIGPIPE, SIG_IGN);
+  char home[PATH_MAX];
+  if (!getcwd(home, sizeof home)) strcpy(home, "/");
+
+  for (;;) {
+    const int cs = accept(ls, NULL, NULL);
+    if (cs < 0) {
+      if (errno == EINTR) continue;
+      perror("nlk-server: accept");
+      break;
+    }
+    /* length word + the client's stdout / stderr */
+    uint32_t len = 0;
+    struct msghdr m;
+    struct iovec io = {&len, sizeof len};
+    union { char b[CMSG_SPACE(2 * sizeof(int))]; struct cmsghdr align; } ctl;
+    memset(&m, 0, sizeof m);
+    m.msg_iov = &io;
+    m.msg_iovlen = 1;
+    m.msg_control = ctl.b;
+    m.msg_controllen = sizeof ctl.b;
+    int fds[2] = {-1, -1};
+    if (recvmsg(cs, &m, MSG_WAITALL) != (ssize_t)sizeof len || len < 8 || len > (1u << 20)) {
+      close(cs);
+      continue;
+    }
+    for (struct cmsghdr *cm = CMSG_FIRSTHDR(&m); cm; cm = CMSG_NXTHDR(&m, cm))
+      if (cm->cmsg_level == SOL_SOCKET && cm->cmsg_type == SCM_RIGHTS && cm->cmsg_len >= CMSG_LEN(2 * sizeof(int)))
+        memcpy(fds, CMSG_DATA(cm), sizeof fds);
+    char *buf = (char *)malloc((size_t)len + 1);
+    if (!buf || read_all(cs, buf, len)) {
+      free(buf);
+      if (fds[0] >= 0) close(fds[0]);
+      if (fds[1] >= 0) close(fds[1]);
+      close(cs);
+      continue;
+    }
+    buf[len] = 0;
+    /* payload -> tool, directory, argv */
+    const char *end = buf + len, *q = buf;
+    const char *magic = q; q += strlen(q) + 1;
+    const char *tool = q < end ? q : ""; q += strlen(q) + 1;
+    const char *cwd = q < end ? q : "."; q += strlen(q) + 1;
+    const int argc = q < end ? atoi(q) : 0; q += strlen(q) + 1;
+    const char **argv = (const char **)calloc((size_t)(argc > 0 ? argc : 0) + 1, sizeof(char *));
+    int ok = argv && !strcmp(magic, "NLK1") && argc >= 0 && argc < 4096;
+    for (int i = 0; ok && i < argc; ++i) {
+      if (q >= end) { ok = 0; break; }
+      argv[i] = q;
+      q += strlen(q) + 1;
+    }
+    int32_t status = 125;
+    int stop = 0;
+    if (ok && !strcmp(tool, "shutdown")) {
+      status = 0;
+      stop = 1;
+    } else if (ok) {
+      cli_tool_fn fn = NULL;
+      for (const struct cli_tool *t = tools; t->name; ++t)
+        if (!strcmp(t->name, tool)) fn = t->fn;
+      /* the tool writes to the CLIENT's stdout / stderr and works in the client's directory */
+      fflush(stdout);
+      fflush(stderr);
+      const int so = dup(1), se = dup(2);
+      if (fds[0] >= 0) dup2(fds[0], 1);
+      if (fds[1] >= 0) dup2(fds[1], 2);
+      if (!fn) {
+        fprintf(stderr, "nlk-server: no tool `%s` here\n", tool);
+        status = 127;
+      } else if (chdir(cwd)) {
+        fprintf(stderr, "nlk-server: cannot enter %s\n", cwd);
+        status = 126;
+      } else {
+        g_serving = 1;
+        if (setjmp(g_back) == 0) status = fn(argc, argv);
+        else status = g_status;
+        g_serving = 0;
+        cli_dev_release();
+      }
+      fflush(stdout);
+      fflush(stderr);
+      dup2(so, 1);
+      dup2(se, 2);
+      close(so);
+      close(se);
+      if (chdir(home)) { /* (the next request brings its own directory) */ }
+    }
+    if (fds[0] >= 0) close(fds[0]);
+    if (fds[1] >= 0) close(fds[1]);
+    (void)write_all(cs, &status, sizeof status);
+    close(cs);
+    free((void *)argv);
+    free(buf);
+    if (stop) break;
+  }
+  close(ls);
+  unlink(path);
+  return 0;
+}

@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include "cli_args.h"
+#include "cli_server.h"
 #include "imgio.h"
 #include "nlk_hip.h"
 #include "nlkalman.h"
@@ -44,14 +45,15 @@ static void dump(const char *title, const struct nlkalman_params *p) {
 static float *to_dev(nlk_ctx *c, const float *h, size_t n) {
   void *d = NULL;
   if (!h) return NULL;
-  if (nlk_dev_alloc(c, &d, n * sizeof(float)) || nlk_h2d(c, d, h, n * sizeof(float))) {
+  if (cli_dev_alloc(c, &d, n * sizeof(float)) || nlk_h2d(c, d, h, n * sizeof(float))) {
     fprintf(stderr, "nlkalman-flt: %s\n", nlk_last_error(c));
-    exit(1);
+    cli_exit(1);
   }
   return (float *)d;
 }
 
-int main(int argc, const char **argv) {
+/* the tool as a function: main() below, or the resident server (main_server.c) */
+int nlk_tool_flt(int argc, const char **argv) {
   const char *noisy_path = NULL, *bflow_path = NULL, *boccl_path = NULL;
   const char *flt10_path = NULL, *flt20_path = NULL, *flt11_path = NULL, *flt21_path = NULL;
   float sigma = 0.f;
@@ -168,7 +170,7 @@ int main(int argc, const char **argv) {
   float *d_occ = to_dev(c, bocc, (size_t)w * h);
   float *d_f10 = to_dev(c, flt10, n), *d_f20 = to_dev(c, flt20, n), *d_f11 = to_dev(c, flt11, n);
   void *d_warp = NULL, *d_f21 = NULL, *tmp = NULL;
-  CHK(nlk_dev_alloc(c, &d_warp, bytes));
+  CHK(cli_dev_alloc(c, &d_warp, bytes));
   CHK(nlk_dev_rgb2opp(c, d_nisy, w, h, ch));
   if (d_f10) CHK(nlk_dev_rgb2opp(c, d_f10, w, h, ch));
   if (d_f20) CHK(nlk_dev_rgb2opp(c, d_f20, w, h, ch));
@@ -179,7 +181,7 @@ int main(int argc, const char **argv) {
       CHK(nlk_dev_warp_bicubic(c, (float *)d_warp, d_f10, d_flo, d_occ, w, h, ch));
       prev = (const float *)d_warp;
     }
-    CHK(nlk_dev_alloc(c, &tmp, bytes));
+    CHK(cli_dev_alloc(c, &tmp, bytes));
     d_f11 = (float *)tmp;
     CHK(nlk_dev_filter_frame(c, d_f11, d_nisy, prev, NULL, w, h, ch, sigma, &f1));
   } else {
@@ -194,7 +196,7 @@ int main(int argc, const char **argv) {
       CHK(nlk_dev_warp_bicubic(c, (float *)d_warp, d_f20, d_flo, d_occ, w, h, ch));
       prev = (const float *)d_warp;
     }
-    CHK(nlk_dev_alloc(c, &d_f21, bytes));
+    CHK(cli_dev_alloc(c, &d_f21, bytes));
     CHK(nlk_dev_filter_frame(c, (float *)d_f21, d_nisy, prev, d_f11, w, h, ch, sigma, &f2));
     if (flt11_path) { /* sic: the reference guards this write with flt11_path (:376) */
       CHK(nlk_dev_opp2rgb(c, (float *)d_f21, w, h, ch));
@@ -211,3 +213,10 @@ int main(int argc, const char **argv) {
   free(host); free(nisy); free(bflo); free(bocc); free(flt10); free(flt20); free(flt11);
   return cli_leave(EXIT_SUCCESS);
 }
+
+#ifndef NLK_TOOL_NO_MAIN
+int main(int argc, const char **argv) {
+  const int remote = cli_remote("nlkalman-flt", argc, argv); /* a resident server (NLK_SERVER) does the work, if there is one */
+  return remote >= 0 ? remote : nlk_tool_flt(argc, argv);
+}
+#endif

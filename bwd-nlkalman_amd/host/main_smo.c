@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include "cli_args.h"
+#include "cli_server.h"
 #include "imgio.h"
 #include "nlk_hip.h"
 #include "nlkalman.h"
@@ -30,14 +31,15 @@ nlk_ctx *nlkalman_hip_context(void);
 static float *to_dev(nlk_ctx *c, const float *h, size_t n) {
   void *d = NULL;
   if (!h) return NULL;
-  if (nlk_dev_alloc(c, &d, n * sizeof(float)) || nlk_h2d(c, d, h, n * sizeof(float))) {
+  if (cli_dev_alloc(c, &d, n * sizeof(float)) || nlk_h2d(c, d, h, n * sizeof(float))) {
     fprintf(stderr, "nlkalman-smo: %s\n", nlk_last_error(c));
-    exit(1);
+    cli_exit(1);
   }
   return (float *)d;
 }
 
-int main(int argc, const char **argv) {
+/* the tool as a function: main() below, or the resident server (main_server.c) */
+int nlk_tool_smo(int argc, const char **argv) {
   const char *flt1_path = NULL, *smo0_path = NULL, *fflo_path = NULL, *focc_path = NULL, *smo1_path = NULL;
   float sigma = 0.f;
   int verbose = 0;
@@ -103,8 +105,8 @@ int main(int argc, const char **argv) {
   float *d_flt1 = to_dev(c, flt1, n), *d_smo0 = to_dev(c, smo0, n);
   float *d_flo = to_dev(c, fflo, (size_t)w * h * 2), *d_occ = to_dev(c, focc, (size_t)w * h);
   void *d_warp = NULL, *d_smo1 = NULL;
-  CHK(nlk_dev_alloc(c, &d_warp, bytes));
-  CHK(nlk_dev_alloc(c, &d_smo1, bytes));
+  CHK(cli_dev_alloc(c, &d_warp, bytes));
+  CHK(cli_dev_alloc(c, &d_smo1, bytes));
   CHK(nlk_dev_rgb2opp(c, d_flt1, w, h, ch));
   CHK(nlk_dev_rgb2opp(c, d_smo0, w, h, ch));
   const float *prev = d_smo0;
@@ -121,3 +123,10 @@ int main(int argc, const char **argv) {
   const char *e = getenv("NLK_SMO_REFERENCE_EXIT");
   return cli_leave((e && e[0] == '1') ? 1 : 0);
 }
+
+#ifndef NLK_TOOL_NO_MAIN
+int main(int argc, const char **argv) {
+  const int remote = cli_remote("nlkalman-smo", argc, argv); /* a resident server (NLK_SERVER) does the work, if there is one */
+  return remote >= 0 ? remote : nlk_tool_smo(argc, argv);
+}
+#endif

@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include "cli_server.h"
 #include "imgio.h"
 #include "nlk_hip.h"
 
@@ -23,7 +24,8 @@ static int fail_hip(const char *what, nlk_ctx *c) {
   return EXIT_FAILURE;
 }
 
-int main(int argc, char *argv[]) {
+/* the tool as a function: main() below, or the resident server (main_server.c) */
+int nlk_tool_tvl1(int argc, const char **argv) {
   if (argc < 3) {
     fprintf(stderr, "Usage: %s I0 I1 [out "
                     "nproc tau lambda theta nscales fscale zfactor nwarps epsilon "
@@ -81,8 +83,8 @@ int main(int argc, char *argv[]) {
   const size_t n = (size_t)nx * ny;
   void *d_im = NULL, *d_g0 = NULL, *d_g1 = NULL, *d_flow = NULL;
   const size_t cmax = (size_t)(c0 > c1 ? c0 : c1);
-  if (nlk_dev_alloc(c, &d_im, n * cmax * sizeof(float)) || nlk_dev_alloc(c, &d_g0, n * sizeof(float)) ||
-      nlk_dev_alloc(c, &d_g1, n * sizeof(float)) || nlk_dev_alloc(c, &d_flow, 2 * n * sizeof(float)))
+  if (cli_dev_alloc(c, &d_im, n * cmax * sizeof(float)) || cli_dev_alloc(c, &d_g0, n * sizeof(float)) ||
+      cli_dev_alloc(c, &d_g1, n * sizeof(float)) || cli_dev_alloc(c, &d_flow, 2 * n * sizeof(float)))
     return fail_hip("allocation", c);
   if (nlk_h2d(c, d_im, I0, n * c0 * sizeof(float)) || nlk_dev_gray(c, (float *)d_g0, (float *)d_im, nx, ny, c0) ||
       nlk_sync(c) ||
@@ -100,6 +102,13 @@ int main(int argc, char *argv[]) {
     return EXIT_FAILURE;
   }
   free(I0); free(I1); free(flow);
-  nlk_dev_free(c, d_im); nlk_dev_free(c, d_g0); nlk_dev_free(c, d_g1); nlk_dev_free(c, d_flow);
+  /* (device buffers: released with the process, or by the resident server after the request - cli_server.h) */
   return EXIT_SUCCESS;
 }
+
+#ifndef NLK_TOOL_NO_MAIN
+int main(int argc, const char **argv) {
+  const int remote = cli_remote("tvl1flow", argc, argv); /* a resident server (NLK_SERVER) does the work, if there is one */
+  return remote >= 0 ? remote : nlk_tool_tvl1(argc, argv);
+}
+#endif

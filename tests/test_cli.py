@@ -164,6 +164,93 @@ def test_image_io_against_pil(tools, tmp_path):
     assert run("nlk-imgconv", tmp_path / "nope.tif", tmp_path / "x.pfm").returncode == 1
 
 
+# ------------------------------------------------------------ the tools behind a resident server
+
+import contextlib
+import time
+
+
+@contextlib.contextmanager
+def server(tmp_path, *flags, **more_env):
+    """bin/nlk-server on a socket of its own; the tools find it through NLK_SERVER"""
+    sock = str(tmp_path / "nlk.sock")
+    proc = subprocess.Popen([os.path.join(BIN, "nlk-server"), *flags, sock], stdout=subprocess.PIPE,
+                            stderr=subprocess.PIPE, env=dict(os.environ, **more_env))
+    try:
+        for _ in range(600):       # (with a device context: the ~0.3 s of a HIP start, once)
+            if os.path.exists(sock) or proc.poll() is not None:
+                break
+            time.sleep(0.05)
+        assert proc.poll() is None and os.path.exists(sock), proc.stderr.read()
+        yield dict(os.environ, NLK_SERVER=sock)
+    finally:
+        subprocess.run([os.path.join(BIN, "nlk-server"), "--stop", sock], capture_output=True)
+        try:
+            proc.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+
+
+def test_tools_behind_the_resident_server_speak_the_same_grammar(tools, tmp_path):
+    """NLK_SERVER=<socket>: the tool hands its arguments, directory, stdout and stderr to bin/nlk-server and
+    exits with the status it returns (host/cli_server.h). Usage text, messages, exit codes and where they are
+    printed must be what the tool prints by itself (reference: src/main-flt.c:71-149, lib/argparse); without a
+    listener the tool works by itself; the server survives tools that leave through exit()."""
+    with server(tmp_path, "--lazy") as env:
+        for tool, args in (("nlkalman-flt", ["-h"]), ("nlkalman-smo", ["--help"]), ("nlkalman-flt", ["--nope"]),
+                           ("nlkalman-smo", ["-s"]), ("nlkalman-flt", ["--f1_p", "x"]), ("nlkalman-flt", ["--f1_p", "0"]),
+                           ("nlkalman-smo", ["--s1_p", "0", "--smo1", "x.tif"]), ("tvl1flow", []),
+                           ("nlkalman-flt", ["-i", "missing.tif", "--flt11", "o.tif", "-s", "10"])):
+            local = run(tool, *args, cwd=tmp_path)
+            remote = run(tool, *args, cwd=tmp_path, env=env)
+            assert (remote.returncode, remote.stdout, remote.stderr) == (local.returncode, local.stdout, local.stderr), \
+                (tool, args)
+        r = run("nlkalman-flt", "-h", env=dict(env, NLK_SERVER=str(tmp_path / "nobody.sock")))
+        assert r.returncode == 0 and r.stdout.startswith("Usage: nlkalman-flt")     # no listener: by itself
+    r = subprocess.run([os.path.join(BIN, "nlk-server"), "--stop", str(tmp_path / "nlk.sock")], capture_output=True,
+                       text=True)
+    assert r.returncode == 1 and "nobody listens" in r.stderr
+
+
+@pytest.mark.gpu
+def test_pipeline_through_the_resident_server(tools, tmp_path):
+    """The steps scripts/nlkalman-seq.sh runs per frame (flow, first and second iteration, smoother) as separate
+    processes - once by themselves, once with bin/nlk-server doing the work: the files written must be identical
+    byte for byte (bit-reproducible aggregation on both sides: NLK_DETERMINISTIC), device memory must not pile up
+    over requests, and a step must no longer cost a HIP start."""
+    I = cases.inputs("rgb72x48_s40")
+    S = "%g" % I["sigma"]
+    wpfm(str(tmp_path / "n0.pfm"), I["n0"])
+    wpfm(str(tmp_path / "n1.pfm"), I["n1"])
+    wflo(str(tmp_path / "b.flo"), I["flow"])
+
+    def steps(tag, env):
+        q = lambda f: str(tmp_path / (tag + f))  # noqa: E731
+        seq = [("tvl1flow", str(tmp_path / "n1.pfm"), str(tmp_path / "n0.pfm"), q("tv.flo")),
+               ("nlkalman-flt", "-i", str(tmp_path / "n0.pfm"), "-s", S, "--flt11", q("f1_0.pfm"), "--flt21", q("f2_0.pfm")),
+               ("nlkalman-flt", "-i", str(tmp_path / "n1.pfm"), "-s", S, "--f2_p", "0", "-o", str(tmp_path / "b.flo"),
+                "--flt10", q("f1_0.pfm"), "--flt11", q("f1_1.pfm")),
+               ("nlkalman-flt", "-i", str(tmp_path / "n1.pfm"), "-s", S, "--f1_p", "0", "-o", str(tmp_path / "b.flo"),
+                "--flt11", q("f1_1.pfm"), "--flt20", q("f2_0.pfm"), "--flt21", q("f2_1.pfm")),
+               ("nlkalman-smo", "--flt1", q("f2_0.pfm"), "--smo0", q("f2_1.pfm"), "--smo1", q("s1_0.pfm"), "-s", S)]
+        t0 = time.perf_counter()
+        for a in seq:
+            r = run(*a, env=env)
+            assert r.returncode == 0, (a, r.stderr)
+        return (time.perf_counter() - t0) / len(seq)
+
+    alone = steps("a_", dict(os.environ, NLK_DETERMINISTIC="1"))
+    with server(tmp_path, NLK_DETERMINISTIC="1") as env:
+        steps("w_", env)                      # (code objects load on first use)
+        served = min(steps("s_", env) for _ in range(3))
+        for _ in range(40):                   # 200 more requests: what a request allocates is released
+            steps("s_", env)
+    for f in ("tv.flo", "f1_0.pfm", "f2_0.pfm", "f1_1.pfm", "f2_1.pfm", "s1_0.pfm"):
+        a, b = (open(str(tmp_path / (t + f)), "rb").read() for t in ("a_", "s_"))
+        assert a == b, f
+    assert served < 0.1 and served < alone / 2, (served, alone)
+
+
 # ------------------------------------------------------------ GPU: pipeline
 
 @pytest.mark.gpu

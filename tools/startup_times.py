@@ -40,3 +40,20 @@ with tempfile.TemporaryDirectory() as d:
             ts.append(time.perf_counter() - t)
         print("nlkalman-flt wall s", env, [round(x, 3) for x in ts], r.stderr[-900:].replace("\n", " | "))
     t = time.perf_counter(); subprocess.run([exe, "-h"], capture_output=True); print("nlkalman-flt -h wall s", round(time.perf_counter() - t, 3))
+    # the same call with bin/nlk-server holding the device (host/cli_server.h): NLK_SERVER=<socket>
+    srv = os.path.join(ROOT, "bwd-nlkalman_amd", "bin", "nlk-server")
+    sock = d + "/nlk.sock"
+    t = time.perf_counter()
+    proc = subprocess.Popen([srv, sock], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    while not os.path.exists(sock) and proc.poll() is None:
+        time.sleep(0.01)
+    print("nlk-server ready after s", round(time.perf_counter() - t, 3))
+    for env in ({}, {"NLK_CLI_TRACE": "1"}):
+        ts = []
+        for _ in range(5):
+            t = time.perf_counter()
+            r = subprocess.run([exe, "-i", d + "/n1.pfm", "-s", "20", "--flt10", d + "/p.pfm", "--flt11", d + "/o2.pfm", "--f2_p", "0"],
+                               env=dict(os.environ, NLK_SERVER=sock, **env), capture_output=True, text=True)
+            ts.append(time.perf_counter() - t)
+        print("nlkalman-flt through nlk-server wall s", env, [round(x, 3) for x in ts], r.returncode, r.stderr[-300:].replace("\n", " | "))
+    subprocess.run([srv, "--stop", sock], capture_output=True); proc.wait(timeout=30)
