@@ -42,6 +42,15 @@ int cli_dev_alloc(struct nlk_ctx *c, void **p, size_t bytes) {
   return rc;
 }
 
+int cli_dev_free(struct nlk_ctx *c, void *p) {
+  for (int i = 0; i < g_ndev; ++i)
+    if (g_dev[i].p == p) {
+      g_dev[i] = g_dev[--g_ndev];
+      break;
+    }
+  return nlk_dev_free(c, p);
+}
+
 void cli_dev_release(void) {
   for (int i = 0; i < g_ndev; ++i) {
     (void)nlk_sync(g_dev[i].c);

@@ -38,6 +38,7 @@ void cli_exit(int status);
 /* nlk_dev_alloc, remembered; cli_dev_release frees what the current request allocated (a one-shot process never
  * needs to) */
 int cli_dev_alloc(struct nlk_ctx *c, void **p, size_t bytes);
+int cli_dev_free(struct nlk_ctx *c, void *p); /* nlk_dev_free of something cli_dev_alloc returned */
 void cli_dev_release(void);
 
 #endif

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "cli_server.h"
 #include "imgio.h"
 #include "nlk_hip.h"
 
@@ -24,7 +25,7 @@ static nlk_ctx *C;
   do {                                                                     \
     if ((call) != NLK_OK) {                                                \
       fprintf(stderr, "multiscale (hip): %s\n", nlk_last_error(C));        \
-      exit(EXIT_FAILURE);                                                  \
+      cli_exit(EXIT_FAILURE);                                                  \
     }                                                                      \
   } while (0)
 
@@ -50,10 +51,10 @@ struct dimg {
 static struct dimg load(const char *path) {
   struct dimg im;
   float *host = img_read(path, &im.w, &im.h, &im.ch);
-  if (!host) exit(EXIT_FAILURE);
+  if (!host) cli_exit(EXIT_FAILURE);
   void *d = NULL;
   const size_t bytes = (size_t)im.w * im.h * im.ch * sizeof(float);
-  CHK(nlk_dev_alloc(C, &d, bytes));
+  CHK(cli_dev_alloc(C, &d, bytes));
   CHK(nlk_h2d(C, d, host, bytes));
   free(host);
   im.d = (float *)d;
@@ -64,7 +65,7 @@ static void save(const char *path, const float *d, int w, int h, int ch) {
   const size_t bytes = (size_t)w * h * ch * sizeof(float);
   float *host = malloc(bytes);
   CHK(nlk_d2h(C, host, d, bytes));
-  if (img_write(path, host, w, h, ch)) { fprintf(stderr, "cannot write %s\n", path); exit(EXIT_FAILURE); }
+  if (img_write(path, host, w, h, ch)) { fprintf(stderr, "cannot write %s\n", path); cli_exit(EXIT_FAILURE); }
   free(host);
 }
 
@@ -81,7 +82,7 @@ static int decompose(int argc, char **argv) {
   CHK(nlk_dev_image_dct(C, im.d, im.w, im.h, im.ch, 0));
   int w = im.w, h = im.h;
   void *lvl = NULL;
-  CHK(nlk_dev_alloc(C, &lvl, (size_t)im.w * im.h * im.ch * sizeof(float)));
+  CHK(cli_dev_alloc(C, &lvl, (size_t)im.w * im.h * im.ch * sizeof(float)));
   for (int i = 0; i < levels; ++i) {  /* decompose.cpp:31-56 */
     if (w < 1 || h < 1) { fprintf(stderr, "decompose: level %d is empty\n", i); return EXIT_FAILURE; }
     CHK(nlk_dev_copy_block(C, (float *)lvl, w, im.d, im.w, im.ch, w, h));
@@ -124,7 +125,7 @@ static int recompose(int argc, char **argv) {
     CHK(nlk_dev_image_dct(C, im.d, im.w, im.h, im.ch, 0));
     low_frequencies(out, im, factor);
     CHK(nlk_sync(C));
-    nlk_dev_free(C, im.d);
+    cli_dev_free(C, im.d);
   }
   CHK(nlk_dev_image_dct(C, out.d, out.w, out.h, out.ch, 1));
   save(argv[4], out.d, out.w, out.h, out.ch);
@@ -149,7 +150,9 @@ static int merge_coarse(int argc, char **argv) {
   return EXIT_SUCCESS;
 }
 
-int main(int argc, char **argv) {
+/* the three tools as one function that looks at the name it is called by: main() below, or the resident server */
+int nlk_tool_multiscale(int argc, const char **argv_c) {
+  char **argv = (char **)argv_c; /* (the options are removed from the pointer array; the strings stay as they are) */
   const char *base = strrchr(argv[0], '/');
   base = base ? base + 1 : argv[0];
   if (!strcmp(base, "decompose")) return decompose(argc, argv);
@@ -158,3 +161,11 @@ int main(int argc, char **argv) {
   fprintf(stderr, "%s: call me as decompose, recompose or merge_coarse\n", base);
   return EXIT_FAILURE;
 }
+
+#ifndef NLK_TOOL_NO_MAIN
+int main(int argc, const char **argv) {
+  const char *base = strrchr(argv[0], '/');
+  const int remote = cli_remote(base ? base + 1 : argv[0], argc, argv); /* a resident server (NLK_SERVER), if there is one */
+  return remote >= 0 ? remote : nlk_tool_multiscale(argc, argv);
+}
+#endif

@@ -1,6 +1,7 @@
 /* nlk-server — the one-frame-per-process tools of the pipelines behind ONE resident process (cli_server.h).
  *
- *   nlk-server [--lazy] <socket>     serve nlkalman-flt, nlkalman-smo and tvl1flow on that unix socket
+ *   nlk-server [--lazy] <socket>     serve nlkalman-flt, nlkalman-smo, tvl1flow and the multiscale tools
+ *                                    (decompose, recompose, merge_coarse) on that unix socket
  *   nlk-server --stop <socket>       ask the server there to leave
  *
  * The tools find it through NLK_SERVER=<socket>; scripts/nlkalman-seq.sh (reference: :39-41, 80-81, 100-102) runs
@@ -18,6 +19,7 @@ struct nlk_ctx *nlkalman_hip_context(void); /* libnlkalman.so: the process-wide 
 int nlk_tool_flt(int argc, const char **argv);
 int nlk_tool_smo(int argc, const char **argv);
 int nlk_tool_tvl1(int argc, const char **argv);
+int nlk_tool_multiscale(int argc, const char **argv);
 
 int main(int argc, const char **argv) {
   int lazy = 0, stop = 0;
@@ -34,7 +36,9 @@ int main(int argc, const char **argv) {
     return rc < 0 ? (fprintf(stderr, "nlk-server: nobody listens at %s\n", path), 1) : rc;
   }
   static const struct cli_tool tools[] = {
-      {"nlkalman-flt", nlk_tool_flt}, {"nlkalman-smo", nlk_tool_smo}, {"tvl1flow", nlk_tool_tvl1}, {NULL, NULL}};
+      {"nlkalman-flt", nlk_tool_flt}, {"nlkalman-smo", nlk_tool_smo}, {"tvl1flow", nlk_tool_tvl1},
+      {"decompose", nlk_tool_multiscale}, {"recompose", nlk_tool_multiscale}, {"merge_coarse", nlk_tool_multiscale},
+      {NULL, NULL}};
   if (!lazy) (void)nlkalman_hip_context();
   return cli_serve(path, tools);
 }

@@ -199,7 +199,8 @@ def test_tools_behind_the_resident_server_speak_the_same_grammar(tools, tmp_path
     with server(tmp_path, "--lazy") as env:
         for tool, args in (("nlkalman-flt", ["-h"]), ("nlkalman-smo", ["--help"]), ("nlkalman-flt", ["--nope"]),
                            ("nlkalman-smo", ["-s"]), ("nlkalman-flt", ["--f1_p", "x"]), ("nlkalman-flt", ["--f1_p", "0"]),
-                           ("nlkalman-smo", ["--s1_p", "0", "--smo1", "x.tif"]), ("tvl1flow", []),
+                           ("nlkalman-smo", ["--s1_p", "0", "--smo1", "x.tif"]), ("tvl1flow", []), ("decompose", []),
+                           ("recompose", ["-h"]), ("merge_coarse", ["a"]),
                            ("nlkalman-flt", ["-i", "missing.tif", "--flt11", "o.tif", "-s", "10"])):
             local = run(tool, *args, cwd=tmp_path)
             remote = run(tool, *args, cwd=tmp_path, env=env)
@@ -232,7 +233,10 @@ def test_pipeline_through_the_resident_server(tools, tmp_path):
                 "--flt10", q("f1_0.pfm"), "--flt11", q("f1_1.pfm")),
                ("nlkalman-flt", "-i", str(tmp_path / "n1.pfm"), "-s", S, "--f1_p", "0", "-o", str(tmp_path / "b.flo"),
                 "--flt11", q("f1_1.pfm"), "--flt20", q("f2_0.pfm"), "--flt21", q("f2_1.pfm")),
-               ("nlkalman-smo", "--flt1", q("f2_0.pfm"), "--smo0", q("f2_1.pfm"), "--smo1", q("s1_0.pfm"), "-s", S)]
+               ("nlkalman-smo", "--flt1", q("f2_0.pfm"), "--smo0", q("f2_1.pfm"), "--smo1", q("s1_0.pfm"), "-s", S),
+               # (the multiscale wrapper's tools, scripts/msnlkalman-seq.sh:56-60, 106-110)
+               ("decompose", str(tmp_path / "n0.pfm"), q("ms"), "2", ".pfm"),
+               ("recompose", q("ms"), "2", ".pfm", q("rec.pfm"), "-c", "0.7")]
         t0 = time.perf_counter()
         for a in seq:
             r = run(*a, env=env)
@@ -245,7 +249,7 @@ def test_pipeline_through_the_resident_server(tools, tmp_path):
         served = min(steps("s_", env) for _ in range(3))
         for _ in range(40):                   # 200 more requests: what a request allocates is released
             steps("s_", env)
-    for f in ("tv.flo", "f1_0.pfm", "f2_0.pfm", "f1_1.pfm", "f2_1.pfm", "s1_0.pfm"):
+    for f in ("tv.flo", "f1_0.pfm", "f2_0.pfm", "f1_1.pfm", "f2_1.pfm", "s1_0.pfm", "ms0.pfm", "ms1.pfm", "rec.pfm"):
         a, b = (open(str(tmp_path / (t + f)), "rb").read() for t in ("a_", "s_"))
         assert a == b, f
     assert served < 0.1 and served < alone / 2, (served, alone)
