@@ -303,6 +303,41 @@ def test_free_running_chain_1080p_psnr(ctx, built, O, synth):
         assert synth.psnr(g, clean) > synth.psnr(n1 if clean is c1 else n0, clean) + 8
 
 
+def test_8k_frame_replay_inside_the_launch_equals_the_separate_kernels(ctx, built, synth, monkeypatch):
+    """7680 x 4320 RGB: a patch grid of 1919 x 1079 targets - more grid rows than a workgroup has threads, nearly
+    as wide as the row replay's 2048-target limit, 2 M targets. FLT1 spatial (reach 2) and temporal (reach 1): the
+    mask replay inside the group kernel's launch (default) and as separate kernels (NLK_NO_CHASE=1) must give the
+    same decisions for every target and the same frame up to the order of the float sums; k-NN lists identical."""
+    w, h, ch, sigma = 7680, 4320, 3, 20.0
+    n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, 8)
+    o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+    del n0, n1
+    p = built.default_params(sigma, built.FLT1)
+    out = {}
+    for tag, env in (("in", None), ("sep", "1")):
+        if env:
+            monkeypatch.setenv("NLK_NO_CHASE", env)
+        else:
+            monkeypatch.delenv("NLK_NO_CHASE", raising=False)
+        f0, r0 = _dev_frame(ctx, False, o0, None, None, sigma, p)
+        f1, r1 = _dev_frame(ctx, False, o1, f0, None, sigma, p)
+        out[tag] = (f0, r0, f1, r1)
+    monkeypatch.delenv("NLK_NO_CHASE", raising=False)
+    for k in (1, 3):
+        a, b = out["in"][k], out["sep"][k]
+        assert a["active"].size == 1919 * 1079
+        for f in ("active", "nsel", "np0", "nagg", "topk", "gcoords"):
+            assert np.array_equal(a[f], b[f]), (k, f)
+        assert 0.1 < 1 - a["active"].mean() < 0.6
+    _same(out["in"][0], out["sep"][0], o0, "8K first frame, replay inside the launch vs separate kernels", most=256)
+    # (the temporal frames were fed their own first frames: compare them through the same previous frame)
+    monkeypatch.setenv("NLK_NO_CHASE", "1")
+    f1_sep, _ = _dev_frame(ctx, False, o1, out["in"][0], None, sigma, p)
+    monkeypatch.delenv("NLK_NO_CHASE", raising=False)
+    f1_in, _ = _dev_frame(ctx, False, o1, out["in"][0], None, sigma, p)
+    _same(f1_in, f1_sep, o1, "8K temporal frame, replay inside the launch vs separate kernels", most=256)
+
+
 @pytest.mark.parametrize("seed", [101, 102, 103])
 def test_random_parameters_full_size_soak(ctx, built, O, seed):
     """tools/soak_fullsize.py as a test: two random configurations per seed at ~1080p -
