@@ -73,6 +73,60 @@ static float *read_pfm(const char *path, const unsigned char *b, size_t n, int *
   return d; /* top row first, no flip (reference: lib/iio/iio.c:2049-2071) */
 }
 
+/* -------------------------------------------------------------------- PNM */
+/* P2 / P3 (ASCII) and P5 / P6 (binary; two big-endian bytes per sample when maxval > 255) grey and colour maps,
+ * read the way the reference's library reads them (lib/iio/iio.c:1759-1805: comments between the header fields,
+ * one white-space byte after maxval, maxval itself not applied - samples stay what the file says; ASCII samples
+ * may be any number strtof takes). */
+static size_t pnm_skip(const unsigned char *b, size_t n, size_t i) { /* white space and # comments */
+  while (i < n) {
+    if (b[i] == '#') { while (i < n && b[i] != '\n') ++i; }
+    else if (b[i] == ' ' || (b[i] >= '\t' && b[i] <= '\r')) ++i;
+    else break;
+  }
+  return i;
+}
+static int pnm_int(const unsigned char *b, size_t n, size_t *i, long *v) {
+  *i = pnm_skip(b, n, *i);
+  if (*i >= n || b[*i] < '0' || b[*i] > '9') return -1;
+  long x = 0;
+  while (*i < n && b[*i] >= '0' && b[*i] <= '9' && x < (1L << 40)) x = x * 10 + (b[(*i)++] - '0');
+  *v = x;
+  return 0;
+}
+static float *read_pnm(const char *path, const unsigned char *b, size_t n, int *w, int *h, int *ch) {
+  const int kind = b[1] - '0', c = (kind == 3 || kind == 6) ? 3 : 1, ascii = kind == 2 || kind == 3;
+  size_t i = 2;
+  long ww, hh, maxval;
+  if (pnm_int(b, n, &i, &ww) || pnm_int(b, n, &i, &hh) || pnm_int(b, n, &i, &maxval)) return fail(path, "bad PNM header");
+  if (i >= n || !(b[i] == ' ' || (b[i] >= '\t' && b[i] <= '\r'))) return fail(path, "bad PNM header");
+  ++i; /* exactly one white-space byte, then the samples */
+  if (ww <= 0 || hh <= 0 || ww > INT32_MAX || hh > INT32_MAX || !sane_size((uint64_t)ww, (uint64_t)hh, (uint64_t)c))
+    return fail(path, "bad PNM size");
+  if (maxval <= 0 || maxval >= 65536) return fail(path, "PNM maxval out of range");
+  const size_t cnt = (size_t)ww * hh * c;
+  const int wide = maxval > 255;
+  if (!ascii && i + cnt * (wide ? 2 : 1) > n) return fail(path, "truncated PNM");
+  if (ascii && cnt > n) return fail(path, "truncated PNM"); /* (a sample takes at least one byte) */
+  float *d = malloc(cnt * 4);
+  if (!d) return fail(path, "out of memory");
+  if (!ascii) {
+    const unsigned char *q = b + i;
+    for (size_t k = 0; k < cnt; ++k) d[k] = wide ? (float)(q[2 * k] * 256 + q[2 * k + 1]) : (float)q[k];
+  } else {
+    /* (the buffer is NUL-terminated by slurp(): strtof stops there at the latest) */
+    const char *q = (const char *)b + i;
+    for (size_t k = 0; k < cnt; ++k) {
+      char *end;
+      d[k] = strtof(q, &end);
+      if (end == q) { free(d); return fail(path, "truncated PNM"); }
+      q = end;
+    }
+  }
+  *w = (int)ww; *h = (int)hh; *ch = c;
+  return d;
+}
+
 /* -------------------------------------------------------------------- FLO */
 static float *read_flo(const char *path, const unsigned char *b, size_t n, int *w, int *h, int *ch) {
   int32_t ww, hh;
@@ -405,7 +459,8 @@ float *img_read(const char *path, int *w, int *h, int *ch) {
   else if (n >= 8 && ((b[0] == 'I' && b[1] == 'I') || (b[0] == 'M' && b[1] == 'M'))) d = read_tiff(path, b, n, w, h, ch);
   else if (n >= 8 && !memcmp(b, "\x89PNG\r\n\x1a\n", 8)) d = read_png(path, b, n, w, h, ch);
   else if (n >= 8 && b[0] == 'P' && (b[1] == 'f' || b[1] == 'F')) d = read_pfm(path, b, n, w, h, ch);
-  else fail(path, "unknown image format (supported: TIFF, PNG, PFM, FLO)");
+  else if (n >= 8 && b[0] == 'P' && (b[1] == '2' || b[1] == '3' || b[1] == '5' || b[1] == '6')) d = read_pnm(path, b, n, w, h, ch);
+  else fail(path, "unknown image format (supported: TIFF, PNG, PFM, PGM / PPM, FLO)");
   free(b);
   return d;
 }

@@ -156,6 +156,26 @@ def test_image_io_against_pil(tools, tmp_path):
     assert np.array_equal(rpfm(tmp_path / "r.pfm"), rgb8.astype(np.float32))
     run("nlk-imgconv", tmp_path / "r.pfm", tmp_path / "w.png")
     assert np.array_equal(np.asarray(Image.open(tmp_path / "w.png")), rgb8)
+    # PGM / PPM: binary with 8 and 16 bits per sample (another encoder's files), ASCII with comments in the header
+    Image.fromarray(rgb8).save(tmp_path / "r.ppm")
+    run("nlk-imgconv", tmp_path / "r.ppm", tmp_path / "r2.pfm")
+    assert np.array_equal(rpfm(tmp_path / "r2.pfm"), rgb8.astype(np.float32))
+    Image.fromarray(m).save(tmp_path / "m.pgm")
+    run("nlk-imgconv", tmp_path / "m.pgm", tmp_path / "m2.pfm")
+    assert np.array_equal(rpfm(tmp_path / "m2.pfm")[..., 0], m.astype(np.float32))
+    g16 = rng.integers(0, 65536, (11, 14)).astype(np.uint16)
+    with open(tmp_path / "g16.pgm", "wb") as f:
+        f.write(b"P5\n# sixteen bits, most significant byte first\n14 11\n65535\n" + g16.astype(">u2").tobytes())
+    run("nlk-imgconv", tmp_path / "g16.pgm", tmp_path / "g16.pfm")
+    assert np.array_equal(rpfm(tmp_path / "g16.pfm")[..., 0], g16.astype(np.float32))
+    with open(tmp_path / "t.ppm", "w") as f:
+        f.write("P3 # ascii\n# width height\n2 2\n255\n1 2 3  4 5 6\n7 8 9\n10.5 -1 300\n")
+    run("nlk-imgconv", tmp_path / "t.ppm", tmp_path / "t.pfm")
+    assert np.array_equal(rpfm(tmp_path / "t.pfm").ravel(), np.float32([1, 2, 3, 4, 5, 6, 7, 8, 9, 10.5, -1, 300]))
+    for bad in (b"P5\n4 4\n255\nxx", b"P6\n2 2\n70000\n" + bytes(12), b"P2\n2 2\n255\n1 2 3\n", b"P5\n-3 2\n255\n"):
+        with open(tmp_path / "bad.pgm", "wb") as f:
+            f.write(bad)
+        assert run("nlk-imgconv", tmp_path / "bad.pgm", tmp_path / "x.pfm").returncode == 1
     # flow files
     fl = rng.normal(0, 2, (9, 13, 2)).astype(np.float32)
     wflo(tmp_path / "f.flo", fl)

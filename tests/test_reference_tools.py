@@ -101,6 +101,29 @@ def test_frames_we_write_are_read_identically_by_the_reference_library(iio, conv
     assert back.shape == a.shape and np.array_equal(back, a, equal_nan=True)
 
 
+def test_pgm_and_ppm_files_read_like_the_reference_library_reads_them(iio, conv, tmp_path):
+    """lib/iio/iio.c:1759-1805 (P2 / P3 ASCII, P5 / P6 binary with one or two bytes per sample, comments in the
+    header, maxval not applied): host/imgio.c must return the same floats."""
+    rng = np.random.default_rng(12)
+    files = {}
+    rgb8 = rng.integers(0, 256, (13, 17, 3), dtype=np.uint8)
+    files["a.ppm"] = b"P6\n17 13\n255\n" + rgb8.tobytes()
+    g8 = rng.integers(0, 200, (9, 21), dtype=np.uint8)
+    files["b.pgm"] = b"P5 # a comment\n21\n# another\n9 199\n" + g8.tobytes()
+    g16 = rng.integers(0, 65536, (7, 5)).astype(">u2")
+    files["c.pgm"] = b"P5\n5 7\n65535\n" + g16.tobytes()
+    c16 = rng.integers(0, 1024, (4, 6, 3)).astype(">u2")
+    files["d.ppm"] = b"P6\n6 4\n1023\n" + c16.tobytes()
+    files["e.pgm"] = ("P2\n# ascii\n4 3\n15\n" + " ".join(str(v) for v in rng.integers(0, 16, 12)) + "\n").encode()
+    files["f.ppm"] = ("P3\n2 2\n255\n" + "\n".join("%g" % v for v in rng.uniform(-5, 300, 12)) + "\n").encode()
+    for name, data in files.items():
+        with open(tmp_path / name, "wb") as f:
+            f.write(data)
+        conv(tmp_path / name, tmp_path / (name + ".pfm"))
+        ours, theirs = iio.read(tmp_path / (name + ".pfm")), iio.read(tmp_path / name)
+        assert ours.shape == theirs.shape and np.array_equal(ours, theirs), name
+
+
 def test_flow_files_both_directions(iio, conv, tmp_path):
     fl = np.random.default_rng(3).normal(0, 3, (13, 22, 2)).astype(np.float32)
     iio.write(tmp_path / "ref.flo", fl)
