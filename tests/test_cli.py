@@ -176,6 +176,24 @@ def test_image_io_against_pil(tools, tmp_path):
         with open(tmp_path / "bad.pgm", "wb") as f:
             f.write(bad)
         assert run("nlk-imgconv", tmp_path / "bad.pgm", tmp_path / "x.pfm").returncode == 1
+    # JPEG (baseline): another decoder's numbers for grey and full-resolution colour; what is not read fails loudly
+    yy, xx = np.mgrid[0:40, 0:52]
+    pic = np.clip(np.stack([128 + 90 * np.sin(xx / 6.), 100 + yy * 3., 128 + 80 * np.cos(yy / 4. + xx / 9.)], -1)
+                  + rng.normal(0, 8, (40, 52, 3)), 0, 255).astype(np.uint8)
+    for name, a, kw in (("j1", pic[..., 1], dict(quality=90)), ("j3", pic, dict(quality=85, subsampling=0))):
+        Image.fromarray(a).save(tmp_path / (name + ".jpg"), **kw)
+        assert run("nlk-imgconv", tmp_path / (name + ".jpg"), tmp_path / (name + ".pfm")).returncode == 0
+        got = rpfm(tmp_path / (name + ".pfm"))
+        want = np.asarray(Image.open(tmp_path / (name + ".jpg")), np.float32).reshape(got.shape)
+        assert np.array_equal(got, want), name
+    Image.fromarray(pic).save(tmp_path / "prog.jpg", progressive=True)
+    r = run("nlk-imgconv", tmp_path / "prog.jpg", tmp_path / "x.pfm")
+    assert r.returncode == 1 and "baseline only" in r.stderr
+    data = open(tmp_path / "j3.jpg", "rb").read()
+    for cut in (20, 200, len(data) // 2):
+        with open(tmp_path / "cut.jpg", "wb") as f:
+            f.write(data[:cut])
+        assert run("nlk-imgconv", tmp_path / "cut.jpg", tmp_path / "x.pfm").returncode in (0, 1)   # (no crash)
     # flow files
     fl = rng.normal(0, 2, (9, 13, 2)).astype(np.float32)
     wflo(tmp_path / "f.flo", fl)
