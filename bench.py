@@ -66,12 +66,14 @@ def cpu_baseline(O, o1, prev, sigma, p):
 
 
 def kernel_sources_sha():
-    """sha256 over the HIP sources of the product (csrc/*.h, *.hip): what a PMC table was measured on."""
+    """sha256 over the HIP sources of the product (csrc/*.h, *.hip) and the Makefile that holds their compiler flags:
+    what a PMC table was measured on."""
     import glob
     import hashlib
     hsh = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "bwd-nlkalman_amd", "csrc", "*"))):
-        if f.endswith((".h", ".hip")):
+    for f in sorted(glob.glob(os.path.join(ROOT, "bwd-nlkalman_amd", "csrc", "*"))) + \
+            [os.path.join(ROOT, "bwd-nlkalman_amd", "Makefile")]:
+        if f.endswith((".h", ".hip", "Makefile")):
             hsh.update(os.path.basename(f).encode())
             hsh.update(open(f, "rb").read())
     return hsh.hexdigest()
