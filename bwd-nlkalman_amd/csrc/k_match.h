@@ -367,7 +367,7 @@ __device__ __forceinline__ void nlk_match_epilogue(const NlkGeom& g, size_t t, i
 #define NLK_BM7_WAVES 4
 #endif
 template <int PSZ, int CH, int MAXM, int BX = 4>  // BX x 2 targets per block (2: twice the wavefronts on the same tile)
-__global__ void __launch_bounds__(512, MAXM == 7 ? (BX == 2 ? NLK_BM7_WAVES : 3) : ((BX == 2 && PSZ == 8) ? 8 : 2))  // (7 rounds in blocks: 168 registers, the LDS tile allows 3 wavefronts per SIMD)
+__global__ void __launch_bounds__(512, MAXM == 7 ? (BX == 2 ? NLK_BM7_WAVES : 3) : ((MAXM == 2 && PSZ == 8) ? 8 : 2))  // (7 rounds in blocks: 168 registers, the LDS tile allows 3 wavefronts per SIMD)
 k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGeom g,
           NlkTile tl, uint32_t* __restrict__ topk, NlkTarget* __restrict__ tinfo,
           uint32_t* __restrict__ gcoords, uint64_t* __restrict__ marks,
