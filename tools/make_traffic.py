@@ -24,11 +24,18 @@ def parse(path):
     return out
 
 
+def git_head():
+    try:   # (no .git on the GPU box: the table made there names the sources by their hash only)
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
+    except Exception:
+        return os.environ.get("NLK_GIT_HEAD", "unknown (made on the GPU box: see kernel_sources_sha256)")
+
+
 def main(tag):
     from bench import kernel_sources_sha
     res = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_round.sh {tag}), "
                      "bench.py --steps 3 --warmup 1 --no-cpu; mean per launch",
-           "git_head": subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True).strip(),
+           "git_head": git_head(),
            "kernel_sources_sha256": kernel_sources_sha(),
            "note": "raw FETCH_SIZE + WRITE_SIZE (KiB) x 1024. FETCH_SIZE counts the L2's fabric-side read requests "
                    "(Infinity-Cache hits included) and reports half the bytes of wide (16 B per lane) coalesced streaming "
