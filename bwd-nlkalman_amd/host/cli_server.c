@@ -192,19 +192,25 @@ int cli_serve(const char *path, const struct cli_tool *tools) {
       continue;
     }
     buf[len] = 0;
-    /* payload -> tool, directory, argv */
+    /* payload -> tool, directory, argv (every string must end inside the payload: buf[len] is a NUL of ours) */
     const char *end = buf + len, *q = buf;
-    const char *magic = q; q += strlen(q) + 1;
-    const char *tool = q < end ? q : ""; q += strlen(q) + 1;
-    const char *cwd = q < end ? q : "."; q += strlen(q) + 1;
-    const int argc = q < end ? atoi(q) : 0; q += strlen(q) + 1;
-    const char **argv = (const char **)calloc((size_t)(argc > 0 ? argc : 0) + 1, sizeof(char *));
-    int ok = argv && !strcmp(magic, "NLK1") && argc >= 0 && argc < 4096;
+#define NEXT_STRING(var)                         \
+  const char *var = NULL;                        \
+  if (q && q < end) { var = q; q += strlen(q) + 1; } else q = NULL;
+    NEXT_STRING(magic)
+    NEXT_STRING(tool)
+    NEXT_STRING(cwd)
+    NEXT_STRING(argc_s)
+    const int argc = argc_s ? atoi(argc_s) : -1;
+    int ok = magic && tool && cwd && argc_s && !strcmp(magic, "NLK1") && argc >= 0 && argc < 4096;
+    const char **argv = ok ? (const char **)calloc((size_t)argc + 1, sizeof(char *)) : NULL;
+    ok = ok && argv;
     for (int i = 0; ok && i < argc; ++i) {
-      if (q >= end) { ok = 0; break; }
-      argv[i] = q;
-      q += strlen(q) + 1;
+      NEXT_STRING(a)
+      if (!a) ok = 0;
+      else argv[i] = a;
     }
+#undef NEXT_STRING
     int32_t status = 125;
     int stop = 0;
     if (ok && !strcmp(tool, "shutdown")) {

@@ -244,6 +244,19 @@ def test_tools_behind_the_resident_server_speak_the_same_grammar(tools, tmp_path
             remote = run(tool, *args, cwd=tmp_path, env=env)
             assert (remote.returncode, remote.stdout, remote.stderr) == (local.returncode, local.stdout, local.stderr), \
                 (tool, args)
+        # clients that do not speak the protocol (wrong magic, absurd length, a connection that says nothing, no
+        # descriptors attached) are dropped; the server goes on serving
+        import socket
+        import struct as st
+        for junk in (b"", b"\x10\x00\x00\x00" + b"XXXX\0tool\0.\0" + b"0\0", st.pack("<I", 0x7fffffff) + b"abc",
+                     st.pack("<I", 12) + b"NLK1\0nlkalman-flt\0"):
+            c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            c.connect(env["NLK_SERVER"])
+            if junk:
+                c.sendall(junk)
+            c.close()
+        r = run("nlkalman-flt", "-h", env=env)
+        assert r.returncode == 0 and r.stdout.startswith("Usage: nlkalman-flt")
         r = run("nlkalman-flt", "-h", env=dict(env, NLK_SERVER=str(tmp_path / "nobody.sock")))
         assert r.returncode == 0 and r.stdout.startswith("Usage: nlkalman-flt")     # no listener: by itself
     r = subprocess.run([os.path.join(BIN, "nlk-server"), "--stop", str(tmp_path / "nlk.sock")], capture_output=True,
