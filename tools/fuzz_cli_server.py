@@ -34,7 +34,8 @@ with tempfile.TemporaryDirectory() as d:
                            "-I" + host, "-I" + os.path.join(ROOT, "include"), "-o", d + "/srv", d + "/stub.c",
                            os.path.join(host, "cli_server.c")])
     path = d + "/s.sock"
-    srv = subprocess.Popen([d + "/srv", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+    log = open(d + "/srv.err", "w")   # (a file: the loop reports every dropped client, a pipe would fill up)
+    srv = subprocess.Popen([d + "/srv", path], stdout=log, stderr=log,
                            env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="halt_on_error=1"))
     while not os.path.exists(path):
         time.sleep(0.02)
@@ -87,8 +88,10 @@ with tempfile.TemporaryDirectory() as d:
         c.close()
         if it % 250 == 0:
             assert good([b"echo", b"still", b"here"]) == (3, b"[echo][still][here]\n"), it
-    assert srv.poll() is None, srv.stderr.read().decode()[-2000:]
+    assert srv.poll() is None, open(d + "/srv.err").read()[-2000:]
     srv.kill()
-    err = srv.stderr.read().decode()
+    srv.wait()
+    log.close()
+    err = open(d + "/srv.err").read()
     assert "ERROR: AddressSanitizer" not in err and "runtime error" not in err, err[-2000:]
     print("3000 hostile connections: the loop kept answering; no sanitizer report")
