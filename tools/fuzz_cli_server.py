@@ -1,5 +1,5 @@
 """Hostile clients against the request loop of bin/nlk-server (host/cli_server.c), CPU only: the loop is built
-with AddressSanitizer + UBSan around a stand-in tool table (no HIP), then 3000 connections that do not speak
+with AddressSanitizer + UBSan around a stand-in tool table (no HIP), then 2000 connections that do not speak
 the protocol - nothing, random bytes, absurd lengths, mutated payloads, impossible argument counts, directories
 that do not exist - interleaved with well-formed requests that must keep being answered.
    python tools/fuzz_cli_server.py"""
@@ -57,7 +57,7 @@ with tempfile.TemporaryDirectory() as d:
     assert good([b"echo", b"a", b"bb"]) == (3, b"[echo][a][bb]\n")
     assert good([b"echo", b"die"])[0] == 7          # a tool that leaves through cli_exit
     random.seed(4)
-    for it in range(3000):
+    for it in range(2000):
         kind = random.randrange(6)
         c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
         c.connect(path)
@@ -78,7 +78,7 @@ with tempfile.TemporaryDirectory() as d:
             elif kind == 5:
                 p = b"NLK1\0echo\0/nonexistent_dir\0" + b"1\0x\0"
                 c.sendall(struct.pack("<I", len(p)) + p)
-            c.settimeout(0.5)
+            c.settimeout(0.02)
             try:
                 c.recv(4)
             except Exception:
@@ -94,4 +94,4 @@ with tempfile.TemporaryDirectory() as d:
     log.close()
     err = open(d + "/srv.err").read()
     assert "ERROR: AddressSanitizer" not in err and "runtime error" not in err, err[-2000:]
-    print("3000 hostile connections: the loop kept answering; no sanitizer report")
+    print("2000 hostile connections: the loop kept answering; no sanitizer report")
