@@ -88,10 +88,10 @@ with tempfile.TemporaryDirectory() as d:
         c.close()
         if it % 250 == 0:
             assert good([b"echo", b"still", b"here"]) == (3, b"[echo][still][here]\n"), it
-    assert srv.poll() is None, open(d + "/srv.err").read()[-2000:]
+    assert srv.poll() is None, open(d + "/srv.err", errors="replace").read()[-2000:]
     srv.kill()
     srv.wait()
     log.close()
-    err = open(d + "/srv.err").read()
+    err = open(d + "/srv.err", errors="replace").read()
     assert "ERROR: AddressSanitizer" not in err and "runtime error" not in err, err[-2000:]
     print("2000 hostile connections: the loop kept answering; no sanitizer report")
