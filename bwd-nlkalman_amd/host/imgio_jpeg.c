@@ -11,11 +11,10 @@
  *  - Y Cb Cr -> R G B with the 16-bit fixed-point tables of its colour converter (1.402, 0.344136286, 0.714136286,
  *    1.772);
  *  - a subsampled chroma component is brought to full resolution the way libjpeg 7 and later do it: by the inverse
- *    transform itself, producing a 16-point (8 * factor) output from the 8 coefficients of a block, not by
- *    interpolating samples. Here that larger transform is evaluated in double precision: equal to libjpeg's
- *    fixed-point version up to one grey level now and then.
- * tests/test_reference_tools.py compares against the reference's library (grey and 4:4:4 bit for bit). */
-#include <math.h>
+ *    transform itself, which produces 16 samples from the 8 coefficients of a block (a 16-point transform in the same
+ *    13-bit fixed point), not by interpolating samples; factors the transform cannot take (3, and the second half of
+ *    a 4) are plain replication.
+ * tests/test_reference_tools.py compares against the reference's library: bit for bit (grey, 4:4:4, 4:2:2, 4:2:0). */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -149,23 +148,91 @@ static void idct8x8(const int32_t *coef, unsigned char *dst, size_t stride) {
   }
 }
 
-/* ---- a block brought to (8 fx) x (8 fy) samples by the transform itself (double precision) */
-static void idct_scaled(const int32_t *coef, int fx, int fy, unsigned char *dst, size_t stride) {
-  const int nx = 8 * fx, ny = 8 * fy;
-  double tmp[8][32];
-  for (int v = 0; v < 8; ++v)
-    for (int x = 0; x < nx; ++x) {
-      double s = 0;
-      for (int u = 0; u < 8; ++u)
-        s += (u ? 1.0 : M_SQRT1_2) * coef[8 * v + u] * cos((2 * x + 1) * u * M_PI / (2.0 * nx));
-      tmp[v][x] = s;
-    }
-  for (int y = 0; y < ny; ++y)
-    for (int x = 0; x < nx; ++x) {
-      double s = 0;
-      for (int v = 0; v < 8; ++v) s += (v ? 1.0 : M_SQRT1_2) * tmp[v][x] * cos((2 * y + 1) * v * M_PI / (2.0 * ny));
-      dst[y * stride + x] = clamp8((int)floor(s / 4.0 + 128.5));
-    }
+/* ---- 16 output samples from the 8 coefficients of a block: the larger inverse transform libjpeg (7 and later)
+ * brings subsampled chroma to full resolution with, in the same fixed point as the 8-point one. cK = sqrt(2)
+ * cos(K pi / 32); the constants are those combinations rounded to 13 bits. */
+#define FX(x) ((int32_t)((x) * (1 << CB) + 0.5))
+static void idct1d_16(const int32_t in[8], int32_t out[16], int32_t round, int shift) {
+  int32_t t0 = (int32_t)((uint32_t)in[0] << CB) + round;
+  int32_t z1 = in[4];
+  int32_t t1 = z1 * FX(1.306562965), t2 = z1 * F_0_541196100;
+  const int32_t t10 = t0 + t1, t11 = t0 - t1, t12 = t0 + t2, t13 = t0 - t2;
+  z1 = in[2];
+  int32_t z2 = in[6], z3 = z1 - z2;
+  int32_t z4 = z3 * FX(0.275899379);
+  z3 = z3 * FX(1.387039845);
+  t0 = z3 + z2 * F_2_562915447;
+  t1 = z4 + z1 * F_0_899976223;
+  t2 = z3 - z1 * FX(0.601344887);
+  int32_t t3 = z4 - z2 * FX(0.509795579);
+  const int32_t t20 = t10 + t0, t27 = t10 - t0, t21 = t12 + t1, t26 = t12 - t1;
+  const int32_t t22 = t13 + t2, t25 = t13 - t2, t23 = t11 + t3, t24 = t11 - t3;
+  z1 = in[1]; z2 = in[3]; z3 = in[5]; z4 = in[7];
+  int32_t o11 = z1 + z3;
+  int32_t o1 = (z1 + z2) * FX(1.353318001), o2 = o11 * FX(1.247225013), o3 = (z1 + z4) * FX(1.093201867);
+  int32_t o10 = (z1 - z4) * FX(0.897167586);
+  o11 = o11 * FX(0.666655658);
+  int32_t o12 = (z1 - z2) * FX(0.410524528);
+  const int32_t o0 = o1 + o2 + o3 - z1 * FX(2.286341144);
+  const int32_t o13 = o10 + o11 + o12 - z1 * FX(1.835730603);
+  z1 = (z2 + z3) * FX(0.138617169);
+  o1 += z1 + z2 * FX(0.071888074);
+  o2 += z1 - z3 * FX(1.125726048);
+  z1 = (z3 - z2) * FX(1.407403738);
+  o11 += z1 - z3 * FX(0.766367282);
+  o12 += z1 + z2 * FX(1.971951411);
+  z2 += z4;
+  z1 = z2 * -FX(0.666655658);
+  o1 += z1;
+  o3 += z1 + z4 * FX(1.065388962);
+  z2 = z2 * -FX(1.247225013);
+  o10 += z2 + z4 * FX(3.141271809);
+  o12 += z2;
+  z2 = (z3 + z4) * -FX(1.353318001);
+  o2 += z2;
+  o3 += z2;
+  z2 = (z4 - z3) * FX(0.410524528);
+  o10 += z2;
+  o11 += z2;
+  out[0] = (t20 + o0) >> shift;   out[15] = (t20 - o0) >> shift;
+  out[1] = (t21 + o1) >> shift;   out[14] = (t21 - o1) >> shift;
+  out[2] = (t22 + o2) >> shift;   out[13] = (t22 - o2) >> shift;
+  out[3] = (t23 + o3) >> shift;   out[12] = (t23 - o3) >> shift;
+  out[4] = (t24 + o10) >> shift;  out[11] = (t24 - o10) >> shift;
+  out[5] = (t25 + o11) >> shift;  out[10] = (t25 - o11) >> shift;
+  out[6] = (t26 + o12) >> shift;  out[9] = (t26 - o12) >> shift;
+  out[7] = (t27 + o13) >> shift;  out[8] = (t27 - o13) >> shift;
+}
+
+/* a block at twice the resolution along x, y or both, in integers */
+static void idct_double(const int32_t *coef, int fx, int fy, unsigned char *dst, size_t stride) {
+  const int ny = 8 * fy, nx = 8 * fx;
+  int32_t ws[16 * 8], col[8], res[16];
+  for (int x = 0; x < 8; ++x) { /* columns: 8 or 16 rows of work space */
+    for (int y = 0; y < 8; ++y) col[y] = coef[8 * y + x];
+    if (fy == 2) idct1d_16(col, res, 1 << (CB - P1 - 1), CB - P1);
+    else idct1d(col, res, 1 << (CB - P1 - 1), CB - P1);
+    for (int y = 0; y < ny; ++y) ws[8 * y + x] = res[y];
+  }
+  for (int y = 0; y < ny; ++y) {
+    if (fx == 2) idct1d_16(ws + 8 * y, res, (128 << (CB + P1 + 3)) + (1 << (CB + P1 + 2)), CB + P1 + 3);
+    else idct1d(ws + 8 * y, res, (128 << (CB + P1 + 3)) + (1 << (CB + P1 + 2)), CB + P1 + 3);
+    for (int x = 0; x < nx; ++x) dst[y * stride + x] = clamp8(res[x]);
+  }
+}
+
+/* ---- a block of a component subsampled fx x fy times, at full resolution: the transform doubles what it can (one
+ * doubling per direction, where the factor is even), plain replication does the rest - libjpeg's order of things */
+static void block_to_full(const int32_t *coef, int fx, int fy, unsigned char *dst, size_t stride) {
+  const int dx = fx % 2 == 0 ? 2 : 1, dy = fy % 2 == 0 ? 2 : 1, rx = fx / dx, ry = fy / dy;
+  if (rx == 1 && ry == 1) {
+    idct_double(coef, dx, dy, dst, stride);
+    return;
+  }
+  unsigned char tmp[16 * 16];
+  idct_double(coef, dx, dy, tmp, 16);
+  for (int y = 0; y < 8 * fy; ++y)
+    for (int x = 0; x < 8 * fx; ++x) dst[y * stride + x] = tmp[(y / ry) * 16 + x / rx];
 }
 
 struct comp {
@@ -320,7 +387,7 @@ float *nlk_read_jpeg(const char *path, const unsigned char *b, size_t n, int *w,
               const int32_t *blk = C[c].coef + ((size_t)by * C[c].bw + bx) * 64;
               unsigned char *dst = C[c].pix + (size_t)by * 8 * fy * C[c].stride + (size_t)bx * 8 * fx;
               if (fx == 1 && fy == 1) idct8x8(blk, dst, C[c].stride);
-              else idct_scaled(blk, fx, fy, dst, C[c].stride);
+              else block_to_full(blk, fx, fy, dst, C[c].stride);
             }
         }
         out = malloc((size_t)W * H * nc * sizeof(float));
