@@ -66,16 +66,18 @@ def cpu_baseline(O, o1, prev, sigma, p):
 
 
 def kernel_sources_sha():
-    """sha256 over the HIP sources of the product (csrc/*.h, *.hip) and the Makefile that holds their compiler flags:
-    what a PMC table was measured on."""
+    """sha256 over the HIP sources of the product (csrc/*.h, *.hip) and the lines of the Makefile that hold their
+    compiler flags (HIPFLAGS, per-unit scheduling): what a PMC table was measured on."""
     import glob
     import hashlib
     hsh = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "bwd-nlkalman_amd", "csrc", "*"))) + \
-            [os.path.join(ROOT, "bwd-nlkalman_amd", "Makefile")]:
-        if f.endswith((".h", ".hip", "Makefile")):
+    for f in sorted(glob.glob(os.path.join(ROOT, "bwd-nlkalman_amd", "csrc", "*"))):
+        if f.endswith((".h", ".hip")):
             hsh.update(os.path.basename(f).encode())
             hsh.update(open(f, "rb").read())
+    for line in open(os.path.join(ROOT, "bwd-nlkalman_amd", "Makefile"), "rb"):
+        if any(k in line for k in (b"HIPFLAGS", b"SCHED", b"HIPCC")) and not line.lstrip().startswith(b"#"):
+            hsh.update(line)
     return hsh.hexdigest()
 
 
