@@ -463,7 +463,7 @@ float *img_read(const char *path, int *w, int *h, int *ch) {
   else if (n >= 8 && b[0] == 'P' && (b[1] == 'f' || b[1] == 'F')) d = read_pfm(path, b, n, w, h, ch);
   else if (n >= 8 && b[0] == 'P' && (b[1] == '2' || b[1] == '3' || b[1] == '5' || b[1] == '6')) d = read_pnm(path, b, n, w, h, ch);
   else if (n >= 4 && b[0] == 0xFF && b[1] == 0xD8) d = nlk_read_jpeg(path, b, n, w, h, ch);
-  else fail(path, "unknown image format (supported: TIFF, PNG, JPEG (baseline), PFM, PGM / PPM, FLO)");
+  else fail(path, "unknown image format (supported: TIFF, PNG, JPEG, PFM, PGM / PPM, FLO)");
   free(b);
   return d;
 }

@@ -125,7 +125,7 @@ def test_pgm_and_ppm_files_read_like_the_reference_library_reads_them(iio, conv,
 
 
 def test_jpeg_files_read_like_the_reference_library_reads_them(iio, conv, tmp_path):
-    """lib/iio/iio.c:1416-1460 reads JPEG through libjpeg (here IJG 9): baseline files must come back bit for bit -
+    """lib/iio/iio.c:1416-1460 reads JPEG through libjpeg (here IJG 9): baseline and progressive files must come back bit for bit -
     grey, full-resolution colour, and subsampled chroma (4:2:2, 4:2:0, and 4 x 1 / 1 x 4 made by patching a frame
     header), which libjpeg 9 brings to full resolution inside its fixed-point inverse transform (a 16-point
     transform of the 8 coefficients: host/imgio_jpeg.c) - with restart markers and optimised Huffman tables too."""
@@ -142,7 +142,15 @@ def test_jpeg_files_read_like_the_reference_library_reads_them(iio, conv, tmp_pa
              "tiny": (img[:5, :3], dict(quality=90, subsampling=0)), "row": (img[:1, :, 0], dict(quality=95)),
              "rgb422_q85": (img, dict(quality=85, subsampling=1)), "rgb420_q85": (img, dict(quality=85, subsampling=2)),
              "rgb420_q50_rst": (img, dict(quality=50, subsampling=2, restart_marker_blocks=3)),
-             "noise420_q95": (noise, dict(quality=95, subsampling=2)), "noise422_q30": (noise, dict(quality=30, subsampling=1))}
+             "noise420_q95": (noise, dict(quality=95, subsampling=2)), "noise422_q30": (noise, dict(quality=30, subsampling=1)),
+             # progressive: DC and AC bands in separate scans, successive approximation (refinement passes, end-of-band runs)
+             "prog420": (img, dict(quality=85, subsampling=2, progressive=True)),
+             "prog444": (img, dict(quality=90, subsampling=0, progressive=True)),
+             "prog_gray": (img[..., 0], dict(quality=80, progressive=True)),
+             "prog_noise": (noise, dict(quality=95, subsampling=2, progressive=True)),
+             "prog422_q30": (noise, dict(quality=30, subsampling=1, progressive=True)),
+             "prog_rst": (img, dict(quality=75, subsampling=2, progressive=True, restart_marker_blocks=2)),
+             "prog_tiny": (img[:3, :5], dict(quality=90, progressive=True))}
     for name, (a, kw) in files.items():
         Image.fromarray(a).save(tmp_path / (name + ".jpg"), **kw)
     # luminance sampled 4 x 1 and 1 x 4: the 2 x 2 of a 4:2:0 file rewritten in its frame header (six blocks per MCU
