@@ -524,9 +524,13 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   pl.img_match = basic ? pl.img_basic : pl.img_cur;
   NlkTile& tl = pl.tl;
   // 8 x 4 targets per workgroup, four 4 x 2 blocks that share their squared differences. A small grid
-  // (fewer than ~4 such tiles per CU: 256 x 256, 640 x 480) is latency bound instead: 4 x 2 tiles, one
-  // target at a time, two targets per wavefront (C1: match 0.058 -> 0.02 ms)
-  const bool small_grid = (size_t)((g.ngx + 7) / 8) * ((g.ngy + 3) / 4) < 1024;
+  // (fewer than ~2 such tiles per CU: 256 x 256, 512 x 384, a 34-row strip of a 1080p frame) is latency bound
+  // instead: 4 x 2 tiles, one target at a time, two targets per wavefront (C1: match 0.058 -> 0.02 ms).
+  // Where the two meet (round 4, temporal / first-frame match ms, blocks against target by target): 384 tiles
+  // 0.059 / 0.144 against 0.053 / 0.141; 486: 0.061 / 0.148 against 0.060 / 0.178; 600 (640 x 480): 0.071 / 0.188
+  // against 0.071 / 0.221; 950 (800 x 600): 0.087 / 0.241 against 0.095 / 0.302; 1020 (960 x 540, and the 67-row
+  // strips of four GPUs): 0.085 / 0.249 against 0.101 / 0.330. (Until then the limit was 1024 tiles.)
+  const bool small_grid = (size_t)((g.ngx + 7) / 8) * ((g.ngy + 3) / 4) < 576;
   tl.tgx = nlk_or(c->sw.mtx, small_grid ? 4 : 8);
   tl.tgy = nlk_or(c->sw.mty, small_grid ? 2 : 4);
   // 8 wavefronts per workgroup where the search radius is the temporal one (FLT1 / FLT2 temporal, SMO1), measured at
