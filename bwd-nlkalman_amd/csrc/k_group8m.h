@@ -145,10 +145,53 @@ __device__ __forceinline__ float nlk_wave_sum_dpp(float v) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// ---- the separable form (round 5). Per parity quadrant Y_q = C_qr F_q C_qc^T with the 4 x 4
+// even / odd halves of the basis: 2 x 64 MACs instead of the 256 of the Kronecker matrix D_q, on
+// v_mfma_f32_4x4x1_16B_f32 - sixteen independent 4 x 4 blocks, one per lane quad, operand layout and exactness
+// (a k = 1 step is one fmaf) checked by tools/ubench/mfma4x4.hip:
+//     D[i][j] (register i of lane 4 b + j) += A[i] (lane 4 b + i) * B[j] (lane 4 b + j)      for every block b
+// Lane = 4 * patch + folded row i; F_q[i][k] in register k. Stage 1, T = F_q C_qc^T: A = F_q[.][k], B = the lane
+// constant C[2 j + qc][k] - its result T[i][j] sits in lane 4 p + j, register i, which IS the B operand of stage 2,
+// Y = C_qr T (A = the lane constant C[2 a + qr][i]): no shuffle between the stages, and both stages use the same
+// eight constants E[parity][k] = C[2 (lane & 3) + parity][k]. The inverse takes the coefficients as the A operand
+// of its first stage (U^T = Y^T C_qr, B = G[qr][a] = C[2 a + qr][lane & 3]) and the result as the B operand of the
+// second (A = G[qc][b]): X_q[i][m] comes out in lane 4 p + i, register m - the layout the rows were loaded in.
+__device__ __forceinline__ nlk_f4 nlk_mfma4(float a, float b, nlk_f4 c) {
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+// Y_q (register a: coefficient (2 a + qr, 2 (lane & 3) + qc) of the quad's patch) = C + forward transform of F_q
+__device__ __forceinline__ nlk_f4 nlk_sep_fwd(const float (&Fq)[4], const float (&Ec)[4], const float (&Er)[4], nlk_f4 C) {
+  nlk_f4 T = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) T = nlk_mfma4(Fq[k], Ec[k], T);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) C = nlk_mfma4(Er[i], T[i], C);
+  return C;
+}
+// X_q (register m: folded pixel (lane & 3, m) of the quad's patch) = inverse transform of Y_q
+__device__ __forceinline__ nlk_f4 nlk_sep_inv(const nlk_f4& Yq, const float (&Gr)[4], const float (&Gc)[4]) {
+  nlk_f4 U = {0.f, 0.f, 0.f, 0.f}, X = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < 4; ++a) U = nlk_mfma4(Yq[a], Gr[a], U);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) X = nlk_mfma4(Gc[b], U[b], X);
+  return X;
+}
+// floats per channel slot of the gain stash in the separable form: [gain | (1-gain)*mean][lane & 3][quadrant][a],
+// + 4: a lane reads 16 bytes at slot * stride + 16 * (lane & 3) + 4 * q - with a stride of 4 (mod 64 banks) the
+// (plane, lane & 3) pairs of a wavefront meet on no bank
+#define NLK_G8S_SST 132
+// stash slots of the separable form: the image channels, the weight plane, (1-channel frames) one all-zero slot
+// for the idle planes; then 64 floats for -x0 (pass A)
+template <int CH> constexpr int nlk_g8s_slots() { return CH + 2 < 4 ? CH + 2 : 4; }
+template <int CH, bool SEP> constexpr int nlk_g8_stash_floats() {
+  return SEP ? nlk_g8s_slots<CH>() * NLK_G8S_SST + 64 : (CH + 2) * NLK_G8_SST;
+}
+
 #ifndef NLK_G8_WPS
 #define NLK_G8_WPS 3  // wavefronts per SIMD the register budget is cut for (experiments: -DNLK_G8_WPS=2)
 #endif
-template <int CH, bool SMO>
+template <int CH, bool SMO, bool SEP>
 __global__ void __launch_bounds__(64, NLK_G8_WPS)
 k_group8m(const float* __restrict__ img,   // matching / statistics image (planar)
           const float* __restrict__ cur,   // image whose patches are filtered
@@ -254,47 +297,67 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   // channel (gain 0, mean = DCT of a constant-1 patch: 8 at the DC coefficient) and the unused slots
   // of a 1-channel frame as another (all zero), so that its shrinkage is one fma without selects
   float* stash = smem + (CH + 1) * plane;
-  for (int i = lane; i < 2 * NLK_G8_SST; i += 64) stash[CH * NLK_G8_SST + i] = (i == 64) ? 8.f : 0.f;
+  constexpr int SST = SEP ? NLK_G8S_SST : NLK_G8_SST;      // floats per stash slot
+  constexpr int NSLOT = SEP ? nlk_g8s_slots<CH>() : CH + 2;
+  for (int i = lane; i < (NSLOT - CH) * SST; i += 64) stash[CH * SST + i] = (i == 64) ? 8.f : 0.f;
   __syncthreads();
 
   const int lo = lane & 15, g4 = lane >> 4;
-  // D_q as the forward operand (dA: D_q[coef lo][pixel 4*g4+s]) and as the inverse
+  // separable form: lane = 4 * patch slot + folded row; in pass B a step's slot = 4 * member + plane
+  const int si = lane & 3, sp = lane >> 2, spl = sp & 3;
+  // Kronecker form: D_q as the forward operand (dA: D_q[coef lo][pixel 4*g4+s]) and as the inverse
   // operand (dI: D_q[coef 4*g4+s][pixel lo]); q = 2*qr + qc
   nlk_basis_op dA[4], dI[4];
+  // separable form: E[parity][k] = C[2 si + parity][k] (forward, both stages), G[parity][a] = C[2 a + parity][si]
+  float sE[2][4], sG[2][4];
+  if constexpr (SEP) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int qr = q >> 1, qc = q & 1;
-    float a[4], b[4];
+    for (int par = 0; par < 2; ++par)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      a[s] = basis[(2 * (lo >> 2) + qr) * 8 + g4] * basis[(2 * (lo & 3) + qc) * 8 + s];
-      b[s] = basis[(2 * g4 + qr) * 8 + (lo >> 2)] * basis[(2 * s + qc) * 8 + (lo & 3)];
+      for (int s = 0; s < 4; ++s) {
+        sE[par][s] = basis[(2 * si + par) * 8 + s];
+        sG[par][s] = basis[(2 * s + par) * 8 + si];
+      }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int qr = q >> 1, qc = q & 1;
+      float a[4], b[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        a[s] = basis[(2 * (lo >> 2) + qr) * 8 + g4] * basis[(2 * (lo & 3) + qc) * 8 + s];
+        b[s] = basis[(2 * g4 + qr) * 8 + (lo >> 2)] * basis[(2 * s + qc) * 8 + (lo & 3)];
+      }
+      dA[q] = nlk_f4{a[0], a[1], a[2], a[3]};
+      dI[q] = nlk_f4{b[0], b[1], b[2], b[3]};
     }
-    dA[q] = nlk_f4{a[0], a[1], a[2], a[3]};
-    dI[q] = nlk_f4{b[0], b[1], b[2], b[3]};
   }
-  // aggregation role: folded pixel lo = (pi, pj) of plane g4 -> 4 pixels of the patch
+  // aggregation role. Kronecker form: folded pixel lo = (pi, pj) of plane g4 -> 4 pixels of the patch.
+  // Separable form (after the transposition of pass B): plane spl, rows si and 7 - si, columns g4 and 4 + g4.
   const int pi = lo >> 2, pj = lo & 3;
-  const bool agg_on = g4 <= CH;
+  const int aplane = SEP ? spl : g4;
+  const bool agg_on = aplane <= CH;
   int poff[4], goff[4];
   float win[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
-    const int r = (kk & 2) ? 7 - pi : pi, c = (kk & 1) ? 7 - pj : pj;
-    poff[kk] = (agg_on ? g4 : 0) * plane + r * rwp + c;
+    const int r = SEP ? ((kk & 2) ? 7 - si : si) : ((kk & 2) ? 7 - pi : pi);
+    const int c = SEP ? 4 * (kk & 1) + g4 : ((kk & 1) ? 7 - pj : pj);
+    poff[kk] = (agg_on ? aplane : 0) * plane + r * rwp + c;
     goff[kk] = r * g.w + c;
     win[kk] = window[r * 8 + c];
   }
   const size_t npix = (size_t)g.w * g.h;
-  float* acc_p = acc + (size_t)(agg_on ? g4 : 0) * npix;
+  float* acc_p = acc + (size_t)(agg_on ? aplane : 0) * npix;
   const float* src = g.have_basic ? cur : img;  // patches that get filtered
   // the planar images as element offsets from one base (tl.pbase = the start of the context's image slab)
   const float* const pbase = tl.pbase;
   const uint32_t e_img = (uint32_t)(img - pbase), e_src = (uint32_t)(src - pbase), e_prev = prev ? (uint32_t)(prev - pbase) : e_img;
-  const uint32_t rowa = (uint32_t)(g4 * g.w), rowb = (uint32_t)((7 - g4) * g.w);
+  const int lrow = SEP ? si : g4;  // the two patch rows a lane loads: lrow and 7 - lrow
+  const uint32_t rowa = (uint32_t)(lrow * g.w), rowb = (uint32_t)((7 - lrow) * g.w);
   const float s2 = g.sigma2;
-  // pass-B role of the lane as a load slot: channel / member of slot lo
-  const int bch = lo >> 2, bm = lo & 3;
+  // pass-B role of the lane as a load slot: channel / member of its slot
+  const int bch = SEP ? spl : lo >> 2, bm = SEP ? g4 : lo & 3;
 
   for (int tt = 0; tt < cx * cy; ++tt) {
     if (!__builtin_amdgcn_readlane(rec_act, tt)) continue;
@@ -356,12 +419,6 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     // needs one: the group mean (members only) and, in the smoother, the transition term of a
     // candidate whose image patch counts while its previous patch does not (reference: :1659-1667).
     float part_sum = 0.f;
-    float S[6][4];
-    nlk_f4 NX0[4];
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) S[a][q] = 0.f;
     // per lane: offset (floats) of candidate (lane + 64 m)'s patch inside an image plane,
     // bit 31 = "has a valid previous patch"
     uint32_t oreg[2];
@@ -369,6 +426,13 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     for (int m = 0; m < 2; ++m)
       oreg[m] = (uint32_t)(nlk_y(qreg[m]) * g.w + nlk_x(qreg[m])) | ((uint32_t)((vbits[m] >> lane) & 1ull) << 31);
     const uint32_t o_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)oreg[0]) & 0x7fffffffu;
+    if constexpr (!SEP) {
+    float S[6][4];
+    nlk_f4 NX0[4];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) S[a][q] = 0.f;
     // MODE 0: no previous-frame patches (Wiener branch; 16 candidates per step), 1: filter with
     // previous-frame patches (Kalman branch), 2: smoother with previous-frame patches.
     // Schedule: the rows of step it+1 are requested right after those of step it were folded (into the
@@ -514,6 +578,12 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
               term = a * v;
               m = T[0] * in1 - nx0q;
             }
+#ifdef NLK_DBG_PRINT
+            if ((int)t == NLK_DBG_PRINT && ch == 0) printf("KRO t %d q %d a %d j %d T0 %g T1 %g gain %g mean %g nx0 %g\n", (int)t, g4, lo >> 2, lo & 3, T[0], T[1], a, (1 - a) * m, nx0q);
+#endif
+#ifdef NLK_DBG_IDENT
+            a = 1.f; m = 0.f; term = 1.f;
+#endif
             part_sum += term;
             // parked in LDS for pass B: [channel][gain | (1-a)*mean][quadrant][coefficient]
             // (filter: a*PG + (1-a)*M, reference: :879, :902)
@@ -530,7 +600,228 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     if (np0 == 0) pass_a(std::integral_constant<int, 0>{});
     else if (!SMO) pass_a(std::integral_constant<int, 1>{});
     else pass_a(std::integral_constant<int, 2>{});
+    } else {
+    // ---------------- pass A, separable form. A batch = 16 patches, one per lane quad: 16 candidates of the image
+    // and - when the target has previous-frame patches - the same 16 candidates of the previous frame in a second
+    // batch, so that both coefficients of a candidate meet in one lane. A lane holds 16 coefficients of its
+    // patch (4 quadrants x 4 vertical frequencies, horizontal frequency = lane & 3), so the sums over the
+    // candidates are kept PER LANE over the batches (16 registers per statistic) and reduced over the 16 lane quads
+    // once per channel: two row-swap levels that halve the registers (quadrant -> lane group, as in the Kronecker
+    // form), two DPP levels, one select - lane (q, a, j) then owns coefficient (2a + qr, 2j + qc) for the gains.
+    // The shift -x0 (the first candidate's image coefficients: slot 0 of the first batch) is parked in LDS and
+    // is the C operand of every later chain; slots that must not count read the first candidate's image patch,
+    // exactly as above.
+    float* const x0buf = stash + NSLOT * SST;
+    auto pass_a = [&](auto mode_tag) {
+      constexpr int MODE = decltype(mode_tag)::value;
+      constexpr bool HP = MODE != 0;
+      // MODE 0: S0 image sum, S1 image squares. MODE 1: S0 previous sum, S1 previous squares, S2 squared difference,
+      // S3 previous sum over the valid candidates that are NOT group members (the members' mean is (S0 - S3) / n).
+      // MODE 2: S0 / S1 image, S2 / S3 previous, S4 squared difference of the candidates with a valid previous patch
+      constexpr int NS = MODE == 0 ? 2 : (MODE == 1 ? 4 : 5);
+      const int nb = (k + 15) >> 4;
+      if (nb == 0) return;
+      const uint32_t e_dead = o_first + e_img;
+      auto slot_offs = [&](int bb, uint32_t& oi, uint32_t& op) {
+        const int ci = 16 * bb + sp, cl = min(ci, k - 1);
+        const uint32_t oc = nlk_bperm_u(cl < 64 ? oreg[0] : oreg[1], cl & 63);
+        const bool in_k = ci < k, valid = (oc >> 31) != 0u;
+        const uint32_t o = oc & 0x7fffffffu;
+        const bool live_i = MODE == 1 ? (in_k && valid) : in_k;
+        oi = live_i ? o + e_img : e_dead;
+        op = (in_k && valid) ? o + e_prev : e_dead;
+      };
+      auto rows_read = [&](uint32_t off, int cc, float (&R)[16]) {
+        nlk_rows_load32(pbase, off + (uint32_t)cc * (uint32_t)npix, rowa, rowb, R);
+      };
+      const nlk_f4* const x0v = reinterpret_cast<const nlk_f4*>(x0buf + 16 * si);
+      float S[NS][4][4];
+#pragma unroll
+      for (int a = 0; a < NS; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) S[a][q][j] = 0.f;
+      float R[16], F[4][4];
+      uint32_t oi, op, oin, opn;
+      slot_offs(0, oi, op);
+      const uint32_t oi0 = oi, op0 = op;
+      rows_read(oi, 0, R);
+      slot_offs(1, oin, opn);
+      for (int ch = 0; ch < CH; ++ch)
+      for (int b = 0; b < nb; ++b) {
+        const bool wrap = b + 1 == nb;
+        const int chn = wrap ? min(ch + 1, CH - 1) : ch;
+        // the image rows of the next batch (after a channel's last batch the next channel's first; after the very
+        // last one a harmless reload), requested as soon as the registers are free
+        uint32_t o_img_next = wrap ? oi0 : oin;
+        uint32_t o_prev_now = op;
+        nlk_fold(R, F);
+        if (HP) {
+          NLK_PIN_FOLD(F, o_prev_now);
+          __builtin_amdgcn_sched_barrier(0);
+          rows_read(o_prev_now, ch, R);
+        } else {
+          NLK_PIN_FOLD(F, o_img_next);
+          __builtin_amdgcn_sched_barrier(0);
+          rows_read(o_img_next, chn, R);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        nlk_f4 Yi[4], Yp[4];
+        if (b == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Yi[q] = nlk_sep_fwd(F[q], sE[q & 1], sE[q >> 1], nlk_f4{0.f, 0.f, 0.f, 0.f});
+          if (sp == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) reinterpret_cast<nlk_f4*>(x0buf + 16 * si)[q] = -Yi[q];
+          }
+          // (lanes reading what OTHER lanes have just written: without the fences the compiler, reasoning per thread,
+          // moved the reads of the lanes that do not write in front of the writes)
+          nlk_wave_lds_order();
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Yi[q] += x0v[q];
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Yi[q] = nlk_sep_fwd(F[q], sE[q & 1], sE[q >> 1], x0v[q]);
+        }
+        if (HP) {
+          nlk_fold(R, F);
+          NLK_PIN_FOLD(F, o_img_next);
+          __builtin_amdgcn_sched_barrier(0);
+          rows_read(o_img_next, chn, R);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Yp[q] = nlk_sep_fwd(F[q], sE[q & 1], sE[q >> 1], x0v[q]);
+        }
+        oi = o_img_next;
+        op = wrap ? op0 : opn;
+        slot_offs(wrap ? 1 : b + 2, oin, opn);
+        if constexpr (HP) {
+          // the 16 candidates of the batch: valid previous patch / group membership, one bit per lane quad
+          const uint64_t vw = b < 4 ? vbits[0] : vbits[1], gw = b < 4 ? gbits[0] : gbits[1];
+          const uint32_t vch = (uint32_t)(vw >> (16 * (b & 3))) & 0xffffu, gch = (uint32_t)(gw >> (16 * (b & 3))) & 0xffffu;
+          if constexpr (MODE == 1) {
+            const bool mixed = (vch & ~gch) != 0u;  // (wave-uniform) valid candidates that are not members
+            const float mkc = (float)((~gch >> sp) & 1u);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float di = Yi[q][j], d = Yp[q][j];
+                S[0][q][j] += d;
+                S[1][q][j] = fmaf(d, d, S[1][q][j]);
+                const float df = di - d;  // reference: :769-783
+                S[2][q][j] = fmaf(df, df, S[2][q][j]);
+              }
+            if (mixed) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) S[NS > 3 ? 3 : 0][q][j] = fmaf(mkc, Yp[q][j], S[NS > 3 ? 3 : 0][q][j]);
+            }
+          } else {
+            const float mk = (float)((vch >> sp) & 1u);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float di = Yi[q][j], d = Yp[q][j];
+                S[0][q][j] += di;
+                S[1][q][j] = fmaf(di, di, S[1][q][j]);
+                S[NS > 2 ? 2 : 0][q][j] += d;
+                S[NS > 3 ? 3 : 0][q][j] = fmaf(d, d, S[NS > 3 ? 3 : 0][q][j]);
+                const float df = di - d;  // smoother: :1659-1667
+                S[NS > 4 ? 4 : 0][q][j] = fmaf(mk * df, df, S[NS > 4 ? 4 : 0][q][j]);
+              }
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              S[0][q][j] += Yi[q][j];
+              S[1][q][j] = fmaf(Yi[q][j], Yi[q][j], S[1][q][j]);
+            }
+        }
+        if (wrap) {
+          // The channel is complete. Per statistic 16 registers (q, a) x 16 lane quads: the quadrant goes to the lane
+          // group (v_permlane32_swap + add over qr, v_permlane16_swap + add over qc: 16 -> 8 -> 4 registers), the
+          // two remaining lane bits are summed with row rotations, and every lane keeps the register a = its bits 2..3.
+          float T[NS];
+#pragma unroll
+          for (int a = 0; a < NS; ++a) {
+            float X[2][4], Z[4];
+#pragma unroll
+            for (int qc = 0; qc < 2; ++qc)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(S[a][qc][j]), __float_as_uint(S[a][2 + qc][j]), false, false);
+                X[qc][j] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+              }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const auto z = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[0][j]), __float_as_uint(X[1][j]), false, false);
+              Z[j] = __uint_as_float(z[0]) + __uint_as_float(z[1]);
+              Z[j] += nlk_dpp<NLK_DPP_ROR8>(Z[j]);
+              Z[j] += nlk_dpp<0x124 /* row_ror:4 */>(Z[j]);
+            }
+            const float z01 = (spl & 1) ? Z[1] : Z[0], z23 = (spl & 1) ? Z[3] : Z[2];
+            T[a] = (spl & 2) ? z23 : z01;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) S[a][q][j] = 0.f;
+          }
+          // ---- gain of coefficient (quadrant g4, a = spl, horizontal index si) (reference: :799-811, :859-904;
+          // smoother :1683-1776)
+          {
+            const int cidx = 16 * si + 4 * g4 + spl;
+            const float nx0q = x0buf[cidx];
+            float a, term, m;
+            if (MODE == 2) {
+              const float v1 = (T[1] - T[0] * T[0] * in1) * in1;  // image variance
+              const float v0 = (T[NS > 3 ? 3 : 0] - T[NS > 2 ? 2 : 0] * T[NS > 2 ? 2 : 0] * in0) * in0;  // previous-frame variance
+              const float v01n = T[NS > 4 ? 4 : 0] * in0;
+              a = v1 * __builtin_amdgcn_rcpf(v1 + g.beta_t * v01n);
+              const float pv = v0 - g.beta_t * v01n;
+              term = (1 - a * a) * v1 + a * a * (pv > 0.f ? pv : 0.f);
+              m = 0.f;
+            } else if (MODE == 1) {
+              const float v0 = (T[1] - T[0] * T[0] * in0) * in0;
+              const float v01n = T[NS > 2 ? 2 : 0] * in0;
+              const float d = v01n - (g.have_basic ? 0.f : s2);
+              const float v = v0 + (0.f > d ? 0.f : d);
+              a = v * __builtin_amdgcn_rcpf(v + g.beta_t * s2);
+              term = (1 - a * a) * v + a * a * s2;
+              m = (T[0] - T[NS > 3 ? 3 : 0]) * ing - nx0q;
+            } else {
+              const float v1 = (T[1] - T[0] * T[0] * in1) * in1;
+              const float d = v1 - (g.have_basic ? 0.f : s2);
+              const float v = 0.f > d ? 0.f : d;
+              a = v * __builtin_amdgcn_rcpf(v + g.beta_x * s2);
+              term = a * v;
+              m = T[0] * in1 - nx0q;
+            }
+#ifdef NLK_DBG_PRINT
+            if ((int)t == NLK_DBG_PRINT && ch == 0) printf("SEP t %d q %d a %d j %d T0 %g T1 %g gain %g mean %g nx0 %g\n", (int)t, g4, spl, si, T[0], T[1], a, (1 - a) * m, nx0q);
+#endif
+#ifdef NLK_DBG_IDENT
+            a = 1.f; m = 0.f; term = 1.f;
+#endif
+            part_sum += term;
+            // parked in LDS for pass B: [channel][gain | (1-a)*mean][si][quadrant][a]
+            stash[ch * SST + cidx] = a;
+            stash[ch * SST + 64 + cidx] = (1 - a) * m;
+          }
+        }
+      }
+    };
+    if (np0 == 0) pass_a(std::integral_constant<int, 0>{});
+    else if (!SMO) pass_a(std::integral_constant<int, 1>{});
+    else pass_a(std::integral_constant<int, 2>{});
+    }
 
+    nlk_wave_lds_order();  // (the gains were parked by other lanes)
     // ---------------- pass B: shrink, invert and aggregate the group members, 4 per step
     // (slot lo = 4*channel + member; slots without a member / channel read a valid patch
     // and their results are not used)
@@ -570,11 +861,13 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     float ww[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) ww[kk] = wgt * win[kk];
-    const int bst = min(bch, CH + 1);  // stash channel of slot lo: image channel, weights, or nothing
-    const float* st_g = stash + bst * NLK_G8_SST + 4 * g4;  // + 16*q: gains of coefficients 4*g4 .. 4*g4+3
-    const float* st_m = stash + bst * NLK_G8_SST + 64 + 4 * g4;
+    const int bst = min(bch, NSLOT - 1);  // stash slot of the lane's load slot: image channel, weights, or nothing
+    // gains of the lane's four coefficients of quadrant q at + 4 * q (separable) / + 16 * q (Kronecker)
+    const float* st_g = stash + bst * SST + (SEP ? 16 * si : 4 * g4);
+    const float* st_m = st_g + 64;
+    constexpr int QST = SEP ? 4 : 16;
     for (int n0 = 0; n0 < nagg; n0 += 4) {
-      nlk_f4 Y[4], Z[4];
+      nlk_f4 Y[4];
       if (SMO) {
         // The smoother's update (1 - a) A + a B of a member's coefficients (A image, B previous frame,
         // reference: :1775) is A + a (B - A), and every step from here to the frame is linear: the member's
@@ -589,43 +882,76 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       nlk_rows_load32(pbase, e_src + offn, rowa, rowb, R);
 #pragma unroll
       for (int q = 0; q < 4; ++q) Y[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
-      if (SMO) {
-        nlk_rows_load32(pbase, e_psrc + offn, rowa, rowb, Rp);
-        offn = member_off(n0 + 8);
-        __builtin_amdgcn_sched_barrier(0);
-        nlk_mfma_fwd<true>(F, dA, Y);
+      if (SMO) nlk_rows_load32(pbase, e_psrc + offn, rowa, rowb, Rp);
+      offn = member_off(n0 + 8);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (SEP) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const nlk_f4 gq = *reinterpret_cast<const nlk_f4*>(st_g + 16 * q);
-          const nlk_f4 mq = *reinterpret_cast<const nlk_f4*>(st_m + 16 * q);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            // (weight / unused slots carry gain 0 and their value - the constant's DCT - in the mean half; a
-            // pass-through target reads its own patch as "previous" - the difference is zero - and its gains
-            // come from the Wiener formula with beta_x = 0, i.e. may be 0 / 0: not used)
-            Y[q][j] = bch < CH ? (passthrough ? 0.f : gq[j] * Y[q][j]) : mq[j];
-          }
-        }
+        for (int q = 0; q < 4; ++q) Y[q] = nlk_sep_fwd(F[q], sE[q & 1], sE[q >> 1], Y[q]);
       } else {
-        offn = member_off(n0 + 8);
-        __builtin_amdgcn_sched_barrier(0);
         nlk_mfma_fwd<true>(F, dA, Y);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const nlk_f4 gq = *reinterpret_cast<const nlk_f4*>(st_g + 16 * q);
-          const nlk_f4 mq = *reinterpret_cast<const nlk_f4*>(st_m + 16 * q);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) Y[q][j] = fmaf(gq[j], Y[q][j], mq[j]);
-        }
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) Z[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float y[4] = {Y[q][0], Y[q][1], Y[q][2], Y[q][3]};
-        Z[q] = nlk_mfma_q<false>(y, dI[q], Z[q]);
+        const nlk_f4 gq = *reinterpret_cast<const nlk_f4*>(st_g + QST * q);
+        const nlk_f4 mq = *reinterpret_cast<const nlk_f4*>(st_m + QST * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // (smoother: weight / unused slots carry gain 0 and their value - the constant's DCT - in the mean half; a
+          // pass-through target reads its own patch as "previous" - the difference is zero - and its gains
+          // come from the Wiener formula with beta_x = 0, i.e. may be 0 / 0: not used)
+          if (SMO) Y[q][j] = bch < CH ? (passthrough ? 0.f : gq[j] * Y[q][j]) : mq[j];
+          else Y[q][j] = fmaf(gq[j], Y[q][j], mq[j]);
+        }
       }
-      // register m of Z = member n0+m, plane g4, folded pixel lo
+      // PX[m][kk]: the lane's four pixels (aggregation role above) of member n0 + m, plane aplane
+      float PX[4][4];
+      if constexpr (SEP) {
+        nlk_f4 X[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) X[q] = nlk_sep_inv(Y[q], sG[q >> 1], sG[q & 1]);
+        // unfold: rows si (O[0]) and 7 - si (O[1]) of the slot's patch, 8 columns each
+        float O[2][8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float e0 = X[0][c] + X[1][c], e1 = X[0][c] - X[1][c];
+          const float o0 = X[2][c] + X[3][c], o1 = X[2][c] - X[3][c];
+          O[0][c] = e0 + o0; O[0][7 - c] = e1 + o1; O[1][c] = e0 - o0; O[1][7 - c] = e1 - o1;
+        }
+        // One LDS instruction takes one register of all 64 lanes - sixteen patches at once, four of them in every
+        // plane, which may overlap: the tile updates are plain read-modify-writes, so an instruction must touch ONE
+        // member per plane. Transpose the step's member index (lane bits 4..5) with the column index modulo 4
+        // (register) by the row-swap instructions - 4 per group of four registers, no adds: afterwards register
+        // 4 h + m of a row holds column 4 h + g4 of member m (tools/ubench/permlane_swap.hip for what the swaps do).
+#pragma unroll
+        for (int sel = 0; sel < 2; ++sel)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float* o = &O[sel][4 * h];
+            const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[0]), __float_as_uint(o[2]), false, false);
+            const auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[1]), __float_as_uint(o[3]), false, false);
+            const auto u = __builtin_amdgcn_permlane16_swap(x[0], y[0], false, false);
+            const auto v = __builtin_amdgcn_permlane16_swap(x[1], y[1], false, false);
+            PX[0][2 * sel + h] = __uint_as_float(u[0]); PX[1][2 * sel + h] = __uint_as_float(u[1]);
+            PX[2][2 * sel + h] = __uint_as_float(v[0]); PX[3][2 * sel + h] = __uint_as_float(v[1]);
+          }
+      } else {
+        nlk_f4 Z[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Z[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float y[4] = {Y[q][0], Y[q][1], Y[q][2], Y[q][3]};
+          Z[q] = nlk_mfma_q<false>(y, dI[q], Z[q]);
+        }
+        // register m of Z = member n0+m, plane g4, folded pixel lo
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const float e0 = Z[0][m] + Z[1][m], e1 = Z[0][m] - Z[1][m];
+          const float o0 = Z[2][m] + Z[3][m], o1 = Z[2][m] - Z[3][m];
+          PX[m][0] = e0 + o0; PX[m][1] = e1 + o1; PX[m][2] = e0 - o0; PX[m][3] = e1 - o1;
+        }
+      }
       const uint32_t in4 = (uint32_t)((n0 < 64 ? inside[0] >> n0 : inside[1] >> (n0 - 64)) & 0xfull);
       if (in4 == 0xfu && n0 + 4 <= nagg) {
         const uint32_t mb = n0 < 64 ? mbase[0] : mbase[1];
@@ -636,16 +962,13 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         for (int m = 0; m < 4; ++m) tile_off[m] = __builtin_amdgcn_readlane((int)mb, (n0 & 63) + m);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          const float e0 = Z[0][m] + Z[1][m], e1 = Z[0][m] - Z[1][m];
-          const float o0 = Z[2][m] + Z[3][m], o1 = Z[2][m] - Z[3][m];
-          const float px[4] = {e0 + o0, e1 + o1, e0 - o0, e1 - o1};
-          if (agg_on) {  // (CH = 3: every lane group owns a plane)
+          if (agg_on) {  // (CH = 3: every lane owns a plane)
             float* dst = smem + tile_off[m];
             float old[4];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) old[kk] = dst[poff[kk]];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) dst[poff[kk]] = fmaf(ww[kk], px[kk], old[kk]);
+            for (int kk = 0; kk < 4; ++kk) dst[poff[kk]] = fmaf(ww[kk], PX[m][kk], old[kk]);
           }
         }
         continue;
@@ -656,9 +979,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         const uint32_t q = (n0 + m) < 64 ? __builtin_amdgcn_readlane(greg[0], n0 + m)
                                          : __builtin_amdgcn_readlane(greg[1], n0 + m - 64);
         const int qx = nlk_x(q), qy = nlk_y(q);
-        const float e0 = Z[0][m] + Z[1][m], e1 = Z[0][m] - Z[1][m];
-        const float o0 = Z[2][m] + Z[3][m], o1 = Z[2][m] - Z[3][m];
-        float px[4] = {e0 + o0, e1 + o1, e0 - o0, e1 - o1};
+        float px[4] = {PX[m][0], PX[m][1], PX[m][2], PX[m][3]};
         const int lx = qx - rx0, ly = qy - ry0;
         if (lx >= 0 && ly >= 0 && lx + PSZ <= rw && ly + PSZ <= rh) {
           if (agg_on) {
@@ -673,8 +994,8 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
           // a member outside the tile (never with the smoother's own halo; kept complete): straight to the frame,
           // the smoother's image term with it
           float* dst = acc_p + (size_t)qy * g.w + qx;
-          if (SMO && g4 < CH) {
-            const float* ip = src + (size_t)g4 * npix + (size_t)qy * g.w + qx;
+          if (SMO && aplane < CH) {
+            const float* ip = src + (size_t)aplane * npix + (size_t)qy * g.w + qx;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) px[kk] += ip[goff[kk]];
           }

@@ -14,6 +14,9 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
   // psz 8 runs its DCTs on the matrix cores (k_group8m.h); NLK_GROUP_DPP selects the
   // register/DPP kernel (k_group8.h) for comparison
   const bool mfma = !nlk_set(c->sw.group_dpp);
+  // the matrix-core kernel's DCT: separable on 4 x 4 blocks (default, round 5) or the Kronecker form on 16 x 16
+  // (NLK_GROUP_KRON=1: rounds 2-4, kept for comparison)
+  const bool sep = mfma && !nlk_set(c->sw.group_kron);
   // (k_group8m addresses every patch as planes base + a 32-bit byte offset: the call's images must lie in the
   // context's slab and the slab be smaller than 4 GiB - ~119 Mpixel of RGB; beyond that the packed-lane kernel)
   if (mfma) {
@@ -129,12 +132,13 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
 #ifndef NLK_G8_LDS_PAD
 #define NLK_G8_LDS_PAD 0  // (experiments: bytes of unused LDS per workgroup, to cut the occupancy)
 #endif
-    const size_t lds = sizeof(float) * ((size_t)(CH + 1) * tl.plane + (mfma ? (CH + 2) * NLK_G8_SST : 0)) + NLK_G8_LDS_PAD;
+    const size_t stash = mfma ? (sep ? nlk_g8_stash_floats<CH, true>() : nlk_g8_stash_floats<CH, false>()) : 0;
+    const size_t lds = sizeof(float) * ((size_t)(CH + 1) * tl.plane + stash) + NLK_G8_LDS_PAD;
     if (lds > 160 * 1024) return fail(c, NLK_EUNSUP, "aggregation tile needs %zu bytes of LDS", lds);
     void (*kern)(const float*, const float*, const float*, const uint8_t*, NlkGeom, NlkGTile,
                  const uint32_t*, const NlkTarget*, const uint32_t*, const uint8_t*, const float*,
                  const float*, float*);
-    kern = mfma ? k_group8m<CH, SMO> : k_group8<CH, SMO>;
+    kern = mfma ? (sep ? k_group8m<CH, SMO, true> : k_group8m<CH, SMO, false>) : k_group8<CH, SMO>;
     HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
     const float* basis = (const float*)c->tabs.p;
