@@ -168,6 +168,21 @@ __device__ __forceinline__ nlk_f4 nlk_sep_fwd(const float (&Fq)[4], const float 
   for (int i = 0; i < 4; ++i) C = nlk_mfma4(Er[i], T[i], C);
   return C;
 }
+// the four quadrants together: the first stages of all of them, then the second stages - no MFMA waits for the one
+// in front of it (16 registers of intermediate results instead of 4)
+__device__ __forceinline__ void nlk_sep_fwd4(const float (&F)[4][4], const float (&E)[2][4], nlk_f4 (&Y)[4]) {
+  nlk_f4 T[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) T[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) T[q] = nlk_mfma4(F[q][k], E[q & 1][k], T[q]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Y[q] = nlk_mfma4(E[q >> 1][i], T[q][i], Y[q]);
+}
 // X_q (register m: folded pixel (lane & 3, m) of the quad's patch) = inverse transform of Y_q
 __device__ __forceinline__ nlk_f4 nlk_sep_inv(const nlk_f4& Yq, const float (&Gr)[4], const float (&Gc)[4]) {
   nlk_f4 U = {0.f, 0.f, 0.f, 0.f}, X = {0.f, 0.f, 0.f, 0.f};
@@ -184,14 +199,15 @@ __device__ __forceinline__ nlk_f4 nlk_sep_inv(const nlk_f4& Yq, const float (&Gr
 // stash slots of the separable form: the image channels, the weight plane, (1-channel frames) one all-zero slot
 // for the idle planes; then 64 floats for -x0 (pass A)
 template <int CH> constexpr int nlk_g8s_slots() { return CH + 2 < 4 ? CH + 2 : 4; }
-template <int CH, bool SEP> constexpr int nlk_g8_stash_floats() {
-  return SEP ? nlk_g8s_slots<CH>() * NLK_G8S_SST + 64 : (CH + 2) * NLK_G8_SST;
+// SEP: bit 0 = pass A in the separable form, bit 1 = pass B
+template <int CH, int SEP> constexpr int nlk_g8_stash_floats() {
+  return ((SEP & 2) ? nlk_g8s_slots<CH>() * NLK_G8S_SST : (CH + 2) * NLK_G8_SST) + ((SEP & 1) ? 64 : 0);
 }
 
 #ifndef NLK_G8_WPS
 #define NLK_G8_WPS 3  // wavefronts per SIMD the register budget is cut for (experiments: -DNLK_G8_WPS=2)
 #endif
-template <int CH, bool SMO, bool SEP>
+template <int CH, bool SMO, int SEP>
 __global__ void __launch_bounds__(64, NLK_G8_WPS)
 k_group8m(const float* __restrict__ img,   // matching / statistics image (planar)
           const float* __restrict__ cur,   // image whose patches are filtered
@@ -297,8 +313,9 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   // channel (gain 0, mean = DCT of a constant-1 patch: 8 at the DC coefficient) and the unused slots
   // of a 1-channel frame as another (all zero), so that its shrinkage is one fma without selects
   float* stash = smem + (CH + 1) * plane;
-  constexpr int SST = SEP ? NLK_G8S_SST : NLK_G8_SST;      // floats per stash slot
-  constexpr int NSLOT = SEP ? nlk_g8s_slots<CH>() : CH + 2;
+  constexpr bool SEPA = (SEP & 1) != 0, SEPB = (SEP & 2) != 0;  // which pass runs the separable form
+  constexpr int SST = SEPB ? NLK_G8S_SST : NLK_G8_SST;      // floats per stash slot
+  constexpr int NSLOT = SEPB ? nlk_g8s_slots<CH>() : CH + 2;
   for (int i = lane; i < (NSLOT - CH) * SST; i += 64) stash[CH * SST + i] = (i == 64) ? 8.f : 0.f;
   __syncthreads();
 
@@ -310,7 +327,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   nlk_basis_op dA[4], dI[4];
   // separable form: E[parity][k] = C[2 si + parity][k] (forward, both stages), G[parity][a] = C[2 a + parity][si]
   float sE[2][4], sG[2][4];
-  if constexpr (SEP) {
+  if constexpr (SEP != 0) {
 #pragma unroll
     for (int par = 0; par < 2; ++par)
 #pragma unroll
@@ -318,7 +335,8 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         sE[par][s] = basis[(2 * si + par) * 8 + s];
         sG[par][s] = basis[(2 * s + par) * 8 + si];
       }
-  } else {
+  }
+  if constexpr (SEP != 3) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int qr = q >> 1, qc = q & 1;
@@ -335,14 +353,14 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   // aggregation role. Kronecker form: folded pixel lo = (pi, pj) of plane g4 -> 4 pixels of the patch.
   // Separable form (after the transposition of pass B): plane spl, rows si and 7 - si, columns g4 and 4 + g4.
   const int pi = lo >> 2, pj = lo & 3;
-  const int aplane = SEP ? spl : g4;
+  const int aplane = SEPB ? spl : g4;
   const bool agg_on = aplane <= CH;
   int poff[4], goff[4];
   float win[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
-    const int r = SEP ? ((kk & 2) ? 7 - si : si) : ((kk & 2) ? 7 - pi : pi);
-    const int c = SEP ? 4 * (kk & 1) + g4 : ((kk & 1) ? 7 - pj : pj);
+    const int r = SEPB ? ((kk & 2) ? 7 - si : si) : ((kk & 2) ? 7 - pi : pi);
+    const int c = SEPB ? 4 * (kk & 1) + g4 : ((kk & 1) ? 7 - pj : pj);
     poff[kk] = (agg_on ? aplane : 0) * plane + r * rwp + c;
     goff[kk] = r * g.w + c;
     win[kk] = window[r * 8 + c];
@@ -353,11 +371,13 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   // the planar images as element offsets from one base (tl.pbase = the start of the context's image slab)
   const float* const pbase = tl.pbase;
   const uint32_t e_img = (uint32_t)(img - pbase), e_src = (uint32_t)(src - pbase), e_prev = prev ? (uint32_t)(prev - pbase) : e_img;
-  const int lrow = SEP ? si : g4;  // the two patch rows a lane loads: lrow and 7 - lrow
-  const uint32_t rowa = (uint32_t)(lrow * g.w), rowb = (uint32_t)((7 - lrow) * g.w);
+  // the two patch rows a lane loads: lrow and 7 - lrow (by pass)
+  const int lrowA = SEPA ? si : g4, lrowB = SEPB ? si : g4;
+  const uint32_t rowa = (uint32_t)(lrowA * g.w), rowb = (uint32_t)((7 - lrowA) * g.w);
+  const uint32_t rowaB = (uint32_t)(lrowB * g.w), rowbB = (uint32_t)((7 - lrowB) * g.w);
   const float s2 = g.sigma2;
   // pass-B role of the lane as a load slot: channel / member of its slot
-  const int bch = SEP ? spl : lo >> 2, bm = SEP ? g4 : lo & 3;
+  const int bch = SEPB ? spl : lo >> 2, bm = SEPB ? g4 : lo & 3;
 
   for (int tt = 0; tt < cx * cy; ++tt) {
     if (!__builtin_amdgcn_readlane(rec_act, tt)) continue;
@@ -426,7 +446,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     for (int m = 0; m < 2; ++m)
       oreg[m] = (uint32_t)(nlk_y(qreg[m]) * g.w + nlk_x(qreg[m])) | ((uint32_t)((vbits[m] >> lane) & 1ull) << 31);
     const uint32_t o_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)oreg[0]) & 0x7fffffffu;
-    if constexpr (!SEP) {
+    if constexpr (!SEPA) {
     float S[6][4];
     nlk_f4 NX0[4];
 #pragma unroll
@@ -587,8 +607,10 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
             part_sum += term;
             // parked in LDS for pass B: [channel][gain | (1-a)*mean][quadrant][coefficient]
             // (filter: a*PG + (1-a)*M, reference: :879, :902)
-            stash[ch * NLK_G8_SST + g4 * 16 + lo] = a;
-            stash[ch * NLK_G8_SST + 64 + g4 * 16 + lo] = (1 - a) * m;
+            // (Kronecker pass B: [quadrant][coefficient]; separable pass B: [horizontal index][quadrant][vertical index])
+            const int cidx = SEPB ? 16 * (lo & 3) + 4 * g4 + (lo >> 2) : 16 * g4 + lo;
+            stash[ch * SST + cidx] = a;
+            stash[ch * SST + 64 + cidx] = (1 - a) * m;
           }
 #pragma unroll
           for (int a = 0; a < 6; ++a)
@@ -631,10 +653,29 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         oi = live_i ? o + e_img : e_dead;
         op = (in_k && valid) ? o + e_prev : e_dead;
       };
+#ifdef NLK_DBG_NOLOAD
+      bool dbg_first = true;
+#endif
       auto rows_read = [&](uint32_t off, int cc, float (&R)[16]) {
+#ifdef NLK_DBG_NOLOAD
+        if (dbg_first)
+#endif
         nlk_rows_load32(pbase, off + (uint32_t)cc * (uint32_t)npix, rowa, rowb, R);
+#ifdef NLK_DBG_NOLOAD
+        dbg_first = false;
+#endif
       };
       const nlk_f4* const x0v = reinterpret_cast<const nlk_f4*>(x0buf + 16 * si);
+#ifdef NLK_DBG_NOX0
+#define NLK_X0V(q) nlk_f4{0.f, 0.f, 0.f, 0.f}
+#else
+#define NLK_X0V(q) x0v[q]
+#endif
+#ifdef NLK_DBG_SERIAL
+#define NLK_SEP_FWD(F, Y) _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) Y[q_] = nlk_sep_fwd(F[q_], sE[q_ & 1], sE[q_ >> 1], Y[q_])
+#else
+#define NLK_SEP_FWD(F, Y) nlk_sep_fwd4(F, sE, Y)
+#endif
       float S[NS][4][4];
 #pragma unroll
       for (int a = 0; a < NS; ++a)
@@ -670,7 +711,8 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         nlk_f4 Yi[4], Yp[4];
         if (b == 0) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) Yi[q] = nlk_sep_fwd(F[q], sE[q & 1], sE[q >> 1], nlk_f4{0.f, 0.f, 0.f, 0.f});
+          for (int q = 0; q < 4; ++q) Yi[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
+          NLK_SEP_FWD(F, Yi);
           if (sp == 0) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) reinterpret_cast<nlk_f4*>(x0buf + 16 * si)[q] = -Yi[q];
@@ -682,7 +724,8 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
           for (int q = 0; q < 4; ++q) Yi[q] += x0v[q];
         } else {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) Yi[q] = nlk_sep_fwd(F[q], sE[q & 1], sE[q >> 1], x0v[q]);
+          for (int q = 0; q < 4; ++q) Yi[q] = NLK_X0V(q);
+          NLK_SEP_FWD(F, Yi);
         }
         if (HP) {
           nlk_fold(R, F);
@@ -691,11 +734,20 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
           rows_read(o_img_next, chn, R);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) Yp[q] = nlk_sep_fwd(F[q], sE[q & 1], sE[q >> 1], x0v[q]);
+          for (int q = 0; q < 4; ++q) Yp[q] = NLK_X0V(q);
+          NLK_SEP_FWD(F, Yp);
         }
         oi = o_img_next;
         op = wrap ? op0 : opn;
         slot_offs(wrap ? 1 : b + 2, oin, opn);
+#ifdef NLK_DBG_NOSTAT
+        if (true) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) S[0][q][j] += HP ? Yi[q][j] + Yp[q][j] : Yi[q][j];
+        } else
+#endif
         if constexpr (HP) {
           // the 16 candidates of the batch: valid previous patch / group membership, one bit per lane quad
           const uint64_t vw = b < 4 ? vbits[0] : vbits[1], gw = b < 4 ? gbits[0] : gbits[1];
@@ -775,8 +827,10 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
           // ---- gain of coefficient (quadrant g4, a = spl, horizontal index si) (reference: :799-811, :859-904;
           // smoother :1683-1776)
           {
-            const int cidx = 16 * si + 4 * g4 + spl;
-            const float nx0q = x0buf[cidx];
+            const float nx0q = x0buf[16 * si + 4 * g4 + spl];
+            // (where pass B reads the gains: separable [horizontal index][quadrant][vertical index], Kronecker
+            // [quadrant][coefficient])
+            const int cidx = SEPB ? 16 * si + 4 * g4 + spl : 16 * g4 + 4 * spl + si;
             float a, term, m;
             if (MODE == 2) {
               const float v1 = (T[1] - T[0] * T[0] * in1) * in1;  // image variance
@@ -816,9 +870,11 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         }
       }
     };
+#ifndef NLK_DBG_NOA
     if (np0 == 0) pass_a(std::integral_constant<int, 0>{});
     else if (!SMO) pass_a(std::integral_constant<int, 1>{});
     else pass_a(std::integral_constant<int, 2>{});
+#endif
     }
 
     nlk_wave_lds_order();  // (the gains were parked by other lanes)
@@ -835,8 +891,8 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     float R[16], Rp[16], F[4][4];
     {
       const uint32_t off = member_off(0);
-      nlk_rows_load32(pbase, e_src + off, rowa, rowb, R);
-      if (SMO) nlk_rows_load32(pbase, e_psrc + off, rowa, rowb, Rp);
+      nlk_rows_load32(pbase, e_src + off, rowaB, rowbB, R);
+      if (SMO) nlk_rows_load32(pbase, e_psrc + off, rowaB, rowbB, Rp);
     }
     uint32_t offn = member_off(4);
     // Where every member lands in the tile, worked out once per target with one member per lane: its offset
@@ -863,9 +919,12 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     for (int kk = 0; kk < 4; ++kk) ww[kk] = wgt * win[kk];
     const int bst = min(bch, NSLOT - 1);  // stash slot of the lane's load slot: image channel, weights, or nothing
     // gains of the lane's four coefficients of quadrant q at + 4 * q (separable) / + 16 * q (Kronecker)
-    const float* st_g = stash + bst * SST + (SEP ? 16 * si : 4 * g4);
+    const float* st_g = stash + bst * SST + (SEPB ? 16 * si : 4 * g4);
     const float* st_m = st_g + 64;
-    constexpr int QST = SEP ? 4 : 16;
+    constexpr int QST = SEPB ? 4 : 16;
+#ifdef NLK_DBG_NOB
+    if (g.w < 0)
+#endif
     for (int n0 = 0; n0 < nagg; n0 += 4) {
       nlk_f4 Y[4];
       if (SMO) {
@@ -879,13 +938,13 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         for (int c = 0; c < 16; ++c) R[c] = Rp[c] - R[c];
       }
       nlk_fold(R, F);
-      nlk_rows_load32(pbase, e_src + offn, rowa, rowb, R);
+      nlk_rows_load32(pbase, e_src + offn, rowaB, rowbB, R);
 #pragma unroll
       for (int q = 0; q < 4; ++q) Y[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
-      if (SMO) nlk_rows_load32(pbase, e_psrc + offn, rowa, rowb, Rp);
+      if (SMO) nlk_rows_load32(pbase, e_psrc + offn, rowaB, rowbB, Rp);
       offn = member_off(n0 + 8);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SEP) {
+      if constexpr (SEPB) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) Y[q] = nlk_sep_fwd(F[q], sE[q & 1], sE[q >> 1], Y[q]);
       } else {
@@ -906,7 +965,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       }
       // PX[m][kk]: the lane's four pixels (aggregation role above) of member n0 + m, plane aplane
       float PX[4][4];
-      if constexpr (SEP) {
+      if constexpr (SEPB) {
         nlk_f4 X[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) X[q] = nlk_sep_inv(Y[q], sG[q >> 1], sG[q & 1]);
@@ -1008,6 +1067,9 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
 
   // ---------------- flush the tile accumulator
   __syncthreads();
+#ifdef NLK_DBG_NOFLUSH
+  if (g.w > 0) return;
+#endif
   if (tl.slab) {
     // deterministic mode (k_gather.h): the planes as they stand, into this tile's slab
     if (lane == 0) {
