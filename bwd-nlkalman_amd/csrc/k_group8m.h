@@ -159,17 +159,9 @@ __device__ __forceinline__ float nlk_wave_sum_dpp(float v) {
 __device__ __forceinline__ nlk_f4 nlk_mfma4(float a, float b, nlk_f4 c) {
   return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
-// Y_q (register a: coefficient (2 a + qr, 2 (lane & 3) + qc) of the quad's patch) = C + forward transform of F_q
-__device__ __forceinline__ nlk_f4 nlk_sep_fwd(const float (&Fq)[4], const float (&Ec)[4], const float (&Er)[4], nlk_f4 C) {
-  nlk_f4 T = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) T = nlk_mfma4(Fq[k], Ec[k], T);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) C = nlk_mfma4(Er[i], T[i], C);
-  return C;
-}
-// the four quadrants together: the first stages of all of them, then the second stages - no MFMA waits for the one
-// in front of it (16 registers of intermediate results instead of 4)
+// Y[q] (register a: coefficient (2 a + qr, 2 (lane & 3) + qc) of the quad's patch) += forward transform of F[q]. The four
+// quadrants together: the first stages of all of them, then the second stages - no MFMA waits for the one in front of
+// it (C2 group 0.749 -> 0.742 ms against quadrant after quadrant)
 __device__ __forceinline__ void nlk_sep_fwd4(const float (&F)[4][4], const float (&E)[2][4], nlk_f4 (&Y)[4]) {
   nlk_f4 T[4];
 #pragma unroll
@@ -183,14 +175,19 @@ __device__ __forceinline__ void nlk_sep_fwd4(const float (&F)[4][4], const float
 #pragma unroll
     for (int q = 0; q < 4; ++q) Y[q] = nlk_mfma4(E[q >> 1][i], T[q][i], Y[q]);
 }
-// X_q (register m: folded pixel (lane & 3, m) of the quad's patch) = inverse transform of Y_q
-__device__ __forceinline__ nlk_f4 nlk_sep_inv(const nlk_f4& Yq, const float (&Gr)[4], const float (&Gc)[4]) {
-  nlk_f4 U = {0.f, 0.f, 0.f, 0.f}, X = {0.f, 0.f, 0.f, 0.f};
+// X[q] (register m: folded pixel (lane & 3, m) of the quad's patch) = inverse transform of Y[q]
+__device__ __forceinline__ void nlk_sep_inv4(const nlk_f4 (&Y)[4], const float (&G)[2][4], nlk_f4 (&X)[4]) {
+  nlk_f4 U[4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) U = nlk_mfma4(Yq[a], Gr[a], U);
+  for (int q = 0; q < 4; ++q) { U[q] = nlk_f4{0.f, 0.f, 0.f, 0.f}; X[q] = nlk_f4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-  for (int b = 0; b < 4; ++b) X = nlk_mfma4(Gc[b], U[b], X);
-  return X;
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) U[q] = nlk_mfma4(Y[q][a], G[q >> 1][a], U[q]);
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) X[q] = nlk_mfma4(G[q & 1][b], U[q][b], X[q]);
 }
 // floats per channel slot of the gain stash in the separable form: [gain | (1-gain)*mean][lane & 3][quadrant][a],
 // + 4: a lane reads 16 bytes at slot * stride + 16 * (lane & 3) + 4 * q - with a stride of 4 (mod 64 banks) the
@@ -199,9 +196,9 @@ __device__ __forceinline__ nlk_f4 nlk_sep_inv(const nlk_f4& Yq, const float (&Gr
 // stash slots of the separable form: the image channels, the weight plane, (1-channel frames) one all-zero slot
 // for the idle planes; then 64 floats for -x0 (pass A)
 template <int CH> constexpr int nlk_g8s_slots() { return CH + 2 < 4 ? CH + 2 : 4; }
-// SEP: bit 0 = pass A in the separable form, bit 1 = pass B
+// SEP: bit 1 = pass B in the separable form, bit 2 = pass A
 template <int CH, int SEP> constexpr int nlk_g8_stash_floats() {
-  return ((SEP & 2) ? nlk_g8s_slots<CH>() * NLK_G8S_SST : (CH + 2) * NLK_G8_SST) + ((SEP & 1) ? 64 : 0);
+  return ((SEP & 2) ? nlk_g8s_slots<CH>() * NLK_G8S_SST : (CH + 2) * NLK_G8_SST) + ((SEP & 4) ? 64 : 0);
 }
 
 #ifndef NLK_G8_WPS
@@ -313,7 +310,8 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   // channel (gain 0, mean = DCT of a constant-1 patch: 8 at the DC coefficient) and the unused slots
   // of a 1-channel frame as another (all zero), so that its shrinkage is one fma without selects
   float* stash = smem + (CH + 1) * plane;
-  constexpr bool SEPA = (SEP & 1) != 0, SEPB = (SEP & 2) != 0;  // which pass runs the separable form
+  // which pass runs the separable form (bit 1: pass B; bit 2: pass A)
+  constexpr bool SEPA = (SEP & 4) != 0, SEPB = (SEP & 2) != 0;
   constexpr int SST = SEPB ? NLK_G8S_SST : NLK_G8_SST;      // floats per stash slot
   constexpr int NSLOT = SEPB ? nlk_g8s_slots<CH>() : CH + 2;
   for (int i = lane; i < (NSLOT - CH) * SST; i += 64) stash[CH * SST + i] = (i == 64) ? 8.f : 0.f;
@@ -336,7 +334,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         sG[par][s] = basis[(2 * s + par) * 8 + si];
       }
   }
-  if constexpr (SEP != 3) {
+  if constexpr (SEP != 6) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int qr = q >> 1, qc = q & 1;
@@ -372,7 +370,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   const float* const pbase = tl.pbase;
   const uint32_t e_img = (uint32_t)(img - pbase), e_src = (uint32_t)(src - pbase), e_prev = prev ? (uint32_t)(prev - pbase) : e_img;
   // the two patch rows a lane loads: lrow and 7 - lrow (by pass)
-  const int lrowA = SEPA ? si : g4, lrowB = SEPB ? si : g4;
+  const int lrowA = g4, lrowB = SEPB ? si : g4;  // (the separable pass A loads one row per lane: there)
   const uint32_t rowa = (uint32_t)(lrowA * g.w), rowb = (uint32_t)((7 - lrowA) * g.w);
   const uint32_t rowaB = (uint32_t)(lrowB * g.w), rowbB = (uint32_t)((7 - lrowB) * g.w);
   const float s2 = g.sigma2;
@@ -598,12 +596,6 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
               term = a * v;
               m = T[0] * in1 - nx0q;
             }
-#ifdef NLK_DBG_PRINT
-            if ((int)t == NLK_DBG_PRINT && ch == 0) printf("KRO t %d q %d a %d j %d T0 %g T1 %g gain %g mean %g nx0 %g\n", (int)t, g4, lo >> 2, lo & 3, T[0], T[1], a, (1 - a) * m, nx0q);
-#endif
-#ifdef NLK_DBG_IDENT
-            a = 1.f; m = 0.f; term = 1.f;
-#endif
             part_sum += term;
             // parked in LDS for pass B: [channel][gain | (1-a)*mean][quadrant][coefficient]
             // (filter: a*PG + (1-a)*M, reference: :879, :902)
@@ -623,29 +615,74 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     else if (!SMO) pass_a(std::integral_constant<int, 1>{});
     else pass_a(std::integral_constant<int, 2>{});
     } else {
-    // ---------------- pass A, separable form. A batch = 16 patches, one per lane quad: 16 candidates of the image
-    // and - when the target has previous-frame patches - the same 16 candidates of the previous frame in a second
-    // batch, so that both coefficients of a candidate meet in one lane. A lane holds 16 coefficients of its
-    // patch (4 quadrants x 4 vertical frequencies, horizontal frequency = lane & 3), so the sums over the
-    // candidates are kept PER LANE over the batches (16 registers per statistic) and reduced over the 16 lane quads
-    // once per channel: two row-swap levels that halve the registers (quadrant -> lane group, as in the Kronecker
-    // form), two DPP levels, one select - lane (q, a, j) then owns coefficient (2a + qr, 2j + qc) for the gains.
-    // The shift -x0 (the first candidate's image coefficients: slot 0 of the first batch) is parked in LDS and
-    // is the C operand of every later chain; slots that must not count read the first candidate's image patch,
-    // exactly as above.
+    // ---------------- pass A, separable form (SEP bit 2). The transforms leave a PATCH per lane quad and the
+    // coefficients of a patch over the quad's lanes and registers, so the sums over the candidates are kept per lane
+    // over the batches and reduced over the lane quads once per channel; lane (quadrant g4, vertical index spl,
+    // horizontal index si) then owns one coefficient for the gains. The shift -x0 (the first candidate's image
+    // coefficients: slot 0 of the first batch) is parked in LDS and is the C operand of every later chain; slots
+    // that must not count read the first candidate's image patch, exactly as above.
     float* const x0buf = stash + NSLOT * SST;
+    // gain of the coefficient a lane owns after the reduction over the lane quads - quadrant g4, vertical index spl,
+    // horizontal index si - from the channel's totals T (reference: :799-811, :859-904; smoother :1683-1776)
+    auto sep_gain = [&](auto mode_tag, const auto& T, int ch) {
+      constexpr int MODE = decltype(mode_tag)::value;
+      constexpr int NS = MODE == 0 ? 2 : (MODE == 1 ? 4 : 5);
+        const float nx0q = x0buf[16 * si + 4 * g4 + spl];
+        // (where pass B reads the gains: separable [horizontal index][quadrant][vertical index], Kronecker
+        // [quadrant][coefficient])
+        const int cidx = SEPB ? 16 * si + 4 * g4 + spl : 16 * g4 + 4 * spl + si;
+        float a, term, m;
+        if (MODE == 2) {
+          const float v1 = (T[1] - T[0] * T[0] * in1) * in1;  // image variance
+          const float v0 = (T[NS > 3 ? 3 : 0] - T[NS > 2 ? 2 : 0] * T[NS > 2 ? 2 : 0] * in0) * in0;  // previous-frame variance
+          const float v01n = T[NS > 4 ? 4 : 0] * in0;
+          a = v1 * __builtin_amdgcn_rcpf(v1 + g.beta_t * v01n);
+          const float pv = v0 - g.beta_t * v01n;
+          term = (1 - a * a) * v1 + a * a * (pv > 0.f ? pv : 0.f);
+          m = 0.f;
+        } else if (MODE == 1) {
+          const float v0 = (T[1] - T[0] * T[0] * in0) * in0;
+          const float v01n = T[NS > 2 ? 2 : 0] * in0;
+          const float d = v01n - (g.have_basic ? 0.f : s2);
+          const float v = v0 + (0.f > d ? 0.f : d);
+          a = v * __builtin_amdgcn_rcpf(v + g.beta_t * s2);
+          term = (1 - a * a) * v + a * a * s2;
+          m = (T[0] - T[NS > 3 ? 3 : 0]) * ing - nx0q;
+        } else {
+          const float v1 = (T[1] - T[0] * T[0] * in1) * in1;
+          const float d = v1 - (g.have_basic ? 0.f : s2);
+          const float v = 0.f > d ? 0.f : d;
+          a = v * __builtin_amdgcn_rcpf(v + g.beta_x * s2);
+          term = a * v;
+          m = T[0] * in1 - nx0q;
+        }
+        part_sum += term;
+        // parked in LDS for pass B: [channel][gain | (1-a)*mean][si][quadrant][a]
+        stash[ch * SST + cidx] = a;
+        stash[ch * SST + 64 + cidx] = (1 - a) * m;
+    };
+    // HALF a patch per lane quad: lane = 32 h + 4 slot + i loads ONE row of its candidate - row i (h = 0) or 7 - i
+    // (h = 1) -, fetches the mirror row from the other half of the wavefront and keeps the sum P (h = 0: the
+    // quadrants of even vertical frequency) or the difference M (h = 1: odd). A batch = 8 candidates; a lane holds
+    // 2 quadrants x 4 vertical indices = 8 coefficients, so a statistic is 8 registers (with a whole patch per
+    // quad - 16 candidates per batch, 16 registers per statistic - the kernel spilled 27-65 registers and was
+    // slower: profiles/README.md round 5), both images' rows of the next batch are requested a whole batch ahead,
+    // and the reduction over the 8 lane quads of a half is one row-swap level, two rotations and a select.
     auto pass_a = [&](auto mode_tag) {
       constexpr int MODE = decltype(mode_tag)::value;
       constexpr bool HP = MODE != 0;
-      // MODE 0: S0 image sum, S1 image squares. MODE 1: S0 previous sum, S1 previous squares, S2 squared difference,
-      // S3 previous sum over the valid candidates that are NOT group members (the members' mean is (S0 - S3) / n).
-      // MODE 2: S0 / S1 image, S2 / S3 previous, S4 squared difference of the candidates with a valid previous patch
       constexpr int NS = MODE == 0 ? 2 : (MODE == 1 ? 4 : 5);
-      const int nb = (k + 15) >> 4;
+      const int nb = (k + 7) >> 3;
       if (nb == 0) return;
+      const int hh = lane >> 5, hp = (lane >> 2) & 7;
+      const uint32_t rowh = (uint32_t)((hh ? 7 - si : si) * g.w);
+      const float sgn = hh ? -1.f : 1.f;
+      float sEh[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sEh[i] = hh ? sE[1][i] : sE[0][i];
       const uint32_t e_dead = o_first + e_img;
       auto slot_offs = [&](int bb, uint32_t& oi, uint32_t& op) {
-        const int ci = 16 * bb + sp, cl = min(ci, k - 1);
+        const int ci = 8 * bb + hp, cl = min(ci, k - 1);
         const uint32_t oc = nlk_bperm_u(cl < 64 ? oreg[0] : oreg[1], cl & 63);
         const bool in_k = ci < k, valid = (oc >> 31) != 0u;
         const uint32_t o = oc & 0x7fffffffu;
@@ -653,110 +690,97 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         oi = live_i ? o + e_img : e_dead;
         op = (in_k && valid) ? o + e_prev : e_dead;
       };
-#ifdef NLK_DBG_NOLOAD
-      bool dbg_first = true;
-#endif
-      auto rows_read = [&](uint32_t off, int cc, float (&R)[16]) {
-#ifdef NLK_DBG_NOLOAD
-        if (dbg_first)
-#endif
-        nlk_rows_load32(pbase, off + (uint32_t)cc * (uint32_t)npix, rowa, rowb, R);
-#ifdef NLK_DBG_NOLOAD
-        dbg_first = false;
-#endif
+      auto row_read = [&](uint32_t off, int cc, float (&R)[8]) {
+        typedef const __attribute__((address_space(1))) nlk_f4u* gp4;
+        const char* bp = reinterpret_cast<const char*>(pbase);
+        const uint32_t o = (off + (uint32_t)cc * (uint32_t)npix + rowh) * 4u;
+        const nlk_f4u a0 = *(gp4)(bp + (size_t)o), a1 = *(gp4)(bp + (size_t)o + 16);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { R[c] = a0[c]; R[4 + c] = a1[c]; }
       };
-      const nlk_f4* const x0v = reinterpret_cast<const nlk_f4*>(x0buf + 16 * si);
-#ifdef NLK_DBG_NOX0
-#define NLK_X0V(q) nlk_f4{0.f, 0.f, 0.f, 0.f}
-#else
-#define NLK_X0V(q) x0v[q]
-#endif
-#ifdef NLK_DBG_SERIAL
-#define NLK_SEP_FWD(F, Y) _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) Y[q_] = nlk_sep_fwd(F[q_], sE[q_ & 1], sE[q_ >> 1], Y[q_])
-#else
-#define NLK_SEP_FWD(F, Y) nlk_sep_fwd4(F, sE, Y)
-#endif
-      float S[NS][4][4];
+      // the row and its mirror row (in the other half of the wavefront) -> P or M -> F[qc][s]
+      auto fold_half = [&](const float (&R)[8], float (&F)[2][4]) {
+        // (the mirror row through ds_bpermute: measured in place, 32 per batch, a bpermute costs 0.6 cycles - the LDS
+        // pipe is idle here -, a v_permlane32_swap 7.2, a v_fma_f32 1.5: profiles/README.md round 5)
+        float PM[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) PM[c] = fmaf(sgn, R[c], nlk_bperm(R[c], lane ^ 32));  // top + bottom | top - bottom
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { F[0][c] = PM[c] + PM[7 - c]; F[1][c] = PM[c] - PM[7 - c]; }
+      };
+      auto fwd_half = [&](const float (&F)[2][4], nlk_f4 (&Y)[2]) {
+        nlk_f4 T[2] = {nlk_f4{0.f, 0.f, 0.f, 0.f}, nlk_f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int qc = 0; qc < 2; ++qc) T[qc] = nlk_mfma4(F[qc][kk], sE[qc][kk], T[qc]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int qc = 0; qc < 2; ++qc) Y[qc] = nlk_mfma4(sEh[i], T[qc][i], Y[qc]);
+      };
+      nlk_f4* const x0w = reinterpret_cast<nlk_f4*>(x0buf + 16 * si + 8 * hh);  // [qc]: quadrant 2 h + qc
+      const nlk_f4* const x0v = x0w;
+      float S[NS][2][4];
 #pragma unroll
       for (int a = 0; a < NS; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
           for (int j = 0; j < 4; ++j) S[a][q][j] = 0.f;
-      float R[16], F[4][4];
+      float Ri[8], Rp[8];
       uint32_t oi, op, oin, opn;
       slot_offs(0, oi, op);
       const uint32_t oi0 = oi, op0 = op;
-      rows_read(oi, 0, R);
+      row_read(oi, 0, Ri);
+      if (HP) row_read(op, 0, Rp);
       slot_offs(1, oin, opn);
       for (int ch = 0; ch < CH; ++ch)
       for (int b = 0; b < nb; ++b) {
         const bool wrap = b + 1 == nb;
         const int chn = wrap ? min(ch + 1, CH - 1) : ch;
-        // the image rows of the next batch (after a channel's last batch the next channel's first; after the very
-        // last one a harmless reload), requested as soon as the registers are free
-        uint32_t o_img_next = wrap ? oi0 : oin;
-        uint32_t o_prev_now = op;
-        nlk_fold(R, F);
-        if (HP) {
-          NLK_PIN_FOLD(F, o_prev_now);
-          __builtin_amdgcn_sched_barrier(0);
-          rows_read(o_prev_now, ch, R);
-        } else {
-          NLK_PIN_FOLD(F, o_img_next);
-          __builtin_amdgcn_sched_barrier(0);
-          rows_read(o_img_next, chn, R);
-        }
+        float Fi[2][4], Fp[2][4];
+        fold_half(Ri, Fi);
+        if (HP) fold_half(Rp, Fp);
+        // the next batch's rows (after a channel's last batch the next channel's first; after the very last one a
+        // harmless reload), requested now: a whole batch of transforms and statistics for them to arrive
+        uint32_t o_in = wrap ? oi0 : oin, o_pn = wrap ? op0 : opn;
+        if (HP)
+          asm volatile("" : "+v"(Fi[0][0]), "+v"(Fi[0][1]), "+v"(Fi[0][2]), "+v"(Fi[0][3]), "+v"(Fi[1][0]), "+v"(Fi[1][1]),
+                       "+v"(Fi[1][2]), "+v"(Fi[1][3]), "+v"(Fp[0][0]), "+v"(Fp[0][1]), "+v"(Fp[0][2]), "+v"(Fp[0][3]),
+                       "+v"(Fp[1][0]), "+v"(Fp[1][1]), "+v"(Fp[1][2]), "+v"(Fp[1][3]), "+v"(o_in), "+v"(o_pn));
+        else
+          asm volatile("" : "+v"(Fi[0][0]), "+v"(Fi[0][1]), "+v"(Fi[0][2]), "+v"(Fi[0][3]), "+v"(Fi[1][0]), "+v"(Fi[1][1]),
+                       "+v"(Fi[1][2]), "+v"(Fi[1][3]), "+v"(o_in));
         __builtin_amdgcn_sched_barrier(0);
-        nlk_f4 Yi[4], Yp[4];
+        row_read(o_in, chn, Ri);
+        if (HP) row_read(o_pn, chn, Rp);
+        __builtin_amdgcn_sched_barrier(0);
+        slot_offs(wrap ? 1 : b + 2, oin, opn);
+        nlk_f4 Yi[2], Yp[2];
         if (b == 0) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) Yi[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
-          NLK_SEP_FWD(F, Yi);
-          if (sp == 0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) reinterpret_cast<nlk_f4*>(x0buf + 16 * si)[q] = -Yi[q];
-          }
-          // (lanes reading what OTHER lanes have just written: without the fences the compiler, reasoning per thread,
-          // moved the reads of the lanes that do not write in front of the writes)
-          nlk_wave_lds_order();
-#pragma unroll
-          for (int q = 0; q < 4; ++q) Yi[q] += x0v[q];
+          Yi[0] = Yi[1] = nlk_f4{0.f, 0.f, 0.f, 0.f};
+          fwd_half(Fi, Yi);
+          if (hp == 0) { x0w[0] = -Yi[0]; x0w[1] = -Yi[1]; }
+          nlk_wave_lds_order();  // (lanes reading what other lanes have just written)
+          Yi[0] += x0v[0]; Yi[1] += x0v[1];
         } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) Yi[q] = NLK_X0V(q);
-          NLK_SEP_FWD(F, Yi);
+          Yi[0] = x0v[0]; Yi[1] = x0v[1];
+          fwd_half(Fi, Yi);
         }
         if (HP) {
-          nlk_fold(R, F);
-          NLK_PIN_FOLD(F, o_img_next);
-          __builtin_amdgcn_sched_barrier(0);
-          rows_read(o_img_next, chn, R);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) Yp[q] = NLK_X0V(q);
-          NLK_SEP_FWD(F, Yp);
+          Yp[0] = x0v[0]; Yp[1] = x0v[1];
+          fwd_half(Fp, Yp);
         }
-        oi = o_img_next;
-        op = wrap ? op0 : opn;
-        slot_offs(wrap ? 1 : b + 2, oin, opn);
-#ifdef NLK_DBG_NOSTAT
-        if (true) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) S[0][q][j] += HP ? Yi[q][j] + Yp[q][j] : Yi[q][j];
-        } else
-#endif
         if constexpr (HP) {
-          // the 16 candidates of the batch: valid previous patch / group membership, one bit per lane quad
-          const uint64_t vw = b < 4 ? vbits[0] : vbits[1], gw = b < 4 ? gbits[0] : gbits[1];
-          const uint32_t vch = (uint32_t)(vw >> (16 * (b & 3))) & 0xffffu, gch = (uint32_t)(gw >> (16 * (b & 3))) & 0xffffu;
+          // the 8 candidates of the batch: valid previous patch / group membership, one bit per lane quad of a half
+          const uint64_t vw = b < 8 ? vbits[0] : vbits[1], gw = b < 8 ? gbits[0] : gbits[1];
+          const uint32_t vch = (uint32_t)(vw >> (8 * (b & 7))) & 0xffu, gch = (uint32_t)(gw >> (8 * (b & 7))) & 0xffu;
           if constexpr (MODE == 1) {
             const bool mixed = (vch & ~gch) != 0u;  // (wave-uniform) valid candidates that are not members
-            const float mkc = (float)((~gch >> sp) & 1u);
+            const float mkc = (float)((~gch >> hp) & 1u);
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 const float di = Yi[q][j], d = Yp[q][j];
@@ -767,14 +791,14 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
               }
             if (mixed) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q)
+              for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) S[NS > 3 ? 3 : 0][q][j] = fmaf(mkc, Yp[q][j], S[NS > 3 ? 3 : 0][q][j]);
             }
           } else {
-            const float mk = (float)((vch >> sp) & 1u);
+            const float mk = (float)((vch >> hp) & 1u);
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 const float di = Yi[q][j], d = Yp[q][j];
@@ -788,7 +812,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
           }
         } else {
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
+          for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               S[0][q][j] += Yi[q][j];
@@ -796,23 +820,16 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
             }
         }
         if (wrap) {
-          // The channel is complete. Per statistic 16 registers (q, a) x 16 lane quads: the quadrant goes to the lane
-          // group (v_permlane32_swap + add over qr, v_permlane16_swap + add over qc: 16 -> 8 -> 4 registers), the
-          // two remaining lane bits are summed with row rotations, and every lane keeps the register a = its bits 2..3.
+          // The channel is complete. Per statistic 8 registers (qc, a) x 8 lane quads per half: the horizontal parity
+          // goes to lane bit 4 (v_permlane16_swap + add: 8 -> 4 registers; the vertical parity IS the half), lane bits
+          // 2..3 are summed with row rotations, and every lane keeps the register a = its bits 2..3.
           float T[NS];
 #pragma unroll
           for (int a = 0; a < NS; ++a) {
-            float X[2][4], Z[4];
-#pragma unroll
-            for (int qc = 0; qc < 2; ++qc)
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(S[a][qc][j]), __float_as_uint(S[a][2 + qc][j]), false, false);
-                X[qc][j] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
-              }
+            float Z[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const auto z = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[0][j]), __float_as_uint(X[1][j]), false, false);
+              const auto z = __builtin_amdgcn_permlane16_swap(__float_as_uint(S[a][0][j]), __float_as_uint(S[a][1][j]), false, false);
               Z[j] = __uint_as_float(z[0]) + __uint_as_float(z[1]);
               Z[j] += nlk_dpp<NLK_DPP_ROR8>(Z[j]);
               Z[j] += nlk_dpp<0x124 /* row_ror:4 */>(Z[j]);
@@ -820,61 +837,17 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
             const float z01 = (spl & 1) ? Z[1] : Z[0], z23 = (spl & 1) ? Z[3] : Z[2];
             T[a] = (spl & 2) ? z23 : z01;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
               for (int j = 0; j < 4; ++j) S[a][q][j] = 0.f;
           }
-          // ---- gain of coefficient (quadrant g4, a = spl, horizontal index si) (reference: :799-811, :859-904;
-          // smoother :1683-1776)
-          {
-            const float nx0q = x0buf[16 * si + 4 * g4 + spl];
-            // (where pass B reads the gains: separable [horizontal index][quadrant][vertical index], Kronecker
-            // [quadrant][coefficient])
-            const int cidx = SEPB ? 16 * si + 4 * g4 + spl : 16 * g4 + 4 * spl + si;
-            float a, term, m;
-            if (MODE == 2) {
-              const float v1 = (T[1] - T[0] * T[0] * in1) * in1;  // image variance
-              const float v0 = (T[NS > 3 ? 3 : 0] - T[NS > 2 ? 2 : 0] * T[NS > 2 ? 2 : 0] * in0) * in0;  // previous-frame variance
-              const float v01n = T[NS > 4 ? 4 : 0] * in0;
-              a = v1 * __builtin_amdgcn_rcpf(v1 + g.beta_t * v01n);
-              const float pv = v0 - g.beta_t * v01n;
-              term = (1 - a * a) * v1 + a * a * (pv > 0.f ? pv : 0.f);
-              m = 0.f;
-            } else if (MODE == 1) {
-              const float v0 = (T[1] - T[0] * T[0] * in0) * in0;
-              const float v01n = T[NS > 2 ? 2 : 0] * in0;
-              const float d = v01n - (g.have_basic ? 0.f : s2);
-              const float v = v0 + (0.f > d ? 0.f : d);
-              a = v * __builtin_amdgcn_rcpf(v + g.beta_t * s2);
-              term = (1 - a * a) * v + a * a * s2;
-              m = (T[0] - T[NS > 3 ? 3 : 0]) * ing - nx0q;
-            } else {
-              const float v1 = (T[1] - T[0] * T[0] * in1) * in1;
-              const float d = v1 - (g.have_basic ? 0.f : s2);
-              const float v = 0.f > d ? 0.f : d;
-              a = v * __builtin_amdgcn_rcpf(v + g.beta_x * s2);
-              term = a * v;
-              m = T[0] * in1 - nx0q;
-            }
-#ifdef NLK_DBG_PRINT
-            if ((int)t == NLK_DBG_PRINT && ch == 0) printf("SEP t %d q %d a %d j %d T0 %g T1 %g gain %g mean %g nx0 %g\n", (int)t, g4, spl, si, T[0], T[1], a, (1 - a) * m, nx0q);
-#endif
-#ifdef NLK_DBG_IDENT
-            a = 1.f; m = 0.f; term = 1.f;
-#endif
-            part_sum += term;
-            // parked in LDS for pass B: [channel][gain | (1-a)*mean][si][quadrant][a]
-            stash[ch * SST + cidx] = a;
-            stash[ch * SST + 64 + cidx] = (1 - a) * m;
-          }
+          sep_gain(mode_tag, T, ch);
         }
       }
     };
-#ifndef NLK_DBG_NOA
     if (np0 == 0) pass_a(std::integral_constant<int, 0>{});
     else if (!SMO) pass_a(std::integral_constant<int, 1>{});
     else pass_a(std::integral_constant<int, 2>{});
-#endif
     }
 
     nlk_wave_lds_order();  // (the gains were parked by other lanes)
@@ -922,9 +895,6 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     const float* st_g = stash + bst * SST + (SEPB ? 16 * si : 4 * g4);
     const float* st_m = st_g + 64;
     constexpr int QST = SEPB ? 4 : 16;
-#ifdef NLK_DBG_NOB
-    if (g.w < 0)
-#endif
     for (int n0 = 0; n0 < nagg; n0 += 4) {
       nlk_f4 Y[4];
       if (SMO) {
@@ -945,8 +915,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       offn = member_off(n0 + 8);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (SEPB) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Y[q] = nlk_sep_fwd(F[q], sE[q & 1], sE[q >> 1], Y[q]);
+        nlk_sep_fwd4(F, sE, Y);
       } else {
         nlk_mfma_fwd<true>(F, dA, Y);
       }
@@ -967,8 +936,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       float PX[4][4];
       if constexpr (SEPB) {
         nlk_f4 X[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) X[q] = nlk_sep_inv(Y[q], sG[q >> 1], sG[q & 1]);
+        nlk_sep_inv4(Y, sG, X);
         // unfold: rows si (O[0]) and 7 - si (O[1]) of the slot's patch, 8 columns each
         float O[2][8];
 #pragma unroll
@@ -1067,9 +1035,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
 
   // ---------------- flush the tile accumulator
   __syncthreads();
-#ifdef NLK_DBG_NOFLUSH
-  if (g.w > 0) return;
-#endif
+
   if (tl.slab) {
     // deterministic mode (k_gather.h): the planes as they stand, into this tile's slab
     if (lane == 0) {

@@ -15,8 +15,13 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
   // register/DPP kernel (k_group8.h) for comparison
   const bool mfma = !nlk_set(c->sw.group_dpp);
   // the matrix-core kernel's DCTs: the Kronecker form on 16 x 16 products (rounds 2-4) or the separable form on
-  // 4 x 4 blocks (round 5), by pass - NLK_GROUP_SEP bit 0: pass A (statistics), bit 1: pass B (filter, invert, aggregate)
-  const int sep = mfma ? (nlk_or(c->sw.group_sep, 2) & 3) : 0;
+  // 4 x 4 blocks (round 5), by pass - NLK_GROUP_SEP = 0: Kronecker in both passes, 2 (default): Kronecker statistics,
+  // separable filter / inverse / aggregate (pass B), 6: separable in both (measured slower: profiles/README.md)
+  // Default by what was measured at 1080p RGB (profiles/r05_mode_times_1080p.txt, group kernel, Kronecker -> hybrid):
+  // FLT1 temporal 0.796 -> 0.740 ms, FLT1 spatial 1.043 -> 0.978; FLT2 (one member per group) 0.612 -> 0.628 and the
+  // smoother 1.281 -> 1.322 stay with the Kronecker form.
+  int sep = mfma ? nlk_or(c->sw.group_sep, (g.smoother || g.ntagg < 4) ? 0 : 2) : 0;
+  if (sep != 0 && sep != 6) sep = 2;
   // (k_group8m addresses every patch as planes base + a 32-bit byte offset: the call's images must lie in the
   // context's slab and the slab be smaller than 4 GiB - ~119 Mpixel of RGB; beyond that the packed-lane kernel)
   if (mfma) {
@@ -132,16 +137,13 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
 #ifndef NLK_G8_LDS_PAD
 #define NLK_G8_LDS_PAD 0  // (experiments: bytes of unused LDS per workgroup, to cut the occupancy)
 #endif
-    const size_t stash_by_sep[4] = {nlk_g8_stash_floats<CH, 0>(), nlk_g8_stash_floats<CH, 1>(), nlk_g8_stash_floats<CH, 2>(),
-                                    nlk_g8_stash_floats<CH, 3>()};
-    const size_t stash = mfma ? stash_by_sep[sep] : 0;
+    const size_t stash = !mfma ? 0 : sep == 0 ? nlk_g8_stash_floats<CH, 0>() : sep == 2 ? nlk_g8_stash_floats<CH, 2>() : nlk_g8_stash_floats<CH, 6>();
     const size_t lds = sizeof(float) * ((size_t)(CH + 1) * tl.plane + stash) + NLK_G8_LDS_PAD;
     if (lds > 160 * 1024) return fail(c, NLK_EUNSUP, "aggregation tile needs %zu bytes of LDS", lds);
     void (*kern)(const float*, const float*, const float*, const uint8_t*, NlkGeom, NlkGTile,
                  const uint32_t*, const NlkTarget*, const uint32_t*, const uint8_t*, const float*,
                  const float*, float*);
-    kern = !mfma ? k_group8<CH, SMO>
-           : sep == 0 ? k_group8m<CH, SMO, 0> : sep == 1 ? k_group8m<CH, SMO, 1> : sep == 2 ? k_group8m<CH, SMO, 2> : k_group8m<CH, SMO, 3>;
+    kern = !mfma ? k_group8<CH, SMO> : sep == 0 ? k_group8m<CH, SMO, 0> : sep == 2 ? k_group8m<CH, SMO, 2> : k_group8m<CH, SMO, 6>;
     HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
     const float* basis = (const float*)c->tabs.p;

@@ -24,7 +24,7 @@ for name in (sys.argv[1:] or list(cases.CASES)):
     if cases.CASES[name][4].get("patch_sz", 8) != 8:
         continue
     ref = run(0, lambda: cases.run_chain(B, name))
-    for sep in (1, 2, 3):
+    for sep in (2, 6):
         got = run(sep, lambda: cases.run_chain_stagewise(B, ref, name))
         worst = 0.0
         for k in ("f1_0", "f2_0", "f1_1", "f2_1", "s1_0"):
