@@ -259,6 +259,29 @@ def max_threads():
     return lib().nlko_max_threads()
 
 
+RELEASE_FLAGS = "-O3 -ffast-math -fno-finite-math-only -fopenmp"   # = oracle/Makefile RELEASE_FLAGS
+STRICT_FLAGS = "-O2 -ffp-contract=off -fno-fast-math -fopenmp"      # = oracle/Makefile CFLAGS
+
+
+def release_filter_frame():
+    """nlko_filter_frame of the build with the reference's release flags (oracle/Makefile:
+    libnlk_oracle_release.so) - timed by bench.py's cpu_baseline leg, never used as a checker."""
+    so = os.path.join(_HERE, "libnlk_oracle_release.so")
+    src = [os.path.join(_HERE, f) for f in ("nlk_oracle.c", "nlk_oracle.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "libnlk_oracle_release.so"], stdout=subprocess.DEVNULL)
+    L = C.CDLL(so)
+    fp = C.POINTER(C.c_float)
+    L.nlko_filter_frame.argtypes = [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float,
+                                    C.POINTER(Params), C.c_int, C.POINTER(Trace)]
+    return L.nlko_filter_frame
+
+
+def filter_frame_with(fn, nisy1, deno0, bsic1, sigma, params, nthreads=1):
+    """filter_frame through another build's entry point (release_filter_frame())."""
+    return _run(fn, nisy1, deno0, bsic1, sigma, params, nthreads, False)
+
+
 # ---- dual TV-L1 optical flow (tvl1_oracle.c; reference: lib/tvl1flow/)
 TVL1_DEFAULTS = dict(tau=0.25, lam=0.15, theta=0.3, nscales=100, fscale=0, zfactor=0.5,
                      nwarps=5, epsilon=0.01)  # reference: lib/tvl1flow/main.c:26-35

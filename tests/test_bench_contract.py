@@ -88,11 +88,17 @@ def test_default_bench_line():
     assert ro["traffic"] is None or ro["traffic"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    # what was timed says so itself: compiler flags, the DCT, the CPU, threads; both builds of the
+    # port, one warm-up + a median each; value = the faster build
+    assert cb["flags"] and cb["dct"].startswith("table") and cb["cpu"] and cb["threads"] == cb["cores"]
+    assert set(cb["builds"]) == {"strict", "release"} and "-ffast-math" in cb["builds"]["release"]["flags"]
+    assert cb["value"] == max(b["mpix_s"] for b in cb["builds"].values())
+    assert all(b["frames_timed"] >= 1 and b["median_s"] >= b["min_s"] > 0 for b in cb["builds"].values())
     assert abs(d["psnr_delta_db"]) <= 0.02       # BASELINE.json's quality bar, on the bench frame itself
     assert d["value"] > 30 * cb["value"]          # north_star: >= 30x the CPU path on the same box
     # beside the resident call: the first frame of a sequence and the host-pointer API - never `value`
     assert d["first_frame_ms"] > d["ms_per_step"] and d["api_wall_ms"] > d["ms_per_step"]
-    assert 0 < ro["valu"]["frac"] < 1
+    assert 0 < ro["valu"]["frac"] < 1 and ro["valu"]["peak"] == ro["peak"]   # one FP32 datapath: one peak
 
 
 @pytest.mark.gpu
