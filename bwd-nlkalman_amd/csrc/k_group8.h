@@ -66,6 +66,8 @@ struct NlkGTile {
   // generation-tagged words; every workgroup polls the words of its own targets instead of reading `active`.
   // The launch's own first grid row is row chase_row0 of that grid (0 for a whole-frame call, a strip's first row).
   int chase;                     // 0, or the reach (1..3) of the grid whose replay this launch runs
+  int chase_test_skip0;          // test hook (NLK_CHASE_TEST_SKIP0=1): workgroup 0 does NOT replay - every workgroup
+                                 // must get its decisions by replaying the rows it needs itself
   int chase_row0, chase_rows;
   const uint32_t* chase_gen;     // the generation of this launch: a device word the bit-plane kernel has just advanced
                                  // (a kernel argument would be frozen into a captured HIP graph)

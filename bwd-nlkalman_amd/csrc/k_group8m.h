@@ -225,18 +225,21 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   // of NLK_G8_CW x NLK_G8_CH tiles, dealt round-robin to the XCDs, each worked through by one XCD.
   uint32_t chase_gen = 0;
   if (tl.chase) chase_gen = *tl.chase_gen;  // (advanced by the bit-plane kernel in front of this launch)
-  if (tl.chase && blockIdx.x == 0) {
-    // the launch's first workgroup replays the processed mask of the grid rows down to the launch's last one before
-    // its own tile (k_commit_rows.h); every workgroup, this one included, then waits for the decision words of its
-    // targets below
+  // the replay of the grid rows [0, nrows) from the bit planes, decisions published as tagged words (k_commit_rows.h)
+  auto chase_replay = [&](int nrows) {
     __builtin_amdgcn_s_setprio(3);
     if (tl.chase == 1)
-      nlk_commit_rows1<8, true>(tl.chase_planes, nullptr, nullptr, tl.chase_words, chase_gen, g.ngx, 0, tl.chase_rows, lane);
+      nlk_commit_rows1<8, true>(tl.chase_planes, nullptr, nullptr, tl.chase_words, chase_gen, g.ngx, 0, nrows, lane);
     else if (tl.chase == 2)
-      nlk_commit_rows<2, true>(tl.chase_planes, nullptr, nullptr, tl.chase_words, chase_gen, g.ngx, 0, tl.chase_rows, lane);
+      nlk_commit_rows<2, true>(tl.chase_planes, nullptr, nullptr, tl.chase_words, chase_gen, g.ngx, 0, nrows, lane);
     else
-      nlk_commit_rows<3, true>(tl.chase_planes, nullptr, nullptr, tl.chase_words, chase_gen, g.ngx, 0, tl.chase_rows, lane);
+      nlk_commit_rows<3, true>(tl.chase_planes, nullptr, nullptr, tl.chase_words, chase_gen, g.ngx, 0, nrows, lane);
     __builtin_amdgcn_s_setprio(0);
+  };
+  if (tl.chase && blockIdx.x == 0 && !tl.chase_test_skip0) {
+    // the launch's first workgroup replays the processed mask of the grid rows down to the launch's last one before
+    // its own tile; every workgroup, this one included, then waits for the decision words of its targets below
+    chase_replay(tl.chase_rows);
   }
   int tile_x, tile_y, gx0, gy0, cx, cy;
   if ((int)blockIdx.x < tl.nmain) {
@@ -270,7 +273,10 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   const int rw = rx1 - rx0, rh = ry1 - ry0;
   const int rwp = tl.rwp, plane = tl.plane;
   // the tile's target records (requested first: they arrive while the tile is cleared)
-  int rec_act = 0, rec_nsel = 0, rec_nagg = 0;
+  int rec_act = 0, rec_nsel = 0, rec_nagg = 0, chase_bit = 0;
+  const uint64_t* chase_wp = tl.chase_words;
+  uint64_t chase_v = 0;
+  bool chase_late = false;
   uint32_t rec_vb[4] = {0u, 0u, 0u, 0u};
   if (lane < cx * cy) {
     const int ty = lane / cx, tx = lane - ty * cx;
@@ -278,15 +284,18 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     if (tl.chase) {
       // decisions arrive as generation-tagged words (indivisible 64-bit stores / loads at agent scope: no fence, no
       // stale line of another XCD's L2). The replay runs ~30x faster than the launch walks through the grid rows:
-      // only the first wave of workgroups ever waits. A launch whose replay never publishes traps instead of hanging.
-      const uint64_t* wp = tl.chase_words + (size_t)(tl.chase_row0 + gy0 + ty) * 64 + ((gx0 + tx) >> 5);
-      uint64_t v = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int spin = 0; (uint32_t)(v >> 32) != chase_gen; ++spin) {
-        if (spin > (1 << 22)) __builtin_trap();
+      // only the first wave of workgroups ever waits - a few microseconds. HIP promises nothing about the order
+      // workgroups are dispatched in, so a workgroup that has waited ~80 us (three times what the whole replay
+      // takes) stops waiting for workgroup 0 and replays the rows it needs itself, below: the same words with the
+      // same generation, idempotent, and whoever else is waiting for them sees them too.
+      chase_wp = tl.chase_words + (size_t)(tl.chase_row0 + gy0 + ty) * 64 + ((gx0 + tx) >> 5);
+      chase_v = __hip_atomic_load(chase_wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int spin = 0; (uint32_t)(chase_v >> 32) != chase_gen && spin < 64; ++spin) {
         __builtin_amdgcn_s_sleep(16);
-        v = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        chase_v = __hip_atomic_load(chase_wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      rec_act = ((uint32_t)v >> ((gx0 + tx) & 31)) & 1u;
+      chase_late = (uint32_t)(chase_v >> 32) != chase_gen;
+      chase_bit = (gx0 + tx) & 31;
     } else {
       rec_act = active[t];
     }
@@ -294,6 +303,13 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     rec_nsel = info.nsel; rec_nagg = info.nagg;
     rec_vb[0] = (uint32_t)info.vbits[0]; rec_vb[1] = (uint32_t)(info.vbits[0] >> 32);
     rec_vb[2] = (uint32_t)info.vbits[1]; rec_vb[3] = (uint32_t)(info.vbits[1] >> 32);
+  }
+  if (tl.chase) {
+    if (__ballot(chase_late)) {  // (wave-uniform) self-rescue: the rows down to this tile's last one
+      chase_replay(tl.chase_row0 + gy0 + cy);
+      if (lane < cx * cy) chase_v = __hip_atomic_load(chase_wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane < cx * cy) rec_act = ((uint32_t)chase_v >> chase_bit) & 1u;
   }
   if (tl.split) {  // (the two launches of deterministic mode: most tiles of the far one have nothing to do)
     const bool work = rec_act && rec_nagg != 0 &&

@@ -48,7 +48,7 @@ struct NlkRecView {
   X(group_dpp, "NLK_GROUP_DPP") X(group_sep, "NLK_GROUP_SEP") X(generic_match, "NLK_GENERIC_MATCH") X(mtx, "NLK_MTX") X(mty, "NLK_MTY")    \
   X(match_wg8, "NLK_MATCH_WG8") X(match_bx2, "NLK_MATCH_BX2") X(match_block, "NLK_MATCH_BLOCK")              \
   X(match_noblock, "NLK_MATCH_NOBLOCK") X(commit_wave, "NLK_COMMIT_WAVE") X(commit_lds, "NLK_COMMIT_LDS")    \
-  X(commit_band, "NLK_COMMIT_BAND") X(no_chase, "NLK_NO_CHASE") X(bands, "NLK_BANDS") X(host_bands, "NLK_HOST_BANDS")                    \
+  X(commit_band, "NLK_COMMIT_BAND") X(no_chase, "NLK_NO_CHASE") X(chase_test_skip0, "NLK_CHASE_TEST_SKIP0") X(bands, "NLK_BANDS") X(host_bands, "NLK_HOST_BANDS")                    \
   X(host_trace, "NLK_HOST_TRACE") X(gtx, "NLK_GTX") X(gty, "NLK_GTY") X(g8_tail, "NLK_G8_TAIL")              \
   X(g8_single, "NLK_G8_SINGLE") X(tv_wg_pixels, "NLK_TV_WG_PIXELS") X(tv_unblocked, "NLK_TV_UNBLOCKED")      \
   X(tv_batch, "NLK_TV_BATCH") X(tv_mid, "NLK_TV_MID") X(tv_shape, "NLK_TV_SHAPE") X(tv_deep, "NLK_TV_DEEP")  \

@@ -47,6 +47,7 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
     tl.split = split;
     tl.far = pass;
     tl.chase = c->rv.chase_words ? c->rv.chase_reach : 0;
+    tl.chase_test_skip0 = nlk_set(c->sw.chase_test_skip0);
     tl.chase_gen = c->rv.chase_gen;
     tl.chase_row0 = c->rv.chase_row0;
     tl.chase_rows = c->rv.chase_rows;

@@ -650,6 +650,70 @@ def test_mask_replay_inside_the_group_launch_equals_the_separate_kernels(ctx, bu
     monkeypatch.delenv("NLK_NO_CHASE", raising=False)
 
 
+def test_mask_replay_rescues_itself_when_workgroup_0_never_replays(ctx, built, synth, monkeypatch):
+    """The replay inside the group kernel's launch must not depend on the order workgroups are dispatched in (HIP
+    promises none): a workgroup whose decision words have not arrived after ~80 us replays the rows it needs itself -
+    the same words, the same generation. NLK_CHASE_TEST_SKIP0=1 makes workgroup 0 skip its replay, so EVERY workgroup
+    takes that path: same decisions as the separate kernels (which the full-size tests hold against the oracle),
+    small grids and 1080p, reach 1 (temporal) and reach 2 (first frame)."""
+    for w, h, ch, seed in [(96, 64, 3, 31), (1920, 1080, 3, 32)]:
+        sigma = 20.0
+        n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, seed)
+        o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+        p1 = built.default_params(sigma, built.FLT1)
+        monkeypatch.delenv("NLK_CHASE_TEST_SKIP0", raising=False)
+        monkeypatch.setenv("NLK_NO_CHASE", "1")
+        prev, r0 = _dev_frame(ctx, False, o0, None, None, sigma, p1)
+        fb, rb = _dev_frame(ctx, False, o1, prev, None, sigma, p1)
+        monkeypatch.delenv("NLK_NO_CHASE", raising=False)
+        monkeypatch.setenv("NLK_CHASE_TEST_SKIP0", "1")
+        f0, ra0 = _dev_frame(ctx, False, o0, None, None, sigma, p1)
+        fa, ra = _dev_frame(ctx, False, o1, prev, None, sigma, p1)
+        for f in ("active", "nsel", "np0", "nagg", "topk", "gcoords"):
+            assert np.array_equal(ra[f], rb[f]), (w, h, f)
+            assert np.array_equal(ra0[f], r0[f]), (w, h, f, "first frame")
+        assert 0.05 < 1 - ra["active"].mean() < 0.6
+        fa, _ = cases.excuse_flips(fa, fb, o1, f"self-rescued replay {w}x{h}", most=8)
+        cases.assert_close(fa, fb, f"self-rescued replay vs separate kernels {w}x{h}")
+        f0, _ = cases.excuse_flips(f0, prev, o0, f"self-rescued replay, first frame {w}x{h}", most=8)
+        cases.assert_close(f0, prev, f"self-rescued replay vs separate kernels, first frame {w}x{h}")
+    monkeypatch.delenv("NLK_CHASE_TEST_SKIP0", raising=False)
+
+
+def test_group_kernel_dct_forms_agree(ctx, built, synth, monkeypatch):
+    """k_group8m runs its DCTs in two forms: the Kronecker form on 16 x 16 x 4 matrix products and the separable
+    folded form on 4 x 4 blocks (v_mfma_f32_4x4x1_16B_f32), selectable by pass (NLK_GROUP_SEP: 0 Kronecker in both
+    passes, 2 separable pass B, 6 separable in both; the default picks by mode). Same records, same formulas,
+    different summation orders: all four frame calls agree to FP noise, one and three channels, NaN holes."""
+    for w, h, ch in [(320, 200, 3), (131, 97, 1)]:
+        sigma = 20.0
+        n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, 5)
+        o0, o1 = (built.rgb2opp(n0), built.rgb2opp(n1)) if ch == 3 else (n0, n1)
+        p1, p2, p3 = (built.default_params(sigma, m) for m in (built.FLT1, built.FLT2, built.SMO1))
+
+        def chain(ref=None):
+            f0, _ = _dev_frame(ctx, False, o0, None, None, sigma, p1)
+            f0i = f0 if ref is None else ref[0]
+            hole = f0i.copy()
+            hole[h // 5:h // 3, w // 3:w // 2] = np.nan                      # spatial-fallback targets
+            f1, _ = _dev_frame(ctx, False, o1, hole, None, sigma, p1)
+            f1i = f1 if ref is None else ref[1]
+            f2, _ = _dev_frame(ctx, False, o1, hole, f1i, sigma, p2)
+            f2i = f2 if ref is None else ref[2]
+            s0, _ = _dev_frame(ctx, True, f0i, f2i, None, sigma, p3)
+            return f0, f1, f2, s0
+
+        monkeypatch.setenv("NLK_GROUP_SEP", "0")
+        a = chain()
+        for sep in ("2", "6"):
+            monkeypatch.setenv("NLK_GROUP_SEP", sep)
+            b = chain(a)
+            for name, x, y in zip(("flt1 spatial", "flt1 temporal", "flt2", "smo1"), a, b):
+                assert np.isfinite(x).all() and np.isfinite(y).all()
+                cases.assert_close(y, x, f"group kernel NLK_GROUP_SEP={sep} vs Kronecker, {name}, {w}x{h}x{ch}")
+    monkeypatch.delenv("NLK_GROUP_SEP", raising=False)
+
+
 def test_group_kernels_agree_matrix_vs_dpp(ctx, built, synth, monkeypatch):
     """The 8x8 group kernel has two implementations: k_group8m (DCTs on the f32
     matrix cores, the default) and k_group8 (registers + DPP, NLK_GROUP_DPP=1).
