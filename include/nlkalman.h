@@ -17,6 +17,23 @@
 #ifndef NLKALMAN_H
 #define NLKALMAN_H
 
+/* The reference header also carries its build configuration as macros, and its tools test them
+ * (src/main-flt.c:43,59,87,102,181,200; src/main-smo.c:41,66,115: `#ifndef K_SIMILAR_PATCHES` selects
+ * between the k-nearest-patches fields below and a `dista_th` field): a program written against the
+ * reference header needs the same macros from this one. The configuration this library implements is
+ * the reference's as shipped (src/nlkalman.h:1-11): DECOUPLE_FILTER2, WEIGHTED_AGGREGATION and
+ * K_SIMILAR_PATCHES defined, LAMBDA_DISTANCE not. (Round 5: without them the reference's mains did NOT
+ * compile against this header - found by tests/test_host.py::test_reference_mains_link_against_the_drop_in_library.) */
+#ifndef DECOUPLE_FILTER2
+#define DECOUPLE_FILTER2
+#endif
+#ifndef WEIGHTED_AGGREGATION
+#define WEIGHTED_AGGREGATION
+#endif
+#ifndef K_SIMILAR_PATCHES
+#define K_SIMILAR_PATCHES
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif

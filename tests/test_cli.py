@@ -368,6 +368,48 @@ def test_two_frame_pipeline_files(tools, O, tmp_path, name):
         assert abs(cases.synth.psnr(got["f2_1"], clean) - cases.synth.psnr(g["f2_1"], clean)) <= 0.02
 
 
+@pytest.mark.gpu
+def test_reference_mains_on_top_of_the_library(tools, tmp_path):
+    """The reference's own main-flt.c / main-smo.c, compiled unmodified against include/nlkalman.h and linked against
+    libnlkalman.so in the build container (oracle/Makefile: _ref/refmain-*; tests/test_host.py links them), run the
+    script's call sequence on two frames beside this repo's own tools: the same files out up to the order of the frame
+    path's float atomics (both front ends hand the same arrays to the same library; PFM files - those binaries carry
+    iio without image libraries)."""
+    ref = {t: os.path.join(ROOT, "oracle", "_ref", "refmain-nlkalman-" + t) for t in ("flt", "smo")}
+    if not all(os.path.exists(x) for x in ref.values()):
+        pytest.skip("oracle/_ref/refmain-* not built (make -C oracle ref, in the build container)")
+    I = cases.inputs("rgb72x48_s40")
+    S = "%g" % I["sigma"]
+    wpfm(tmp_path / "n0.pfm", I["n0"])
+    wpfm(tmp_path / "n1.pfm", I["n1"])
+    wflo(tmp_path / "b.flo", I["flow"])
+    wflo(tmp_path / "f.flo", -I["flow"])
+    wpfm(tmp_path / "occ.pfm", I["occ"])
+
+    def seq(tag, flt, smo):
+        p = lambda f: str(tmp_path / f)          # noqa: E731
+        o = lambda f: str(tmp_path / (tag + f))  # noqa: E731
+        calls = [
+            (flt, ["-i", p("n0.pfm"), "-s", S, "--flt11", o("f1_0.pfm"), "--flt21", o("f2_0.pfm")], 0),
+            (flt, ["-i", p("n1.pfm"), "-s", S, "--f2_p", "0", "-o", p("b.flo"), "-k", p("occ.pfm"),
+                   "--flt10", o("f1_0.pfm"), "--flt11", o("f1_1.pfm")], 0),
+            (flt, ["-i", p("n1.pfm"), "-s", S, "--f1_p", "0", "-o", p("b.flo"), "-k", p("occ.pfm"),
+                   "--flt11", o("f1_1.pfm"), "--flt20", o("f2_0.pfm"), "--flt21", o("f2_1.pfm")], 0),
+            (smo, ["--flt1", o("f2_0.pfm"), "--smo0", o("f2_1.pfm"), "-o", p("f.flo"), "-k", p("occ.pfm"),
+                   "--smo1", o("s1_0.pfm"), "-s", S], None),   # (the reference's smoother returns 1 on success)
+        ]
+        for exe, args, rc in calls:
+            r = subprocess.run([exe, *args], capture_output=True, text=True)
+            assert (r.returncode == rc) if rc is not None else (r.returncode in (0, 1)), (exe, r.stderr)
+    seq("ours_", os.path.join(BIN, "nlkalman-flt"), os.path.join(BIN, "nlkalman-smo"))
+    seq("ref_", ref["flt"], ref["smo"])
+    for f in ("f1_0", "f2_0", "f1_1", "f2_1", "s1_0"):
+        a, b = rpfm(tmp_path / ("ours_" + f + ".pfm")), rpfm(tmp_path / ("ref_" + f + ".pfm"))
+        assert a.shape == b.shape and np.isfinite(a).all()
+        # (two runs of the frame path differ by the order of its float atomics: FP noise, not bytes)
+        cases.assert_close(a, b, "reference main vs this repo's tool, " + f)
+
+
 def test_hostile_image_files_are_rejected(tools, tmp_path):
     """LZW codes beyond the next free entry, stale-table cycles, short
     uncompressed strips, the floating-point predictor on integer samples and absurd header sizes must end in an
