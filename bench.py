@@ -327,32 +327,90 @@ def bench_sequence(args, pkg, synth, ctx, torch, rank, world, dev):
     emit(res)
 
 
-def launch_ranks(n):
+def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1
     --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a
     child process (the ranks are its children). This parent never touches the GPU (no torch import, no
     exec of a process that initialised HIP); it forwards rank 0's single JSON line and returns the
-    launcher's exit status, so a failed rank is a non-zero exit."""
+    launcher's exit status, so a failed rank is a non-zero exit.
+
+    The run cannot end without a line because a step HANGS (the C strip driver's neighbour send / recv has never
+    met a second device - DESIGN.md §6): the child runs under a time limit (NLK_BENCH_LAUNCH_TIMEOUT seconds;
+    default 300 + 120 for the CPU legs + 50 ms per step - a fresh box pages torch in for a minute or two); past
+    it, its whole process group is killed and a FRESH child is started with the Python strip driver
+    (--strip-driver py; never a process that has touched the GPU re-used or re-exec'ed), and the line says
+    which driver produced it and why (`launch`)."""
+    import signal
     import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    n = args.gpus
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    for l in r.stdout.splitlines():
-        if not l.startswith("{") and l.strip():
-            print(l, file=sys.stderr)                   # anything else a rank printed is not the line
-    if r.returncode == 0 and len(lines) != 1:
+    limit = float(os.environ.get("NLK_BENCH_LAUNCH_TIMEOUT",
+                                 300 + (0 if args.no_cpu else 120) + 0.05 * (args.steps + args.warmup)))
+
+    def run_once(extra):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT, start_new_session=True)
+        try:
+            out, _ = proc.communicate(timeout=limit)
+            return proc.returncode, out, False
+        except subprocess.TimeoutExpired:
+            # the launcher AND every rank: the ranks may sit in sessions of their own (a killpg of the launcher's
+            # group would leave them running, holding the pipe open), so the descendants are collected first
+            victims = []
+            try:
+                import psutil
+                victims = psutil.Process(proc.pid).children(recursive=True)
+            except Exception:                                                # noqa: BLE001
+                pass
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+            for v in victims:
+                try:
+                    v.kill()
+                except Exception:                                            # noqa: BLE001
+                    pass
+            try:
+                out, _ = proc.communicate(timeout=15)
+            except subprocess.TimeoutExpired:                                # (somebody still holds the pipe: give it up)
+                proc.kill()
+                out = ""
+            return -9, out or "", True
+
+    launch = {"strip_driver_requested": args.strip_driver, "time_limit_s": round(limit, 1)}
+    rc, out, timed_out = run_once([])
+    if timed_out and args.strip_driver == "c":
+        print(f"bench.py: the ranks did not finish within {limit:.0f} s with the C strip driver: killed; "
+              "starting fresh ranks with --strip-driver py", file=sys.stderr)
+        launch["fallback"] = "py"
+        launch["reason"] = f"the run with the C strip driver did not finish within {limit:.0f} s and was killed"
+        rc, out, timed_out = run_once(["--strip-driver", "py"])
+    if timed_out:
+        print(f"bench.py: the ranks did not finish within {limit:.0f} s: killed, no line", file=sys.stderr)
+        return 1
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    for ln in out.splitlines():
+        if not ln.startswith("{") and ln.strip():
+            print(ln, file=sys.stderr)                   # anything else a rank printed is not the line
+    if rc == 0 and len(lines) != 1:
         print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
         return 1
-    for l in lines:
-        print(l)
-    return r.returncode
+    for ln in lines:
+        try:
+            d = json.loads(ln)
+            d["launch"] = launch
+            ln = json.dumps(d)
+        except ValueError:
+            pass
+        print(ln)
+    return rc
 
 
 def main():
@@ -387,7 +445,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` by itself: start the N ranks as CHILD processes before this
         # process makes any GPU call (it never does), forward rank 0's line, exit with their status
-        raise SystemExit(launch_ranks(args.gpus))
+        raise SystemExit(launch_ranks(args))
 
     # The ONE JSON line goes out through a private copy of stdout; whatever else this process writes to file
     # descriptor 1 from here on - librccl prints a five-line version banner there when a communicator is made -
@@ -456,6 +514,12 @@ def main():
     t_out = torch.empty_like(t_n1)
 
     cs, c_driver_note = None, None
+    ctx_whole = ctx   # (the strip drivers below may hand `ctx` over to a strip's own context)
+    if args.strip_driver == "c" and (world > 1 or args.force_strips) and os.environ.get("NLK_STRIPS_TEST_HANG") == "1":
+        # test hook: a C strip driver whose first step never returns (tests/test_bench_contract.py: the launcher must
+        # kill the ranks and produce the line with the Python driver)
+        while True:
+            time.sleep(3600)
     if args.workload == "C5":
         if world != 1:
             raise SystemExit("workload C5 is single-GPU")
@@ -547,6 +611,50 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # Row-strip runs check themselves before anything is timed: every rank computes the WHOLE frame on its own GPU
+    # (one call, ~1 ms) and compares the rows one strip step gave it. Same decisions = same pixels up to the order
+    # of the float sums (2e-3 on the 0..255 scale); the pixels excused are exactly those that sit at the reference's
+    # `aggr > 1e-6` threshold and fell on the other side - one of the two outputs equals the input bit for bit
+    # in every channel (tests/cases.py: excuse_flips). A mismatch on any rank ends the run with a non-zero status.
+    selfcheck = None
+    if (world > 1 or args.force_strips) and args.workload != "C5":
+        t_full = torch.empty_like(t_n1)
+        ctx_whole.filter_frame(t_full.data_ptr(), t_n1.data_ptr(), t_prev.data_ptr(), None, w, h, ch, sigma, p)
+        one_step()
+        barrier()
+        if cs is not None:
+            y0, y1, rows_ptr, _ = cs.own_rows(0)
+            t_rows = torch.empty((y1 - y0, w, ch), dtype=torch.float32, device=dev)
+            ctx.d2d(t_rows.data_ptr(), rows_ptr, (y1 - y0) * w * ch * 4)
+            ctx.sync()
+        else:
+            y0, y1, t_rows = sf.own_rows()
+        torch.cuda.synchronize()
+        a, b, inp = t_rows, t_full[y0:y1], t_n1[y0:y1]
+        flipped = ((a == inp).all(dim=2) ^ (b == inp).all(dim=2))
+        diff = (a - b).abs().amax(dim=2)
+        diff = torch.where(flipped, torch.zeros_like(diff), diff)
+        diff = torch.nan_to_num(diff, nan=float("inf"))
+        st = torch.tensor([float(diff.max().item()) if diff.numel() else 0.0, float(flipped.sum().item())],
+                          dtype=torch.float64, device=dev)
+        if world > 1:
+            if one_gpu:
+                st = st.cpu()                      # (gloo)
+            mx = st[:1].clone()
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            sm = st[1:].clone()
+            dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+            st = torch.cat([mx, sm])
+        selfcheck = {"max_abs": round(float(st[0].item()), 6), "threshold_pixels_excused": int(st[1].item()),
+                     "tolerance": 2e-3, "what": "own rows of one strip step against the whole-frame call on the same GPU, every rank"}
+        if not st[0].item() <= 2e-3:
+            if rank == 0:
+                print(f"bench.py: strip self-check FAILED: max |strip step - whole-frame call| = {st[0].item():g} "
+                      f"(> 2e-3) on some rank's own rows: no line", file=sys.stderr)
+            if world > 1:
+                dist.destroy_process_group()
+            raise SystemExit(3)
 
     for _ in range(args.warmup):
         one_step()
@@ -769,6 +877,9 @@ def main():
                                   "ranks": model}
         if strip_info is not None:
             res["strip_step"] = strip_info
+        if selfcheck is not None:
+            res["strip_selfcheck_max_abs"] = selfcheck["max_abs"]
+            res["strip_selfcheck"] = selfcheck
         if phase_ms is not None:
             res["strip_phase_ms"] = phase_ms
         if one_gpu and world > 1:

@@ -71,6 +71,35 @@ def test_bench_two_and_eight_ranks_on_one_gpu(n):
     # threshold in the default atomic-order mode, so max-abs is reported, the PSNR bar asserted)
     assert abs(d["psnr_delta_db"]) <= 0.02 and d["max_abs_vs_cpu"] >= 0
     assert 0 < d["roofline"]["frac"] < 1
+    # the run checked itself before timing: every rank's own rows of a strip step against the whole-frame call
+    assert 0 <= d["strip_selfcheck_max_abs"] <= 2e-3 and d["strip_selfcheck"]["threshold_pixels_excused"] >= 0
+    assert d["launch"]["strip_driver_requested"] == "c" and "fallback" not in d["launch"]
+
+
+@pytest.mark.gpu
+def test_bench_survives_a_hanging_strip_driver():
+    """The first real `--gpus N` run is also the first execution of the C strip driver's neighbour send / recv
+    between two devices: if a step hangs, the launcher kills the ranks after its time limit and produces the line
+    with FRESH ranks on the Python strip driver, and the line says so. NLK_STRIPS_TEST_HANG=1
+    makes every rank that would use the C driver sleep forever instead."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=500,
+                       env=dict(env, NLK_BENCH_ONE_GPU="1", NLK_STRIPS_TEST_HANG="1", NLK_BENCH_LAUNCH_TIMEOUT="120"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["launch"]["fallback"] == "py" and "killed" in d["launch"]["reason"]
+    assert d["strip_step"]["driver"].startswith("Python") and 0 <= d["strip_selfcheck_max_abs"] <= 2e-3
+    assert "killed" in r.stderr
+
+
+@pytest.mark.gpu
+def test_strip_selfcheck_at_one_gpu():
+    """--force-strips at N = 1 runs the same self-check (the one strip is the frame)."""
+    d = _bench("--steps", "3", "--warmup", "1", "--no-cpu", "--no-extras", "--force-strips")
+    assert 0 <= d["strip_selfcheck_max_abs"] <= 2e-3
 
 
 @pytest.mark.gpu
