@@ -106,15 +106,16 @@ void cli_parse(const struct cli_option *opts, const char *prog, const char *desc
 #include <pthread.h>
 #include <time.h>
 
-struct nlk_ctx;
-struct nlk_ctx *nlkalman_hip_context(void); /* process-wide context of libnlkalman.so (exits on failure) */
+int nlkalman_hip_context_warm(void); /* libnlkalman.so: creates the process-wide context if it can; never exits */
 
 static pthread_t g_warm_thread;
 static int g_warm_started = 0;
 
+/* (a failure is not this thread's to report: the tool's own first use of the context tries again, prints and exits -
+ * one thread in exit(), after cli_warm_join()) */
 static void *warm_main(void *arg) {
   (void)arg;
-  (void)nlkalman_hip_context();
+  (void)nlkalman_hip_context_warm();
   return NULL;
 }
 
@@ -127,14 +128,21 @@ void cli_warm_join(void) {
   g_warm_started = 0;
 }
 
+static int g_trace_on = -1;
+static struct timespec g_trace_t0;
+
+void cli_trace_reset(void) { /* (resident server: a request's trace counts from the request, not from the server's start) */
+  if (g_trace_on > 0) clock_gettime(CLOCK_MONOTONIC, &g_trace_t0);
+}
+
 void cli_trace(const char *what) {
-  static int on = -1;
-  static struct timespec t0;
   struct timespec t;
-  if (on < 0) {
-    on = getenv("NLK_CLI_TRACE") != NULL;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
+  if (g_trace_on < 0) {
+    g_trace_on = getenv("NLK_CLI_TRACE") != NULL;
+    clock_gettime(CLOCK_MONOTONIC, &g_trace_t0);
   }
+  const int on = g_trace_on;
+  const struct timespec t0 = g_trace_t0;
   if (!on) return;
   clock_gettime(CLOCK_MONOTONIC, &t);
   fprintf(stderr, "[cli %8.2f ms] %s\n", (t.tv_sec - t0.tv_sec) * 1e3 + (t.tv_nsec - t0.tv_nsec) * 1e-6, what);

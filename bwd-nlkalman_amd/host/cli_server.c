@@ -1,3 +1,4 @@
+#define _GNU_SOURCE /* struct ucred, SO_PEERCRED, MSG_CMSG_CLOEXEC */
 /* cli_server.c — see cli_server.h. Wire format of a request, client -> server on a unix stream socket:
  *   [u32 payload bytes] with the client's stdout and stderr attached (SCM_RIGHTS), then the payload:
  *   "NLK1" 0, tool 0, working directory 0, argc (decimal) 0, argv[0] 0 ... argv[argc-1] 0
@@ -13,6 +14,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/socket.h>
+#include <sys/stat.h>
+#include <sys/time.h>
 #include <sys/un.h>
 #include <unistd.h>
 
@@ -23,19 +26,28 @@ static jmp_buf g_back;
 static int g_serving = 0;
 static volatile int g_status = 0;
 
+void cli_warm_join(void); /* cli_args.c */
+
 void cli_exit(int status) {
+  cli_warm_join(); /* nobody leaves - exit() and its handlers, or the jump back - while the warm-up thread is in hipInit */
   if (!g_serving) exit(status);
   g_status = status;
   longjmp(g_back, 1);
 }
 
-#define CLI_MAX_DEV 64
-static struct { struct nlk_ctx *c; void *p; } g_dev[CLI_MAX_DEV];
-static int g_ndev = 0;
+static struct cli_dev { struct nlk_ctx *c; void *p; } *g_dev = NULL;
+static int g_ndev = 0, g_dev_cap = 0;
 
 int cli_dev_alloc(struct nlk_ctx *c, void **p, size_t bytes) {
+  if (g_serving && g_ndev == g_dev_cap) { /* (an allocation that cannot be tracked is not made: it would never be released) */
+    const int cap = g_dev_cap ? 2 * g_dev_cap : 64;
+    struct cli_dev *t = (struct cli_dev *)realloc(g_dev, (size_t)cap * sizeof *t);
+    if (!t) return NLK_ENOMEM;
+    g_dev = t;
+    g_dev_cap = cap;
+  }
   const int rc = nlk_dev_alloc(c, p, bytes);
-  if (rc == NLK_OK && g_serving && g_ndev < CLI_MAX_DEV) {
+  if (rc == NLK_OK && g_serving) {
     g_dev[g_ndev].c = c;
     g_dev[g_ndev++].p = *p;
   }
@@ -51,6 +63,28 @@ int cli_dev_free(struct nlk_ctx *c, void *p) {
   return nlk_dev_free(c, p);
 }
 
+/* host buffers of a request (images read, staging): one release at the request's end, whichever way the tool left */
+static void **g_host = NULL;
+static int g_nhost = 0, g_host_cap = 0;
+
+void *cli_host_keep(void *p) {
+  if (!p) return NULL;
+  if (g_nhost == g_host_cap) {
+    const int cap = g_host_cap ? 2 * g_host_cap : 32;
+    void **t = (void **)realloc(g_host, (size_t)cap * sizeof *t);
+    if (!t) { free(p); return NULL; }
+    g_host = t;
+    g_host_cap = cap;
+  }
+  g_host[g_nhost++] = p;
+  return p;
+}
+
+void cli_host_release(void) {
+  for (int i = 0; i < g_nhost; ++i) free(g_host[i]);
+  g_nhost = 0;
+}
+
 void cli_dev_release(void) {
   for (int i = 0; i < g_ndev; ++i) {
     (void)nlk_sync(g_dev[i].c);
@@ -60,6 +94,9 @@ void cli_dev_release(void) {
 }
 
 /* ---- both ends of the socket */
+#define CLI_MAX_FDS 8               /* descriptors a request may carry before it is refused (2 are expected) */
+#define CLI_SERVER_IO_TIMEOUT_S 10  /* a connected client must send its request within this */
+#define CLI_CLIENT_IO_TIMEOUT_S 600 /* a client waits this long for the answer (a 4K frame call takes ~0.1 s) */
 static int write_all(int fd, const void *buf, size_t n) {
   const char *p = (const char *)buf;
   while (n) {
@@ -101,6 +138,12 @@ int cli_remote(const char *tool, int argc, const char **argv) {
   if (connect(s, (struct sockaddr *)&a, sizeof a)) {
     close(s);
     return -1; /* nobody listening: the caller does the work itself */
+  }
+  {
+    /* a request may take as long as a frame call does - but not for ever (a wedged server) */
+    const struct timeval tv = {CLI_CLIENT_IO_TIMEOUT_S, 0};
+    setsockopt(s, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+    setsockopt(s, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
   }
   char cwd[PATH_MAX];
   if (!getcwd(cwd, sizeof cwd)) strcpy(cwd, ".");
@@ -150,10 +193,25 @@ int cli_remote(const char *tool, int argc, const char **argv) {
 int cli_serve(const char *path, const struct cli_tool *tools) {
   struct sockaddr_un a;
   if (unix_address(path, &a)) return fprintf(stderr, "nlk-server: socket path too long\n"), 1;
+  /* a server already answering on this path keeps it (an unconditional unlink would silently take its socket over) */
+  {
+    const int probe = socket(AF_UNIX, SOCK_STREAM, 0);
+    if (probe >= 0) {
+      const int live = connect(probe, (struct sockaddr *)&a, sizeof a) == 0;
+      close(probe);
+      if (live) return fprintf(stderr, "nlk-server: another server is listening on %s\n", path), 1;
+    }
+  }
   const int ls = socket(AF_UNIX, SOCK_STREAM, 0);
   if (ls < 0) return perror("nlk-server: socket"), 1;
-  unlink(path);
-  if (bind(ls, (struct sockaddr *)&a, sizeof a) || listen(ls, 64)) return perror("nlk-server: bind / listen"), 1;
+  unlink(path); /* (a stale socket file nobody listens on) */
+  /* the socket belongs to this user alone: whoever can connect makes the server read and write image files under
+     its uid in a directory of the client's choosing. Mode 0600 from the start (umask around bind), and every
+     connection's peer must be this uid (SO_PEERCRED below). */
+  const mode_t um = umask(0177);
+  const int bound = bind(ls, (struct sockaddr *)&a, sizeof a);
+  umask(um);
+  if (bound || chmod(path, 0600) || listen(ls, 64)) return perror("nlk-server: bind / listen"), 1;
   signal(SIGPIPE, SIG_IGN);
   char home[PATH_MAX];
   if (!getcwd(home, sizeof home)) strcpy(home, "/");
@@ -165,24 +223,57 @@ int cli_serve(const char *path, const struct cli_tool *tools) {
       perror("nlk-server: accept");
       break;
     }
+    /* the requests are served one after the other: a client that connects and then says nothing must not hold
+       every pipeline step up for ever */
+    {
+      const struct timeval tv = {CLI_SERVER_IO_TIMEOUT_S, 0};
+      setsockopt(cs, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+      setsockopt(cs, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
+      struct ucred cr;
+      socklen_t crl = sizeof cr;
+      if (getsockopt(cs, SOL_SOCKET, SO_PEERCRED, &cr, &crl) || cr.uid != geteuid()) {
+        close(cs);
+        continue;
+      }
+    }
     /* length word + the client's stdout / stderr */
     uint32_t len = 0;
     struct msghdr m;
     struct iovec io = {&len, sizeof len};
-    union { char b[CMSG_SPACE(2 * sizeof(int))]; struct cmsghdr align; } ctl;
+    union { char b[CMSG_SPACE(CLI_MAX_FDS * sizeof(int))]; struct cmsghdr align; } ctl;
     memset(&m, 0, sizeof m);
     m.msg_iov = &io;
     m.msg_iovlen = 1;
     m.msg_control = ctl.b;
     m.msg_controllen = sizeof ctl.b;
     int fds[2] = {-1, -1};
-    if (recvmsg(cs, &m, MSG_WAITALL) != (ssize_t)sizeof len || len < 8 || len > (1u << 20)) {
+    const ssize_t got = recvmsg(cs, &m, MSG_WAITALL | MSG_CMSG_CLOEXEC);
+    /* every descriptor that arrived is ours to close: exactly two are expected; any other count, other control
+       messages' descriptors, or a truncated control buffer (more were sent than fit) end the request */
+    int nfd = 0, bad_fds = (m.msg_flags & MSG_CTRUNC) != 0;
+    int all[CLI_MAX_FDS];
+    if (got >= 0)
+      for (struct cmsghdr *cm = CMSG_FIRSTHDR(&m); cm; cm = CMSG_NXTHDR(&m, cm))
+        if (cm->cmsg_level == SOL_SOCKET && cm->cmsg_type == SCM_RIGHTS) {
+          const int k = (int)((cm->cmsg_len - CMSG_LEN(0)) / sizeof(int));
+          for (int i = 0; i < k; ++i) {
+            int fd;
+            memcpy(&fd, CMSG_DATA(cm) + i * sizeof(int), sizeof fd);
+            if (nfd < CLI_MAX_FDS) all[nfd++] = fd;
+            else { close(fd); bad_fds = 1; }
+          }
+        }
+    if (nfd == 2 && !bad_fds) { fds[0] = all[0]; fds[1] = all[1]; }
+    else {
+      for (int i = 0; i < nfd; ++i) close(all[i]);
+      if (nfd) bad_fds = 1;
+    }
+    if (got != (ssize_t)sizeof len || len < 8 || len > (1u << 20) || bad_fds) {
+      if (fds[0] >= 0) close(fds[0]);
+      if (fds[1] >= 0) close(fds[1]);
       close(cs);
       continue;
     }
-    for (struct cmsghdr *cm = CMSG_FIRSTHDR(&m); cm; cm = CMSG_NXTHDR(&m, cm))
-      if (cm->cmsg_level == SOL_SOCKET && cm->cmsg_type == SCM_RIGHTS && cm->cmsg_len >= CMSG_LEN(2 * sizeof(int)))
-        memcpy(fds, CMSG_DATA(cm), sizeof fds);
     char *buf = (char *)malloc((size_t)len + 1);
     if (!buf || read_all(cs, buf, len)) {
       free(buf);
@@ -238,6 +329,8 @@ int cli_serve(const char *path, const struct cli_tool *tools) {
         else status = g_status;
         g_serving = 0;
         cli_dev_release();
+        cli_host_release();
+        cli_trace_reset();
       }
       fflush(stdout);
       fflush(stderr);

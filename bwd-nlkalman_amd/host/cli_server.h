@@ -35,6 +35,12 @@ int cli_remote(const char *tool, int argc, const char **argv);
 int cli_serve(const char *path, const struct cli_tool *tools);
 /* exit(status) - or, inside the server, back to its loop with that status */
 void cli_exit(int status);
+/* host memory of a request: cli_host_keep(p) registers a malloc'ed buffer (returns p; NULL stays NULL) and
+ * cli_host_release() frees every registered one - the tools' wrappers and the server's loop call it, so that an
+ * early `return 1` or a cli_exit() from deep inside leaks nothing in a resident process */
+void *cli_host_keep(void *p);
+void cli_host_release(void);
+void cli_trace_reset(void); /* cli_args.c: the elapsed-time trace starts again with the next request */
 /* nlk_dev_alloc, remembered; cli_dev_release frees what the current request allocated (a one-shot process never
  * needs to) */
 int cli_dev_alloc(struct nlk_ctx *c, void **p, size_t bytes);

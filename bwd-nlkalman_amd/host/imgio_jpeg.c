@@ -411,6 +411,15 @@ float *nlk_read_jpeg(const char *path, const unsigned char *b, size_t n, int *w,
         if (hmax % C[c].hs || vmax % C[c].vs || hmax / C[c].hs > 4 || vmax / C[c].vs > 4)
           err = "JPEG sampling factors that do not divide each other are not supported";
       if (err) break;
+      /* the same bound as every other format (imgio.c: sane_size), and the file must be able to hold the image at
+         all: a 200-byte header that announces 65500 x 65500 must not make this process allocate 17 GB (inside
+         nlk-server that would take the resident process down). Even an all-zero baseline scan spends about a bit
+         per 8 x 8 block and component. */
+      if ((uint64_t)W * (uint64_t)H * (uint64_t)nc > ((uint64_t)1 << 31) ||
+          ((uint64_t)W * (uint64_t)H / 64) * (uint64_t)nc / 8 > (uint64_t)n + 1024) {
+        err = "JPEG size is unreasonable for the size of the file";
+        break;
+      }
       const int mcuw = 8 * hmax, mcuh = 8 * vmax;
       mx = (W + mcuw - 1) / mcuw;
       my = (H + mcuh - 1) / mcuh;
@@ -480,6 +489,7 @@ float *nlk_read_jpeg(const char *path, const unsigned char *b, size_t n, int *w,
           if (!(st.marker >= 0xD0 && st.marker <= 0xD7))
             while (st.p + 1 < st.end && !(st.p[0] == 0xFF && st.p[1] >= 0xD0 && st.p[1] <= 0xD7)) ++st.p;
           st.p += 2;
+          if (st.p > st.end) st.p = st.end;
           st.marker = 0;
           for (int k = 0; k < sc.ns; ++k) C[sc.ci[k]].pred = 0;
           eobrun = 0;

@@ -52,8 +52,19 @@ static float *to_dev(nlk_ctx *c, const float *h, size_t n) {
   return (float *)d;
 }
 
-/* the tool as a function: main() below, or the resident server (main_server.c) */
+static int tool_body(int argc, const char **argv);
+
+/* the tool as a function: main() below, or the resident server (main_server.c). Whichever way the body returns -
+ * there are a dozen early `return 1` in it, as in the reference's main - the warm-up thread is joined (nobody reaches
+ * exit() while it is inside hipInit) and the host images are released. */
 int nlk_tool_flt(int argc, const char **argv) {
+  const int rc = tool_body(argc, argv);
+  cli_warm_join();
+  cli_host_release();
+  return rc;
+}
+
+static int tool_body(int argc, const char **argv) {
   const char *noisy_path = NULL, *bflow_path = NULL, *boccl_path = NULL;
   const char *flt10_path = NULL, *flt20_path = NULL, *flt11_path = NULL, *flt21_path = NULL;
   float sigma = 0.f;
@@ -129,33 +140,33 @@ int nlk_tool_flt(int argc, const char **argv) {
 
   /* inputs (reference: src/main-flt.c:216-332; same messages) */
   int w, h, ch, w1, h1, c1;
-  float *nisy = img_read(noisy_path, &w, &h, &ch);
+  float *nisy = (float *)cli_host_keep(img_read(noisy_path, &w, &h, &ch));
   if (!nisy) return fprintf(stderr, "Error while openning bwd optical flow\n"), 1;
   float *bflo = NULL, *bocc = NULL, *flt10 = NULL, *flt20 = NULL, *flt11 = NULL;
   if (bflow_path) {
-    bflo = img_read(bflow_path, &w1, &h1, &c1);
+    bflo = (float *)cli_host_keep(img_read(bflow_path, &w1, &h1, &c1));
     if (!bflo) return fprintf(stderr, "Error while openning bwd optical flow\n"), 1;
     if (w * h != w1 * h1 || c1 != 2) return fprintf(stderr, "Frame and optical flow size missmatch\n"), 1;
   }
   if (bflow_path && boccl_path) {
-    bocc = img_read(boccl_path, &w1, &h1, &c1);
+    bocc = (float *)cli_host_keep(img_read(boccl_path, &w1, &h1, &c1));
     if (!bocc) return fprintf(stderr, "Error while openning occlusion mask\n"), 1;
     if (w * h != w1 * h1 || c1 != 1) return fprintf(stderr, "Frame and occlusion mask size missmatch\n"), 1;
   }
   if (flt10_path) {
-    flt10 = img_read(flt10_path, &w1, &h1, &c1);
+    flt10 = (float *)cli_host_keep(img_read(flt10_path, &w1, &h1, &c1));
     if (!flt10) fprintf(stderr, "Error while openning previous filter 1 output\n");
     if (flt10 && w * h * ch != w1 * h1 * c1)
       return fprintf(stderr, "Frame and previous filter 1 output size missmatch\n"), 1;
   }
   if (flt20_path) {
-    flt20 = img_read(flt20_path, &w1, &h1, &c1);
+    flt20 = (float *)cli_host_keep(img_read(flt20_path, &w1, &h1, &c1));
     if (!flt20) fprintf(stderr, "Error while openning previous filter 2 output\n");
     if (flt20 && w * h * ch != w1 * h1 * c1)
       return fprintf(stderr, "Frame and previous filter 2 output size missmatch\n"), 1;
   }
   if (!apply_filt1) {
-    flt11 = img_read(flt11_path, &w1, &h1, &c1);
+    flt11 = (float *)cli_host_keep(img_read(flt11_path, &w1, &h1, &c1));
     if (!flt11) return fprintf(stderr, "Error while openning filter 1 output\n"), 1;
     if (w * h * ch != w1 * h1 * c1) return fprintf(stderr, "Frame and filter 1 output size missmatch\n"), 1;
   }
@@ -189,7 +200,7 @@ int nlk_tool_flt(int argc, const char **argv) {
   }
 
   cli_trace("first iteration enqueued");
-  float *host = malloc(bytes);
+  float *host = (float *)cli_host_keep(malloc(bytes));
   if (apply_filt2) {
     const float *prev = d_f20;
     if (d_flo && d_f20) { /* d_warp is free again: FLT1 has consumed it in stream order */
@@ -210,7 +221,6 @@ int nlk_tool_flt(int argc, const char **argv) {
     if (img_write(flt11_path, host, w, h, ch)) return fprintf(stderr, "cannot write %s\n", flt11_path), 1;
   }
   cli_trace("outputs written");
-  free(host); free(nisy); free(bflo); free(bocc); free(flt10); free(flt20); free(flt11);
   return cli_leave(EXIT_SUCCESS);
 }
 

@@ -38,8 +38,19 @@ static float *to_dev(nlk_ctx *c, const float *h, size_t n) {
   return (float *)d;
 }
 
-/* the tool as a function: main() below, or the resident server (main_server.c) */
+static int tool_body(int argc, const char **argv);
+
+/* the tool as a function: main() below, or the resident server (main_server.c). Whichever way the body returns -
+ * there are a dozen early `return 1` in it, as in the reference's main - the warm-up thread is joined (nobody reaches
+ * exit() while it is inside hipInit) and the host images are released. */
 int nlk_tool_smo(int argc, const char **argv) {
+  const int rc = tool_body(argc, argv);
+  cli_warm_join();
+  cli_host_release();
+  return rc;
+}
+
+static int tool_body(int argc, const char **argv) {
   const char *flt1_path = NULL, *smo0_path = NULL, *fflo_path = NULL, *focc_path = NULL, *smo1_path = NULL;
   float sigma = 0.f;
   int verbose = 0;
@@ -82,19 +93,19 @@ int nlk_tool_smo(int argc, const char **argv) {
            s1.search_sz_t, s1.npatches_t, s1.npatches_tagg, s1.dista_lambda, s1.beta_t);
 
   int w, h, ch, w1, h1, c1;
-  float *flt1 = img_read(flt1_path, &w, &h, &ch);
+  float *flt1 = (float *)cli_host_keep(img_read(flt1_path, &w, &h, &ch));
   if (!flt1) return fprintf(stderr, "Opening %s failed\n", flt1_path), 1;
-  float *smo0 = img_read(smo0_path, &w1, &h1, &c1);
+  float *smo0 = (float *)cli_host_keep(img_read(smo0_path, &w1, &h1, &c1));
   if (!smo0) return fprintf(stderr, "Opening %s failed\n", smo0_path), 1;
   if (w * h * ch != w1 * h1 * c1) return fprintf(stderr, "Filtered frames size missmatch\n"), 1;
   float *fflo = NULL, *focc = NULL;
   if (fflo_path) {
-    fflo = img_read(fflo_path, &w1, &h1, &c1);
+    fflo = (float *)cli_host_keep(img_read(fflo_path, &w1, &h1, &c1));
     if (!fflo) return fprintf(stderr, "Opening %s failed\n", fflo_path), 1;
     if (w * h != w1 * h1 || c1 != 2) return fprintf(stderr, "Frame and optical flow size missmatch\n"), 1;
   }
   if (fflo_path && focc_path) {
-    focc = img_read(focc_path, &w1, &h1, &c1);
+    focc = (float *)cli_host_keep(img_read(focc_path, &w1, &h1, &c1));
     if (!focc) return fprintf(stderr, "Opening %s failed\n", focc_path), 1;
     if (w * h != w1 * h1 || c1 != 1) return fprintf(stderr, "Frame and occlusion mask size missmatch\n"), 1;
   }
@@ -116,10 +127,9 @@ int nlk_tool_smo(int argc, const char **argv) {
   }
   CHK(nlk_dev_smooth_frame(c, (float *)d_smo1, d_flt1, prev, NULL, w, h, ch, sigma, &s1));
   CHK(nlk_dev_opp2rgb(c, (float *)d_smo1, w, h, ch));
-  float *host = malloc(bytes);
+  float *host = (float *)cli_host_keep(malloc(bytes));
   CHK(nlk_d2h(c, host, d_smo1, bytes));
   if (img_write(smo1_path, host, w, h, ch)) return fprintf(stderr, "cannot write %s\n", smo1_path), 1;
-  free(host); free(flt1); free(smo0); free(fflo); free(focc);
   const char *e = getenv("NLK_SMO_REFERENCE_EXIT");
   return cli_leave((e && e[0] == '1') ? 1 : 0);
 }

@@ -25,7 +25,16 @@ static int fail_hip(const char *what, nlk_ctx *c) {
 }
 
 /* the tool as a function: main() below, or the resident server (main_server.c) */
+static int tool_body(int argc, const char **argv);
+
+/* (every way out of the body releases the host images: a resident process must not grow on failed requests) */
 int nlk_tool_tvl1(int argc, const char **argv) {
+  const int rc = tool_body(argc, argv);
+  cli_host_release();
+  return rc;
+}
+
+static int tool_body(int argc, const char **argv) {
   if (argc < 3) {
     fprintf(stderr, "Usage: %s I0 I1 [out "
                     "nproc tau lambda theta nscales fscale zfactor nwarps epsilon "
@@ -60,9 +69,9 @@ int nlk_tool_tvl1(int argc, const char **argv) {
   if (epsilon <= 0) { epsilon = D.epsilon; if (verbose) fprintf(stderr, "warning: epsilon changed to %f\n", epsilon); }
 
   int nx, ny, c0, nx2, ny2, c1;
-  float *I0 = img_read(image1_name, &nx, &ny, &c0);
+  float *I0 = (float *)cli_host_keep(img_read(image1_name, &nx, &ny, &c0));
   if (!I0) { fprintf(stderr, "ERROR: could not read image from file \"%s\"\n", image1_name); return EXIT_FAILURE; }
-  float *I1 = img_read(image2_name, &nx2, &ny2, &c1);
+  float *I1 = (float *)cli_host_keep(img_read(image2_name, &nx2, &ny2, &c1));
   if (!I1) { fprintf(stderr, "ERROR: could not read image from file \"%s\"\n", image2_name); return EXIT_FAILURE; }
   if (nx != nx2 || ny != ny2) {
     fprintf(stderr, "ERROR: input images size mismatch %dx%d != %dx%d\n", nx, ny, nx2, ny2);
@@ -94,14 +103,13 @@ int nlk_tool_tvl1(int argc, const char **argv) {
   int iters = 0;
   if (nlk_dev_tvl1_flow(c, (float *)d_flow, (float *)d_g0, (float *)d_g1, nx, ny, &P, &iters))
     return fail_hip("flow", c);
-  float *flow = (float *)malloc(2 * n * sizeof(float));
+  float *flow = (float *)cli_host_keep(malloc(2 * n * sizeof(float)));
   if (!flow || nlk_d2h(c, flow, d_flow, 2 * n * sizeof(float))) return fail_hip("download", c);
   if (verbose) fprintf(stderr, "Iterations: %d\n", iters);
   if (img_write(outfile, flow, nx, ny, 2)) {
     fprintf(stderr, "ERROR: could not write \"%s\"\n", outfile);
     return EXIT_FAILURE;
   }
-  free(I0); free(I1); free(flow);
   /* (device buffers: released with the process, or by the resident server after the request - cli_server.h) */
   return EXIT_SUCCESS;
 }

@@ -12,6 +12,7 @@
  * NLK_DEVICES=0,1,... splits the two frame functions over several devices (multidev.c).
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -39,18 +40,35 @@ static void die(const char *what, nlk_ctx *c) {
   exit(1);
 }
 
-static nlk_ctx *ctx(void) {
+/* The process-wide context is created once, under a lock: the command-line tools bring it up on a second thread while
+ * they read their inputs (cli_args.c: cli_warm_start), and the resident server may see a request's first call while
+ * that thread is still at it. `may_exit` = 0 (the warm-up thread): a failure is only recorded - the thread that needs
+ * the context tries again and is the ONE that prints and exits (two threads in exit() is undefined behaviour). */
+static pthread_mutex_t g_ctx_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static nlk_ctx *ctx_get(int may_exit) {
+  pthread_mutex_lock(&g_ctx_lock);
   if (!g_ctx) {
     /* NLK_DEVICE, else the first index of NLK_DEVICES (a list of one device, or a call the list cannot split), else 0 */
     const char *dev = getenv("NLK_DEVICE");
     const int first = nlk_multi_first_device();
-    if (nlk_ctx_create(&g_ctx, dev ? atoi(dev) : (first >= 0 ? first : 0)) != NLK_OK) die("cannot initialise the GPU", NULL);
+    if (nlk_ctx_create(&g_ctx, dev ? atoi(dev) : (first >= 0 ? first : 0)) != NLK_OK) {
+      g_ctx = NULL;
+      pthread_mutex_unlock(&g_ctx_lock);
+      if (may_exit) die("cannot initialise the GPU", NULL);
+      return NULL;
+    }
     atexit(ctx_atexit);
   }
-  return g_ctx;
+  nlk_ctx *c = g_ctx;
+  pthread_mutex_unlock(&g_ctx_lock);
+  return c;
 }
 
+static nlk_ctx *ctx(void) { return ctx_get(1); }
+
 nlk_ctx *nlkalman_hip_context(void) { return ctx(); } /* for the CLIs */
+int nlkalman_hip_context_warm(void) { return ctx_get(0) ? 0 : -1; } /* the CLIs' warm-up thread: never exits */
 
 /* Device buffers of the image helpers, kept between calls like the frame calls' (hipMalloc / hipFree
  * cost ~0.5 ms per call at 1080p). The API is not re-entrant, like the reference's (its FFTW plans are

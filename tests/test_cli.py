@@ -257,6 +257,27 @@ def test_tools_behind_the_resident_server_speak_the_same_grammar(tools, tmp_path
             c.close()
         r = run("nlkalman-flt", "-h", env=env)
         assert r.returncode == 0 and r.stdout.startswith("Usage: nlkalman-flt")
+        #  the socket is this user's alone; a second server does not take a live one's socket over; a client
+        # that connects and says nothing is dropped after the server's I/O timeout instead of holding every step up;
+        # descriptors beyond the two a request carries are closed, not leaked
+        import stat
+        import time
+        assert stat.S_IMODE(os.stat(env["NLK_SERVER"]).st_mode) == 0o600
+        r2 = subprocess.run([os.path.join(BIN, "nlk-server"), "--lazy", env["NLK_SERVER"]], capture_output=True, text=True, timeout=60)
+        assert r2.returncode != 0 and "another server is listening" in r2.stderr
+        mute = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        mute.connect(env["NLK_SERVER"])               # ... and nothing more
+        t0 = time.time()
+        r = run("nlkalman-flt", "-h", env=env)         # served once the mute client has timed out (10 s)
+        assert r.returncode == 0 and r.stdout.startswith("Usage: nlkalman-flt") and time.time() - t0 < 30
+        mute.close()
+        import array
+        fat = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        fat.connect(env["NLK_SERVER"])
+        fat.sendmsg([st.pack("<I", 12)], [(socket.SOL_SOCKET, socket.SCM_RIGHTS, array.array("i", [1, 2, 1, 2, 1]).tobytes())])
+        fat.close()
+        r = run("nlkalman-flt", "-h", env=env)
+        assert r.returncode == 0 and r.stdout.startswith("Usage: nlkalman-flt")
         r = run("nlkalman-flt", "-h", env=dict(env, NLK_SERVER=str(tmp_path / "nobody.sock")))
         assert r.returncode == 0 and r.stdout.startswith("Usage: nlkalman-flt")     # no listener: by itself
     r = subprocess.run([os.path.join(BIN, "nlk-server"), "--stop", str(tmp_path / "nlk.sock")], capture_output=True,
