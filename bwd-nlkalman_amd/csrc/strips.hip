@@ -330,13 +330,15 @@ int enqueue_step(nlk_strips* S) {
     if ((rc = tick(T, PH_N))) return rc;
     HIPCHK(T.c, hipEventRecord(T.ev_group, T.c->stream));
   }
-  // (nobody may overwrite a buffer a local neighbour still reads: the next step's first writes - the halo
-  // rows of `prev`, the packed accumulator rows - wait for the neighbours' step to be over)
+  // (nobody may overwrite a buffer another local strip still reads: the next step's first writes - the halo
+  // rows of `prev`, the packed accumulator rows, and the mark words of the strip's own rows, which EVERY other
+  // strip copies on its own stream (not only the neighbours: ADVICE r4) - wait for every local strip's step to be
+  // over; ev_group is recorded behind all of a strip's copies)
   if (!S->rccl && !S->dry && S->world > 1)
     for (Strip& T : S->s) {
       HIPCHK(T.c, hipSetDevice(T.device));
-      for (int r : {T.rank - 1, T.rank + 1})
-        if (Strip* N = local_of(S, r)) HIPCHK(T.c, hipStreamWaitEvent(T.c->stream, N->ev_group, 0));
+      for (Strip& N : S->s)
+        if (&N != &T) HIPCHK(T.c, hipStreamWaitEvent(T.c->stream, N.ev_group, 0));
     }
   return NLK_OK;
 }
