@@ -116,9 +116,9 @@ def kernel_sources_sha():
 def measured_traffic(workload, instance, largest_grid=False):
     """HBM-side bytes per launch of kernel `instance` (full template name, e.g. "k_bm_topk<8, 3, 2>": the
     instantiation this run timed) from the committed PMC passes (profiles/<tag>_traffic.json, made by
-    tools/profile_round.sh + tools/make_traffic.py; tag = NLK_TRAFFIC_TAG, default r04) - only while the
+    tools/profile_round.sh + tools/make_traffic.py; tag = NLK_TRAFFIC_TAG, default r05) - only while the
     kernel sources are still the ones the table was measured on; otherwise (None, why)."""
-    tag = os.environ.get("NLK_TRAFFIC_TAG", "r04")
+    tag = os.environ.get("NLK_TRAFFIC_TAG", "r05")
     tpath = os.path.join(ROOT, "profiles", f"{tag}_traffic.json")
     if not os.path.exists(tpath):
         return None, f"no PMC table profiles/{tag}_traffic.json committed"
@@ -774,7 +774,9 @@ def main():
         tfl = alg_flops[dom] / world / dur / 1e12 if dur > 0 else 0.0
         kname = ("k_group8m" if psz == 8 and ch in (1, 3) else "k_groupp") if dom == "group" else "k_bm_topk"
         # the instantiation the timed (temporal) frames launch: what the PMC table is looked up by
-        inst = ((f"k_group8m<{ch}, false>" if kname == "k_group8m" else f"k_groupp<{psz}, false>") if dom == "group"
+        # (k_group8m's third template argument: which pass runs the separable DCT form - tu_group8.hip; FLT1: 2)
+        g8sep = os.environ.get("NLK_GROUP_SEP", "2")
+        inst = ((f"k_group8m<{ch}, false, {g8sep}>" if kname == "k_group8m" else f"k_groupp<{psz}, false>") if dom == "group"
                 else f"k_bm_topk<{psz}, {ch}, {((2 * p.search_sz_t + 1) ** 2 + 63) // 64}>")
         # HBM-side bytes per launch: PMC passes of the same sources (see measured_traffic)
         traffic, traffic_note = (None, "single-GPU runs only") if world > 1 else measured_traffic(args.workload, inst)

@@ -17,7 +17,7 @@ done
 [ -f $SRC/api_wall.txt ] && cp $SRC/api_wall.txt profiles/${TAG}_api_wall.txt
 [ -f $SRC/startup_times.txt ] && cp $SRC/startup_times.txt profiles/${TAG}_startup_times.txt
 [ -f $SRC/power_probe.txt ] && cp $SRC/power_probe.txt profiles/${TAG}_power_probe.txt
-for f in strip_model_phases ab_no_chase first_frame_bands; do
+for f in strip_model_phases ab_no_chase first_frame_bands mode_times_1080p_gray ab_group_sep mode_times_1080p_by_sep; do
   [ -f $SRC/$f.txt ] && cp $SRC/$f.txt profiles/${TAG}_$f.txt
 done
 # the traffic table reads gpurun_out/<tag>/pmc_*_summary.txt

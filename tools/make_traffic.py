@@ -74,4 +74,4 @@ def main(tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r04")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r05")

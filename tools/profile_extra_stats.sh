@@ -3,7 +3,7 @@
 # (tools/mode_times.py: first frame, temporal, second iteration, smoother) and one rank of 8 stepped alone
 # (tools/strip_model_phases.py 8).   tools/profile_extra_stats.sh <tag>
 set -u
-TAG=${1:-r04x}
+TAG=${1:-r05x}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT

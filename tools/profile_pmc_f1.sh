@@ -1,7 +1,7 @@
 #!/bin/bash
 # The F1 (TV-L1) counter passes of tools/profile_round.sh alone: tools/profile_pmc_f1.sh <tag>
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT

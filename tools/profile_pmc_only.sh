@@ -1,7 +1,7 @@
 #!/bin/bash
 # The rocprofv3 part of tools/profile_round.sh alone (kernel statistics + PMC passes of C2 and C3): tools/profile_pmc_only.sh <tag>
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT

@@ -4,7 +4,7 @@
 #   tools/profile_round.sh <tag>      -> gpurun_out/<tag>/ ; then tools/make_traffic.py <tag>
 # Every command runs under `timeout` (a profiler that does not come back must not eat the GPU budget).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -29,6 +29,9 @@ done
 $T python3 $ROOT/tools/startup_times.py > $OUT/startup_times.txt 2>&1
 $T python3 $ROOT/tools/power_probe.py --steps 3000 --warmup 50 --no-cpu > $OUT/power_probe.txt 2>&1
 $T python3 $ROOT/tools/mode_times.py > $OUT/mode_times_1080p.txt 2>&1
+$T python3 $ROOT/tools/mode_times.py 1920 1080 1 20 > $OUT/mode_times_1080p_gray.txt 2>&1
+(cd $ROOT && bash tools/ab_sep.sh C2 2) > $OUT/ab_group_sep.txt 2>&1
+for s in 0 2 6; do echo "NLK_GROUP_SEP=$s"; NLK_GROUP_SEP=$s $T python3 $ROOT/tools/mode_times.py 2>/dev/null | grep layout; done > $OUT/mode_times_1080p_by_sep.txt 2>&1
 NLK_HOST_TRACE=1 $T python3 $ROOT/tools/api_wall.py > $OUT/api_wall.txt 2>&1
 # the one-rank-of-N model (exchanges skipped) and where its step goes
 for W in C2 C3; do
