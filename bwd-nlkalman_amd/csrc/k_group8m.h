@@ -5,12 +5,17 @@
 // basis in both directions: with F_q[i][j] = X[i][j] +- X[i][7-j] +- X[7-i][j]
 // +- X[7-i][7-j] (q = parity of the vertical / horizontal frequency, i, j < 4)
 //   Y[2a+qr][2b+qc] = sum_{i,j} C[2a+qr][i] C[2b+qc][j] F_q[i][j]
-// i.e. four 16x16 matrices D_q applied to four 16-vectors: 1024 MACs per patch,
-// all of them useful, as v_mfma_f32_16x16x4_f32 products over 16 patches at a
-// time (exact f32: the f32 MFMA is an fmaf chain). The inverse uses the same
-// matrices and unfolds with the same butterflies.
+// It runs in two forms, chosen per pass by the template argument SEP (tu_group8.hip picks by mode):
+//   Kronecker  four 16x16 matrices D_q applied to four 16-vectors: 1024 MACs per patch, all of them
+//              useful, as v_mfma_f32_16x16x4_f32 products over 16 patches at a time (exact f32: the
+//              f32 MFMA is an fmaf chain); the inverse uses the same matrices. Candidates land in
+//              REGISTERS: what the statistics of pass A want. Roles below.
+//   separable  Y_q = C_qr F_q C_qc^T, 512 MACs per patch, on v_mfma_f32_4x4x1_16B_f32 with one patch
+//              per lane quad (round 5; described where its helpers are defined): what pass B runs
+//              for the first iteration's groups; a separable pass A exists (SEP bit 2) and loses.
+// Both unfold with the same butterflies.
 //
-// Lane roles (lo = lane & 15, g4 = lane >> 4):
+// Lane roles of the Kronecker form (lo = lane & 15, g4 = lane >> 4):
 //   loads    lane = patch slot lo, rows g4 and 7-g4 of that patch (2 x 8 floats);
 //            its folded values F_q[g4][s] are the MFMA operand of k-step s.
 //   pass A   C = X^T D_q^T: register j of quadrant q = coefficient lo of
@@ -369,18 +374,16 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   const int pi = lo >> 2, pj = lo & 3;
   const int aplane = SEPB ? spl : g4;
   const bool agg_on = aplane <= CH;
-  int poff[4], goff[4];
+  int poff[4];
   float win[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
     const int r = SEPB ? ((kk & 2) ? 7 - si : si) : ((kk & 2) ? 7 - pi : pi);
     const int c = SEPB ? 4 * (kk & 1) + g4 : ((kk & 1) ? 7 - pj : pj);
     poff[kk] = (agg_on ? aplane : 0) * plane + r * rwp + c;
-    goff[kk] = r * g.w + c;
     win[kk] = window[r * 8 + c];
   }
   const size_t npix = (size_t)g.w * g.h;
-  float* acc_p = acc + (size_t)(agg_on ? aplane : 0) * npix;
   const float* src = g.have_basic ? cur : img;  // patches that get filtered
   // the planar images as element offsets from one base (tl.pbase = the start of the context's image slab)
   const float* const pbase = tl.pbase;
@@ -1036,7 +1039,16 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         } else if (agg_on) {
           // a member outside the tile (never with the smoother's own halo; kept complete): straight to the frame,
           // the smoother's image term with it
-          float* dst = acc_p + (size_t)qy * g.w + qx;
+          // (the frame offsets of the lane's four pixels are worked out HERE - the rare path - not kept in registers
+          // across the passes)
+          int goff[4];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const int r = SEPB ? ((kk & 2) ? 7 - si : si) : ((kk & 2) ? 7 - pi : pi);
+            const int c = SEPB ? 4 * (kk & 1) + g4 : ((kk & 1) ? 7 - pj : pj);
+            goff[kk] = r * g.w + c;
+          }
+          float* dst = acc + (size_t)aplane * npix + (size_t)qy * g.w + qx;
           if (SMO && aplane < CH) {
             const float* ip = src + (size_t)aplane * npix + (size_t)qy * g.w + qx;
 #pragma unroll
