@@ -28,6 +28,9 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (w, h, ch, sigma, patch, seed)   — BASELINE.json configs
     "C1": (256, 256, 1, 20.0, 8, 0),
+    # C1L: a single-channel frame at the real size (the reference's own published numbers are on *_mono sequences,
+    # scripts/dev-scripts/best-results.sh:60-61)
+    "C1L": (1920, 1080, 1, 20.0, 8, 9),
     "C2": (1920, 1080, 3, 20.0, 8, 1),
     "C3": (3840, 2160, 3, 40.0, 12, 2),
     # C5: the full per-frame chain flt1 -> flt2 -> smo1 on resident frames (single GPU only)
@@ -821,7 +824,7 @@ def main():
                                   "commit_ms is the bit-plane kernel alone, group_ms includes the replay "
                                   "(NLK_NO_CHASE=1: separate kernels)",
                "roofline": roof}
-        if world == 1 and not striped and not args.no_extras and args.workload in ("C1", "C2", "C3"):
+        if world == 1 and not striped and not args.no_extras and args.workload in ("C1", "C1L", "C2", "C3"):
             # beside the resident temporal call: the first frame of a sequence (deno0 = NULL: the spatial branch
             # everywhere, 441-candidate windows) and the drop-in API on host pointers (PCIe
             # included; pageable host memory, frame in row bands). Neither is `value`.

@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 T="timeout 300"
-for W in C2 C3 C1; do $T python3 $ROOT/bench.py --workload $W > $OUT/bench_$W.json 2> $OUT/bench_$W.err; done
+for W in C2 C3 C1 C1L; do $T python3 $ROOT/bench.py --workload $W > $OUT/bench_$W.json 2> $OUT/bench_$W.err; done
 $T python3 $ROOT/bench.py --workload C5 --no-cpu > $OUT/bench_C5.json 2> $OUT/bench_C5.err
 $T python3 $ROOT/bench.py --workload F1 > $OUT/bench_F1.json 2> $OUT/bench_F1.err
 $T python3 $ROOT/bench.py --workload S1 --steps 10 --warmup 2 > $OUT/bench_S1.json 2> $OUT/bench_S1.err
