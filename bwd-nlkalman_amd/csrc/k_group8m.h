@@ -333,6 +333,9 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   float* stash = smem + (CH + 1) * plane;
   // which pass runs the separable form (bit 1: pass B; bit 2: pass A)
   constexpr bool SEPA = (SEP & 4) != 0, SEPB = (SEP & 2) != 0;
+  // single-channel frames in the separable pass B: SIXTEEN members per step (below) instead of 4 members x {image,
+  // weights, idle, idle}
+  constexpr bool G16 = SEPB && CH == 1;
   constexpr int SST = SEPB ? NLK_G8S_SST : NLK_G8_SST;      // floats per stash slot
   constexpr int NSLOT = SEPB ? nlk_g8s_slots<CH>() : CH + 2;
   for (int i = lane; i < (NSLOT - CH) * SST; i += 64) stash[CH * SST + i] = (i == 64) ? 8.f : 0.f;
@@ -380,7 +383,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   for (int kk = 0; kk < 4; ++kk) {
     const int r = SEPB ? ((kk & 2) ? 7 - si : si) : ((kk & 2) ? 7 - pi : pi);
     const int c = SEPB ? 4 * (kk & 1) + g4 : ((kk & 1) ? 7 - pj : pj);
-    poff[kk] = (agg_on ? aplane : 0) * plane + r * rwp + c;
+    poff[kk] = (G16 ? 0 : (agg_on ? aplane : 0) * plane) + r * rwp + c;  // (G16: the plane is chosen per round)
     win[kk] = window[r * 8 + c];
   }
   const size_t npix = (size_t)g.w * g.h;
@@ -873,9 +876,18 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     // ---------------- pass B: shrink, invert and aggregate the group members, 4 per step
     // (slot lo = 4*channel + member; slots without a member / channel read a valid patch
     // and their results are not used)
-    const int bchc = min(bch, CH - 1);
+    // G16 (one channel, separable form): the weight plane needs no transform (its pixels are the constant 1) and there
+    // is only one image plane, so all sixteen slots of a step carry the image patch of a member of their own - slot
+    // (m, pl) = member n0 + 4 pl + m - and 20 members take 2 steps instead of 5. After the transposition register jm
+    // of lane group pl is member n0 + 4 pl + jm; the tile is then updated in sixteen rounds, one member each: the
+    // 16 lanes of group pl add the member's pixels to the image plane while the 16 lanes of the next group add its
+    // weights to the weight plane (an LDS instruction may touch ONE member per plane: the same 8 instructions per
+    // member as before, half the lanes idle).
+    constexpr int MPS = G16 ? 16 : 4;  // members per step
+    const int bchc = G16 ? 0 : min(bch, CH - 1);
+    const int bmm = G16 ? 4 * spl + g4 : bm;
     auto member_off = [&](int n0) -> uint32_t {   // (element offset inside an image: channel plane + patch)
-      const int n = min(n0 + bm, nagg - 1);
+      const int n = min(n0 + bmm, nagg - 1);
       const uint32_t qm = nlk_bperm_u(n < 64 ? greg[0] : greg[1], n & 63);
       return (uint32_t)bchc * (uint32_t)npix + (uint32_t)(nlk_y(qm) * g.w + nlk_x(qm));
     };
@@ -886,7 +898,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       nlk_rows_load32(pbase, e_src + off, rowaB, rowbB, R);
       if (SMO) nlk_rows_load32(pbase, e_psrc + off, rowaB, rowbB, Rp);
     }
-    uint32_t offn = member_off(4);
+    uint32_t offn = member_off(MPS);
     // Where every member lands in the tile, worked out once per target with one member per lane: its offset
     // (floats) inside a plane, and one bit per member "inside the tile" (entries past the last member count as
     // inside). A step whose four members are all inside - every step of a temporal target: the tile's halo is
@@ -909,12 +921,13 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     float ww[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) ww[kk] = wgt * win[kk];
-    const int bst = min(bch, NSLOT - 1);  // stash slot of the lane's load slot: image channel, weights, or nothing
+    const int bst = G16 ? 0 : min(bch, NSLOT - 1);  // stash slot of the lane's load slot: image channel, weights, or nothing
+    const bool slot_is_channel = G16 ? true : bch < CH;
     // gains of the lane's four coefficients of quadrant q at + 4 * q (separable) / + 16 * q (Kronecker)
     const float* st_g = stash + bst * SST + (SEPB ? 16 * si : 4 * g4);
     const float* st_m = st_g + 64;
     constexpr int QST = SEPB ? 4 : 16;
-    for (int n0 = 0; n0 < nagg; n0 += 4) {
+    for (int n0 = 0; n0 < nagg; n0 += MPS) {
       nlk_f4 Y[4];
       if (SMO) {
         // The smoother's update (1 - a) A + a B of a member's coefficients (A image, B previous frame,
@@ -931,7 +944,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
 #pragma unroll
       for (int q = 0; q < 4; ++q) Y[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
       if (SMO) nlk_rows_load32(pbase, e_psrc + offn, rowaB, rowbB, Rp);
-      offn = member_off(n0 + 8);
+      offn = member_off(n0 + 2 * MPS);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (SEPB) {
         nlk_sep_fwd4(F, sE, Y);
@@ -947,7 +960,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
           // (smoother: weight / unused slots carry gain 0 and their value - the constant's DCT - in the mean half; a
           // pass-through target reads its own patch as "previous" - the difference is zero - and its gains
           // come from the Wiener formula with beta_x = 0, i.e. may be 0 / 0: not used)
-          if (SMO) Y[q][j] = bch < CH ? (passthrough ? 0.f : gq[j] * Y[q][j]) : mq[j];
+          if (SMO) Y[q][j] = slot_is_channel ? (passthrough ? 0.f : gq[j] * Y[q][j]) : mq[j];
           else Y[q][j] = fmaf(gq[j], Y[q][j], mq[j]);
         }
       }
@@ -997,6 +1010,47 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
           const float o0 = Z[2][m] + Z[3][m], o1 = Z[2][m] - Z[3][m];
           PX[m][0] = e0 + o0; PX[m][1] = e1 + o1; PX[m][2] = e0 - o0; PX[m][3] = e1 - o1;
         }
+      }
+      if constexpr (G16) {
+#pragma unroll
+        for (int jm = 0; jm < 4; ++jm)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int n = n0 + 4 * t + jm;   // (wave-uniform) the member this round adds
+            if (n >= nagg) continue;
+            const bool act_img = spl == t, act_w = spl == ((t + 1) & 3);
+            const bool in = ((n < 64 ? inside[0] >> n : inside[1] >> (n - 64)) & 1ull) != 0;
+            const int toff = n < 64 ? __builtin_amdgcn_readlane((int)mbase[0], n) : __builtin_amdgcn_readlane((int)mbase[1], n - 64);
+            const uint32_t q = n < 64 ? __builtin_amdgcn_readlane(greg[0], n) : __builtin_amdgcn_readlane(greg[1], n - 64);
+            if (act_img || act_w) {
+              float px[4];
+#pragma unroll
+              for (int kk = 0; kk < 4; ++kk) px[kk] = act_img ? PX[jm][kk] : 1.f;
+              if (in) {
+                float* dst = smem + toff + (act_w ? plane : 0);
+                float old[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) old[kk] = dst[poff[kk]];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) dst[poff[kk]] = fmaf(ww[kk], px[kk], old[kk]);
+              } else {
+                // a member outside the tile: straight to the frame, the smoother's image term with it
+                const int qx = nlk_x(q), qy = nlk_y(q);
+                int goff[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) goff[kk] = ((kk & 2) ? 7 - si : si) * g.w + 4 * (kk & 1) + g4;
+                float* dst = acc + (act_w ? npix : (size_t)0) + (size_t)qy * g.w + qx;
+                if (SMO && act_img) {
+                  const float* ip = src + (size_t)qy * g.w + qx;
+#pragma unroll
+                  for (int kk = 0; kk < 4; ++kk) px[kk] += ip[goff[kk]];
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) unsafeAtomicAdd(dst + goff[kk], ww[kk] * px[kk]);
+              }
+            }
+          }
+        continue;
       }
       const uint32_t in4 = (uint32_t)((n0 < 64 ? inside[0] >> n0 : inside[1] >> (n0 - 64)) & 0xfull);
       if (in4 == 0xfu && n0 + 4 <= nagg) {

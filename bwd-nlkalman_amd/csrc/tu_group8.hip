@@ -20,7 +20,11 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
   // Default by what was measured at 1080p RGB (profiles/r05_mode_times_1080p.txt, group kernel, Kronecker -> hybrid):
   // FLT1 temporal 0.796 -> 0.740 ms, FLT1 spatial 1.043 -> 0.978; FLT2 (one member per group) 0.612 -> 0.628 and the
   // smoother 1.281 -> 1.322 stay with the Kronecker form.
-  int sep = mfma ? nlk_or(c->sw.group_sep, (g.smoother || g.ntagg < 4) ? 0 : 2) : 0;
+  // Single-channel frames (`r05_mode_times_1080p_gray_by_sep.txt`; the separable pass B packs 16 members per step
+  // there): FLT1 temporal 0.514 (Kronecker) / 0.404 (2) / 0.393 (6), first frame 0.594 / 0.487 / 0.482, the smoother
+  // 0.926 / 0.547 / 0.576, FLT2 0.315 / 0.331 / 0.358.
+  const int sep_default = g.ch == 1 ? (g.ntagg < 4 ? 0 : (g.smoother ? 2 : 6)) : ((g.smoother || g.ntagg < 4) ? 0 : 2);
+  int sep = mfma ? nlk_or(c->sw.group_sep, sep_default) : 0;
   if (sep != 0 && sep != 6) sep = 2;
   // (k_group8m addresses every patch as planes base + a 32-bit byte offset: the call's images must lie in the
   // context's slab and the slab be smaller than 4 GiB - ~119 Mpixel of RGB; beyond that the packed-lane kernel)
