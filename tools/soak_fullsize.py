@@ -1,3 +1,5 @@
+"""Full-size soak: random parameter sets at ~1080p (one or three channels, all three modes, NaN holes) against the serial
+oracle - records exact, pixels 2e-3.   python tools/soak_fullsize.py <seed> <count>   (NLK_GROUP_SEP forces a DCT form)"""
 import os, sys, numpy as np, importlib
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo/oracle')
 ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
@@ -31,7 +33,6 @@ for it in range(int(sys.argv[2])):
     g, rec = tp._dev_frame(ctx, smoother, cur, prev, basic, sigma, p)
     what = f"#{it} {w}x{h}x{ch} mode{mode} {over} sigma{sigma}"
     tp._check_records(rec, tr, what)
-    edge = np.abs(tr["aggr"] - 1e-6) <= 1e-10
-    g = np.where(edge[..., None], r, g)
-    cases.assert_close(g, r, what, flips=80)
+    g, _ = cases.excuse_threshold_pixels(g, r, tr, what, 256)   # (the only excused samples: pixels AT the aggr > 1e-6 threshold)
+    cases.assert_close(g, r, what)
     print("ok", what, "active", float(tr["active"].mean()), flush=True)
