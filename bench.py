@@ -450,6 +450,11 @@ def main():
         # process makes any GPU call (it never does), forward rank 0's line, exit with their status
         raise SystemExit(launch_ranks(args))
 
+    if os.environ.get("NLK_STRIPS_TEST_HANG") == "early" and args.strip_driver == "c" and "WORLD_SIZE" in os.environ:
+        # test hook for boxes without a GPU (tests/test_bench_contract.py): a rank that hangs before it touches anything
+        while True:
+            time.sleep(3600)
+
     # The ONE JSON line goes out through a private copy of stdout; whatever else this process writes to file
     # descriptor 1 from here on - librccl prints a five-line version banner there when a communicator is made -
     # goes to stderr instead.

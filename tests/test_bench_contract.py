@@ -47,6 +47,25 @@ def test_bench_launches_its_own_ranks_and_reports_their_failure():
     assert "no CPU fallback" in r.stderr          # the ranks started and said why they stopped
 
 
+def test_bench_kills_hanging_ranks_and_starts_fresh_ones():
+    """The launcher's time limit without a GPU: ranks that hang (NLK_STRIPS_TEST_HANG=early: before they touch anything)
+    are killed with all their descendants, FRESH ranks are started with the Python strip driver - and, there being no
+    GPU here, refuse to run: a non-zero exit, no JSON line, both facts on stderr, and the parent is back in time."""
+    import time
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the GPU variant is test_bench_survives_a_hanging_strip_driver")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=400,
+                       env=dict(env, NLK_BENCH_ONE_GPU="1", NLK_STRIPS_TEST_HANG="early", NLK_BENCH_LAUNCH_TIMEOUT="30"))
+    assert r.returncode != 0 and time.time() - t0 < 300
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "killed; starting fresh ranks with --strip-driver py" in r.stderr
+    assert "no CPU fallback" in r.stderr          # the fresh ranks started and said why they stopped
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [2, 8])
 def test_bench_two_and_eight_ranks_on_one_gpu(n):
