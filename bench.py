@@ -388,12 +388,23 @@ def launch_ranks(args):
             return -9, out or "", True
 
     launch = {"strip_driver_requested": args.strip_driver, "time_limit_s": round(limit, 1)}
+    import tempfile
+    mark = os.path.join(tempfile.gettempdir(), f"nlk_bench_stuck_{os.getpid()}")
+    if os.path.exists(mark):
+        os.remove(mark)
+    env["NLK_BENCH_STUCK_FILE"] = mark
     rc, out, timed_out = run_once([])
-    if timed_out and args.strip_driver == "c":
-        print(f"bench.py: the ranks did not finish within {limit:.0f} s with the C strip driver: killed; "
-              "starting fresh ranks with --strip-driver py", file=sys.stderr)
+    # (the ranks' own watchdog over the C driver's first step leaves this file: torch.distributed.run itself only says
+    # that a rank failed)
+    stuck = rc != 0 and os.path.exists(mark) and not [ln for ln in out.splitlines() if ln.startswith("{")]
+    if os.path.exists(mark):
+        os.remove(mark)
+    if (timed_out or stuck) and args.strip_driver == "c":
+        why = (f"the run with the C strip driver did not finish within {limit:.0f} s and was killed" if timed_out else
+               "the ranks' watchdog ended the run with the C strip driver: its set-up and first step did not get through")
+        print(f"bench.py: {why}; starting fresh ranks with --strip-driver py", file=sys.stderr)
         launch["fallback"] = "py"
-        launch["reason"] = f"the run with the C strip driver did not finish within {limit:.0f} s and was killed"
+        launch["reason"] = why
         rc, out, timed_out = run_once(["--strip-driver", "py"])
     if timed_out:
         print(f"bench.py: the ranks did not finish within {limit:.0f} s: killed, no line", file=sys.stderr)
@@ -523,6 +534,32 @@ def main():
 
     cs, c_driver_note = None, None
     ctx_whole = ctx   # (the strip drivers below may hand `ctx` over to a strip's own context)
+    # The C strip driver's first steps run under a watchdog in every rank. Started by a launcher of its own (the
+    # driver's `python -m torch.distributed.run ... bench.py --gpus N`) there is no parent to time the ranks out: a
+    # step that hangs - the neighbour send / recv between two devices has never run - would hold the job until somebody
+    # else's clock ends it. A hung collective cannot be recovered inside the process, so the watchdog ends the rank at
+    # once with status 5 and says what to do; `python bench.py --gpus N` (launch_ranks) takes that status, like its own
+    # time limit, as the signal to start fresh ranks on the Python driver.
+    watchdog = None
+    if args.strip_driver == "c" and (world > 1 or args.force_strips) and args.workload != "C5":
+        import threading
+        trial_s = float(os.environ.get("NLK_BENCH_C_TRIAL_TIMEOUT", 90))
+
+        def _stuck():
+            sys.stderr.write(f"bench.py: rank {rank}: the C strip driver did not get through its set-up and first step "
+                             f"in {trial_s:.0f} s - a hung collective cannot be undone in this process: exiting with "
+                             "status 5 (use --strip-driver py, or `python bench.py --gpus N`, which falls back by itself)\n")
+            sys.stderr.flush()
+            mark = os.environ.get("NLK_BENCH_STUCK_FILE")   # (launch_ranks: the launcher in between reports only "a rank failed")
+            if mark:
+                try:
+                    open(mark, "w").close()
+                except OSError:
+                    pass
+            os._exit(5)
+        watchdog = threading.Timer(trial_s, _stuck)
+        watchdog.daemon = True
+        watchdog.start()
     if args.strip_driver == "c" and (world > 1 or args.force_strips) and os.environ.get("NLK_STRIPS_TEST_HANG") == "1":
         # test hook: a C strip driver whose first step never returns (tests/test_bench_contract.py: the launcher must
         # kill the ranks and produce the line with the Python driver)
@@ -656,6 +693,9 @@ def main():
             st = torch.cat([mx, sm])
         selfcheck = {"max_abs": round(float(st[0].item()), 6), "threshold_pixels_excused": int(st[1].item()),
                      "tolerance": 2e-3, "what": "own rows of one strip step against the whole-frame call on the same GPU, every rank"}
+        if watchdog is not None:
+            watchdog.cancel()   # (set-up and a whole step went through)
+            watchdog = None
         if not st[0].item() <= 2e-3:
             if rank == 0:
                 print(f"bench.py: strip self-check FAILED: max |strip step - whole-frame call| = {st[0].item():g} "
@@ -664,6 +704,8 @@ def main():
                 dist.destroy_process_group()
             raise SystemExit(3)
 
+    if watchdog is not None:
+        watchdog.cancel()
     for _ in range(args.warmup):
         one_step()
     barrier()

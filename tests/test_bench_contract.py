@@ -62,7 +62,7 @@ def test_bench_kills_hanging_ranks_and_starts_fresh_ones():
                        env=dict(env, NLK_BENCH_ONE_GPU="1", NLK_STRIPS_TEST_HANG="early", NLK_BENCH_LAUNCH_TIMEOUT="30"))
     assert r.returncode != 0 and time.time() - t0 < 300
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert "killed; starting fresh ranks with --strip-driver py" in r.stderr
+    assert "was killed; starting fresh ranks with --strip-driver py" in r.stderr
     assert "no CPU fallback" in r.stderr          # the fresh ranks started and said why they stopped
 
 
@@ -104,7 +104,8 @@ def test_bench_survives_a_hanging_strip_driver():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu"],
                        capture_output=True, text=True, cwd=ROOT, timeout=500,
-                       env=dict(env, NLK_BENCH_ONE_GPU="1", NLK_STRIPS_TEST_HANG="1", NLK_BENCH_LAUNCH_TIMEOUT="120"))
+                       env=dict(env, NLK_BENCH_ONE_GPU="1", NLK_STRIPS_TEST_HANG="1", NLK_BENCH_LAUNCH_TIMEOUT="120",
+                                NLK_BENCH_C_TRIAL_TIMEOUT="1000"))   # (the launcher's own limit, not the ranks' watchdog)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout
@@ -112,6 +113,14 @@ def test_bench_survives_a_hanging_strip_driver():
     assert d["n_gpus"] == 2 and d["launch"]["fallback"] == "py" and "killed" in d["launch"]["reason"]
     assert d["strip_step"]["driver"].startswith("Python") and 0 <= d["strip_selfcheck_max_abs"] <= 2e-3
     assert "killed" in r.stderr
+    # the ranks' own watchdog (what protects a run started by somebody else's launcher): with a short fuse it ends the
+    # hanging ranks with status 5 before the launcher's limit, and the launcher falls back the same way
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=500,
+                       env=dict(env, NLK_BENCH_ONE_GPU="1", NLK_STRIPS_TEST_HANG="1", NLK_BENCH_C_TRIAL_TIMEOUT="15"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    assert d["launch"]["fallback"] == "py" and "watchdog" in d["launch"]["reason"] and "status 5" in r.stderr
 
 
 @pytest.mark.gpu
