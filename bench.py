@@ -824,8 +824,8 @@ def main():
         tfl = alg_flops[dom] / world / dur / 1e12 if dur > 0 else 0.0
         kname = ("k_group8m" if psz == 8 and ch in (1, 3) else "k_groupp") if dom == "group" else "k_bm_topk"
         # the instantiation the timed (temporal) frames launch: what the PMC table is looked up by
-        # (k_group8m's third template argument: which pass runs the separable DCT form - tu_group8.hip; FLT1: 2)
-        g8sep = os.environ.get("NLK_GROUP_SEP", "2")
+        # (k_group8m's third template argument: which pass runs the separable DCT form - tu_group8.hip; FLT1: 2, one channel: 6)
+        g8sep = os.environ.get("NLK_GROUP_SEP", "6" if ch == 1 else "2")
         inst = ((f"k_group8m<{ch}, false, {g8sep}>" if kname == "k_group8m" else f"k_groupp<{psz}, false>") if dom == "group"
                 else f"k_bm_topk<{psz}, {ch}, {((2 * p.search_sz_t + 1) ** 2 + 63) // 64}>")
         # HBM-side bytes per launch: PMC passes of the same sources (see measured_traffic)
