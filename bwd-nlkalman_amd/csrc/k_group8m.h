@@ -209,7 +209,9 @@ template <int CH, int SEP> constexpr int nlk_g8_stash_floats() {
 #ifndef NLK_G8_WPS
 #define NLK_G8_WPS 3  // wavefronts per SIMD the register budget is cut for (experiments: -DNLK_G8_WPS=2)
 #endif
-template <int CH, bool SMO, int SEP>
+// (UNIT: which translation unit instantiated the kernel - the same source compiled under two instruction schedulers,
+// tu_group8.hip and tu_group8_ilp.hip; it changes nothing but the symbol)
+template <int CH, bool SMO, int SEP, int UNIT = 0>
 __global__ void __launch_bounds__(64, NLK_G8_WPS)
 k_group8m(const float* __restrict__ img,   // matching / statistics image (planar)
           const float* __restrict__ cur,   // image whose patches are filtered

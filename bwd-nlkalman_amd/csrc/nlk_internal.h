@@ -45,7 +45,7 @@ struct NlkRecView {
 #define NLK_UNSET (-2147483647 - 1)
 #define NLK_SWITCH_LIST(X)                                                                                   \
   X(deterministic, "NLK_DETERMINISTIC") X(generic_group, "NLK_GENERIC_GROUP") X(group_packed, "NLK_GROUP_PACKED") \
-  X(group_dpp, "NLK_GROUP_DPP") X(group_sep, "NLK_GROUP_SEP") X(generic_match, "NLK_GENERIC_MATCH") X(mtx, "NLK_MTX") X(mty, "NLK_MTY")    \
+  X(group_dpp, "NLK_GROUP_DPP") X(group_sep, "NLK_GROUP_SEP") X(group_ilp, "NLK_GROUP_ILP") X(generic_match, "NLK_GENERIC_MATCH") X(mtx, "NLK_MTX") X(mty, "NLK_MTY")    \
   X(match_wg8, "NLK_MATCH_WG8") X(match_bx2, "NLK_MATCH_BX2") X(match_block, "NLK_MATCH_BLOCK")              \
   X(match_noblock, "NLK_MATCH_NOBLOCK") X(commit_wave, "NLK_COMMIT_WAVE") X(commit_lds, "NLK_COMMIT_LDS")    \
   X(commit_band, "NLK_COMMIT_BAND") X(no_chase, "NLK_NO_CHASE") X(chase_test_skip0, "NLK_CHASE_TEST_SKIP0") X(bands, "NLK_BANDS") X(host_bands, "NLK_HOST_BANDS")                    \

@@ -5,6 +5,8 @@
 #include "k_group8m.h"
 #include "nlk_internal.h"
 
+const void* nlk_group8m_ilp_kernel(int ch, bool smoother, int sep);  // tu_group8_ilp.hip
+
 namespace {
 
 template <int CH, bool SMO>
@@ -149,6 +151,10 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
                  const uint32_t*, const NlkTarget*, const uint32_t*, const uint8_t*, const float*,
                  const float*, float*);
     kern = !mfma ? k_group8<CH, SMO> : sep == 0 ? k_group8m<CH, SMO, 0> : sep == 2 ? k_group8m<CH, SMO, 2> : k_group8m<CH, SMO, 6>;
+    // (the same kernel compiled under the max-ilp scheduler, where that is the faster one: tu_group8_ilp.hip;
+    // NLK_GROUP_ILP=0 keeps this unit's)
+    if (mfma && nlk_or(c->sw.group_ilp, 1) != 0)
+      if (const void* k2 = nlk_group8m_ilp_kernel(CH, SMO, sep)) kern = reinterpret_cast<decltype(kern)>(const_cast<void*>(k2));
     HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
     const float* basis = (const float*)c->tabs.p;
