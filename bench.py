@@ -825,8 +825,10 @@ def main():
         kname = ("k_group8m" if psz == 8 and ch in (1, 3) else "k_groupp") if dom == "group" else "k_bm_topk"
         # the instantiation the timed (temporal) frames launch: what the PMC table is looked up by
         # (k_group8m's third template argument: which pass runs the separable DCT form - tu_group8.hip; FLT1: 2, one channel: 6)
+        # (the fourth: 1 = the copy compiled under the max-ilp scheduler, tu_group8_ilp.hip - RGB FLT1 in form 2 only)
         g8sep = os.environ.get("NLK_GROUP_SEP", "6" if ch == 1 else "2")
-        inst = ((f"k_group8m<{ch}, false, {g8sep}>" if kname == "k_group8m" else f"k_groupp<{psz}, false>") if dom == "group"
+        g8unit = 1 if ch == 3 and g8sep == "2" and os.environ.get("NLK_GROUP_ILP", "1") != "0" else 0
+        inst = ((f"k_group8m<{ch}, false, {g8sep}, {g8unit}>" if kname == "k_group8m" else f"k_groupp<{psz}, false>") if dom == "group"
                 else f"k_bm_topk<{psz}, {ch}, {((2 * p.search_sz_t + 1) ** 2 + 63) // 64}>")
         # HBM-side bytes per launch: PMC passes of the same sources (see measured_traffic)
         traffic, traffic_note = (None, "single-GPU runs only") if world > 1 else measured_traffic(args.workload, inst)
