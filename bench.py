@@ -427,6 +427,61 @@ def launch_ranks(args):
     return rc
 
 
+def run_preflight(rank):
+    """A rank started by somebody else's launcher (the driver's `python -m torch.distributed.run ... bench.py --gpus N`)
+    has no parent that could time it out, and a collective that hangs cannot be undone inside the process (the
+    watchdog below can only end the rank - and with it the run, without a line). So BEFORE this rank touches its GPU,
+    the C strip driver's whole first contact with N devices - communicator, buffers, one step, the self-check against
+    the whole-frame call - is tried in a CHILD process per rank (the same command with --steps 1, a rendezvous port of
+    its own, its own short watchdog). All children fine: the ranks go on with the C driver. Any child hung, crashed or
+    wrong: it is killed with its descendants, and EVERY rank takes the Python driver (agreed by an all-reduce); the
+    line says so (`preflight`). Returns {"ok", "seconds", "why"}."""
+    import signal
+    import subprocess
+    import tempfile
+    env = dict(os.environ)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)     # (the children's rank 0 hosts their store itself)
+    env.pop("NLK_BENCH_STUCK_FILE", None)
+    port = int(env.get("MASTER_PORT", "29500"))
+    env["MASTER_PORT"] = str(20000 + (port * 31 + 7919) % 20000)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env["NLK_BENCH_C_TRIAL_TIMEOUT"] = os.environ.get("NLK_BENCH_PREFLIGHT_TRIAL", "60")
+    limit = float(os.environ.get("NLK_BENCH_PREFLIGHT_TIMEOUT", 240))
+    cmd = ([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] +
+           ["--preflight-child", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-extras"])
+    t0 = time.time()
+    with tempfile.TemporaryFile(mode="w+") as errf:
+        proc = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=errf, env=env, cwd=ROOT, start_new_session=True)
+        why = None
+        try:
+            rc = proc.wait(timeout=limit)
+            if rc != 0:
+                why = f"the trial process of rank {rank} ended with status {rc}"
+        except subprocess.TimeoutExpired:
+            victims = []
+            try:
+                import psutil
+                victims = psutil.Process(proc.pid).children(recursive=True)
+            except Exception:                                                # noqa: BLE001
+                pass
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+            for v in victims:
+                try:
+                    v.kill()
+                except Exception:                                            # noqa: BLE001
+                    pass
+            proc.wait()
+            why = f"the trial process of rank {rank} did not finish within {limit:.0f} s and was killed"
+        if why:
+            errf.seek(0)
+            tail = errf.read()[-1500:]
+            sys.stderr.write(f"bench.py: {why}; its last words:\n{tail}\n")
+    return {"ok": why is None, "seconds": round(time.time() - t0, 1), "why": why}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -452,6 +507,8 @@ def main():
                     help="N = 1 only: additionally step ONE middle rank of a world of 2 / 4 / 8 alone, every exchange "
                          "skipped (csrc/strips.hip dry run): the kernels + launch gaps one rank pays per frame at that "
                          "world size - an upper bound of the scaling curve a one-GPU box can measure, not a result")
+    ap.add_argument("--preflight-child", action="store_true",
+                    help="internal: this process is the trial run a rank starts before it uses the C strip driver (run_preflight)")
     ap.add_argument("--strip-graph", action="store_true",
                     help="C strip driver: capture the step into a HIP graph once and replay it")
     args = ap.parse_args()
@@ -487,6 +544,11 @@ def main():
     if world > 1 and not one_gpu and torch.cuda.device_count() < world:   # device_count() does not initialise HIP
         raise SystemExit(f"--gpus {world} but {torch.cuda.device_count()} HIP device(s) visible "
                          "(NLK_BENCH_ONE_GPU=1 puts every rank on device 0 over gloo: plumbing check, not a measurement)")
+    preflight = None
+    want_pf = os.environ.get("NLK_BENCH_PREFLIGHT", "1")   # ("0": none; "force": also with every rank on one device)
+    if (world > 1 and args.strip_driver == "c" and not args.preflight_child and args.workload not in ("C5", "S1", "F1")
+            and want_pf != "0" and (not one_gpu or want_pf == "force")):
+        preflight = run_preflight(rank)                    # (child processes: this one has not touched the GPU yet)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # NLK_BENCH_ONE_GPU=1 (development aid): every rank on device 0 with the gloo backend and host
@@ -501,6 +563,16 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if preflight is not None:
+        okt = torch.tensor([1 if preflight["ok"] else 0], dtype=torch.int32, device="cpu" if one_gpu else dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        preflight["ok_on_every_rank"] = int(okt.item()) == 1
+        if not preflight["ok_on_every_rank"]:
+            if rank == 0:
+                print("bench.py: the C strip driver's trial run failed on some rank: every rank takes --strip-driver py",
+                      file=sys.stderr)
+            args.strip_driver = "py"
 
     pkg = importlib.import_module("bwd-nlkalman_amd")
     synth = importlib.import_module("bwd-nlkalman_amd.synth")
@@ -931,6 +1003,10 @@ def main():
                                   "ranks": model}
         if strip_info is not None:
             res["strip_step"] = strip_info
+        if preflight is not None:
+            # (rank 0's own trial + what the ranks agreed on: run_preflight)
+            res["preflight"] = dict(preflight, what="the C strip driver's set-up, one step and the self-check tried in a child "
+                                                    "process per rank before the ranks touched their GPUs")
         if selfcheck is not None:
             res["strip_selfcheck_max_abs"] = selfcheck["max_abs"]
             res["strip_selfcheck"] = selfcheck

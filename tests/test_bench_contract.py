@@ -116,6 +116,63 @@ def test_bench_survives_a_hanging_strip_driver():
     assert "status 5" in r.stderr and "starting fresh ranks with --strip-driver py" in r.stderr
 
 
+def test_preflight_reports_a_hung_and_a_failed_trial(monkeypatch):
+    """run_preflight (what protects ranks started by somebody else's launcher): the trial child that hangs is killed
+    with its descendants at the time limit, the one that fails is reported with its status - neither touches this
+    process. Without a GPU: the hang is NLK_STRIPS_TEST_HANG=early, the failure is the child's "needs a GPU"."""
+    import importlib.util
+    import time
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the GPU variant is test_ranks_under_a_foreign_launcher_try_the_c_driver_in_a_child_first")
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    for k, v in (("WORLD_SIZE", "2"), ("RANK", "0"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29431"),
+                 ("NLK_BENCH_ONE_GPU", "1"), ("NLK_BENCH_PREFLIGHT_TIMEOUT", "6")):
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("NLK_STRIPS_TEST_HANG", "early")
+    t0 = time.time()
+    r = bench.run_preflight(0)
+    assert r["ok"] is False and "did not finish within 6 s and was killed" in r["why"] and time.time() - t0 < 60
+    monkeypatch.delenv("NLK_STRIPS_TEST_HANG")
+    monkeypatch.setenv("NLK_BENCH_PREFLIGHT_TIMEOUT", "200")
+    r = bench.run_preflight(0)
+    assert r["ok"] is False and "ended with status" in r["why"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hang", [False, True])
+def test_ranks_under_a_foreign_launcher_try_the_c_driver_in_a_child_first(hang):
+    """The driver starts N > 1 as `python -m torch.distributed.run ... bench.py --gpus N`: no parent of ours can time the
+    ranks out. Every rank therefore tries the C strip driver's first contact in a child process before it touches its
+    GPU (run_preflight); a child that hangs (NLK_STRIPS_TEST_HANG=1: ended by its own watchdog with status 5) sends
+    EVERY rank to the Python driver, and the run still ends with its line. On this one-GPU box the ranks share device
+    0 over gloo (NLK_BENCH_PREFLIGHT=force: the trial is normally skipped there)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(NLK_BENCH_ONE_GPU="1", NLK_BENCH_PREFLIGHT="force", NLK_BENCH_PREFLIGHT_TRIAL="10")
+    if hang:
+        env["NLK_STRIPS_TEST_HANG"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-extras"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and 0 <= d["strip_selfcheck_max_abs"] <= 2e-3
+    pf = d["preflight"]
+    assert pf["ok"] is (not hang) and pf["ok_on_every_rank"] is (not hang)
+    if hang:
+        assert "status 5" in pf["why"] and d["strip_step"]["driver"].startswith("Python")
+
+
 @pytest.mark.gpu
 def test_strip_selfcheck_at_one_gpu():
     """--force-strips at N = 1 runs the same self-check (the one strip is the frame)."""
