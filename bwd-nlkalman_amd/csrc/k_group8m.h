@@ -131,10 +131,17 @@ __device__ __forceinline__ nlk_f4 nlk_mfma_q(const float (&x)[4], const nlk_basi
 }
 
 // C_q += X^T D_q^T (patches along the rows) or D_q X (swapped: coefficients along the rows)
-template <bool SWAP>
+// PRIO: the wavefront's issue priority raised (s_setprio) over the run of matrix instructions, so that a wavefront
+// whose products are ready goes before its neighbours' address arithmetic. Same box, group ms, off -> on (levels 1, 2,
+// 3 alike): RGB FLT1 temporal 0.7215 -> 0.7150, first frame 0.961 -> 0.948, FLT2 0.613 -> 0.609, SMO1 1.291 -> 1.288;
+// one channel FLT1 0.394 -> 0.390, first frame 0.480 -> 0.473, FLT2 unchanged, SMO1 0.547 -> 0.555 (that one stays
+// without: PRIO in the kernel)
+template <bool SWAP, bool PRIO>
 __device__ __forceinline__ void nlk_mfma_fwd(const float (&F)[4][4], const nlk_basis_op (&dA)[4], nlk_f4 (&C)[4]) {
+  if (PRIO) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
   for (int q = 0; q < 4; ++q) C[q] = nlk_mfma_q<SWAP>(F[q], dA[q], C[q]);
+  if (PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
 // sum over the 64 lanes, in every lane, without LDS: two butterfly steps inside the quads and two mirror steps
@@ -167,10 +174,12 @@ __device__ __forceinline__ nlk_f4 nlk_mfma4(float a, float b, nlk_f4 c) {
 // Y[q] (register a: coefficient (2 a + qr, 2 (lane & 3) + qc) of the quad's patch) += forward transform of F[q]. The four
 // quadrants together: the first stages of all of them, then the second stages - no MFMA waits for the one in front of
 // it (C2 group 0.749 -> 0.742 ms against quadrant after quadrant)
+template <bool PRIO>
 __device__ __forceinline__ void nlk_sep_fwd4(const float (&F)[4][4], const float (&E)[2][4], nlk_f4 (&Y)[4]) {
   nlk_f4 T[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) T[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
+  if (PRIO) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
   for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -179,12 +188,15 @@ __device__ __forceinline__ void nlk_sep_fwd4(const float (&F)[4][4], const float
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int q = 0; q < 4; ++q) Y[q] = nlk_mfma4(E[q >> 1][i], T[q][i], Y[q]);
+  if (PRIO) __builtin_amdgcn_s_setprio(0);
 }
 // X[q] (register m: folded pixel (lane & 3, m) of the quad's patch) = inverse transform of Y[q]
+template <bool PRIO>
 __device__ __forceinline__ void nlk_sep_inv4(const nlk_f4 (&Y)[4], const float (&G)[2][4], nlk_f4 (&X)[4]) {
   nlk_f4 U[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) { U[q] = nlk_f4{0.f, 0.f, 0.f, 0.f}; X[q] = nlk_f4{0.f, 0.f, 0.f, 0.f}; }
+  if (PRIO) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -193,6 +205,7 @@ __device__ __forceinline__ void nlk_sep_inv4(const nlk_f4 (&Y)[4], const float (
   for (int b = 0; b < 4; ++b)
 #pragma unroll
     for (int q = 0; q < 4; ++q) X[q] = nlk_mfma4(G[q & 1][b], U[q][b], X[q]);
+  if (PRIO) __builtin_amdgcn_s_setprio(0);
 }
 // floats per channel slot of the gain stash in the separable form: [gain | (1-gain)*mean][lane & 3][quadrant][a],
 // + 4: a lane reads 16 bytes at slot * stride + 16 * (lane & 3) + 4 * q - with a stride of 4 (mod 64 banks) the
@@ -335,6 +348,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   float* stash = smem + (CH + 1) * plane;
   // which pass runs the separable form (bit 1: pass B; bit 2: pass A)
   constexpr bool SEPA = (SEP & 4) != 0, SEPB = (SEP & 2) != 0;
+  constexpr bool PRIO = !(CH == 1 && SMO);  // (raised issue priority over the matrix instructions: nlk_mfma_fwd)
   // single-channel frames in the separable pass B: SIXTEEN members per step (below) instead of 4 members x {image,
   // weights, idle, idle}
   constexpr bool G16 = SEPB && CH == 1;
@@ -527,7 +541,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         if (b == 0) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) C[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
-          nlk_mfma_fwd<false>(F, dA, C);
+          nlk_mfma_fwd<false, PRIO>(F, dA, C);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float x0 = nlk_bperm(C[q][0], lo);
@@ -538,7 +552,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q) C[q] = NX0[q];
-          nlk_mfma_fwd<false>(F, dA, C);
+          nlk_mfma_fwd<false, PRIO>(F, dA, C);
         }
         if (HP) {
           // bit j of the lane group's pair of candidates: group membership (filter) / valid previous patch (smoother)
@@ -949,9 +963,9 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       offn = member_off(n0 + 2 * MPS);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (SEPB) {
-        nlk_sep_fwd4(F, sE, Y);
+        nlk_sep_fwd4<PRIO>(F, sE, Y);
       } else {
-        nlk_mfma_fwd<true>(F, dA, Y);
+        nlk_mfma_fwd<true, PRIO>(F, dA, Y);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -970,7 +984,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       float PX[4][4];
       if constexpr (SEPB) {
         nlk_f4 X[4];
-        nlk_sep_inv4(Y, sG, X);
+        nlk_sep_inv4<PRIO>(Y, sG, X);
         // unfold: rows si (O[0]) and 7 - si (O[1]) of the slot's patch, 8 columns each
         float O[2][8];
 #pragma unroll
