@@ -88,6 +88,58 @@ __device__ __forceinline__ float nlk_tv_sample(const float* __restrict__ im, con
   return (float)nlk_tv_cubic(col, t.tx);
 }
 
+// ---- sum of one value per lane over the wavefront, in every lane: the butterfly v += v[lane ^ off] for off = 32, 16,
+// 8, 4, 2, 1 - the same pairs in the same order as a chain of __shfl_xor, hence the same roundings - without the six
+// LDS-crossbar round trips (ds_bpermute) of that chain: row swaps for 32 and 16 (the sum of the two results is
+// own + partner in every lane), a rotation by 8 inside the rows of 16, two bank-masked row shifts for 4, quad
+// permutations for 2 and 1. A reduction costs ~80 cycles instead of ~400 (it sits between two barriers of every
+// half iteration).
+template <int CTRL, int BANK_MASK = 0xf>
+__device__ __forceinline__ uint32_t nlk_tv_dpp(uint32_t old, uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)x, CTRL, 0xf, BANK_MASK, false);
+}
+__device__ __forceinline__ uint32_t nlk_tv_xor8(uint32_t x) { return nlk_tv_dpp<0x128 /* row_ror:8 */>(x, x); }
+__device__ __forceinline__ uint32_t nlk_tv_xor4(uint32_t x) {
+  uint32_t t = nlk_tv_dpp<0x104 /* row_shl:4: lane i reads i + 4 */, 0x5>(x, x);  // lanes 0-3, 8-11 of a row
+  return nlk_tv_dpp<0x114 /* row_shr:4: lane i reads i - 4 */, 0xa>(t, x);        // lanes 4-7, 12-15
+}
+__device__ __forceinline__ uint32_t nlk_tv_xor2(uint32_t x) { return nlk_tv_dpp<0x4e /* quad_perm 2 3 0 1 */>(x, x); }
+__device__ __forceinline__ uint32_t nlk_tv_xor1(uint32_t x) { return nlk_tv_dpp<0xb1 /* quad_perm 1 0 3 2 */>(x, x); }
+
+__device__ __forceinline__ float nlk_tv_wave_sum(float v) {
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+  v += __uint_as_float(nlk_tv_xor8(__float_as_uint(v)));
+  v += __uint_as_float(nlk_tv_xor4(__float_as_uint(v)));
+  v += __uint_as_float(nlk_tv_xor2(__float_as_uint(v)));
+  v += __uint_as_float(nlk_tv_xor1(__float_as_uint(v)));
+  return v;
+}
+__device__ __forceinline__ double nlk_tv_wave_sum(double v) {
+  auto halves = [](double d, uint32_t& lo, uint32_t& hi) { const uint64_t u = (uint64_t)__double_as_longlong(d); lo = (uint32_t)u; hi = (uint32_t)(u >> 32); };
+  auto whole = [](uint32_t lo, uint32_t hi) { return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo)); };
+  uint32_t lo, hi;
+  halves(v, lo, hi);
+  {
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = whole(a[0], b[0]) + whole(a[1], b[1]);
+  }
+  halves(v, lo, hi);
+  {
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = whole(a[0], b[0]) + whole(a[1], b[1]);
+  }
+  halves(v, lo, hi); v += whole(nlk_tv_xor8(lo), nlk_tv_xor8(hi));
+  halves(v, lo, hi); v += whole(nlk_tv_xor4(lo), nlk_tv_xor4(hi));
+  halves(v, lo, hi); v += whole(nlk_tv_xor2(lo), nlk_tv_xor2(hi));
+  halves(v, lo, hi); v += whole(nlk_tv_xor1(lo), nlk_tv_xor1(hi));
+  return v;
+}
+
 // ---- normalisation to 0..255 (reference: tvl1flow_lib.c:283-341)
 __device__ __forceinline__ int nlk_tv_ord(float f) {  // order-preserving float -> int
   const int i = __float_as_int(f);
@@ -334,7 +386,7 @@ __device__ __forceinline__ void nlk_tv_px_dual(const NlkTvLevel& L, int i, int j
 // fixed-order sum of one float per thread over a workgroup of NLK_TV_THREADS
 __device__ __forceinline__ float nlk_tv_block_sum(float e, float* redf) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
+  e = nlk_tv_wave_sum(e);  // (== the chain e += __shfl_xor(e, off) for off = 32 .. 1)
   __syncthreads();  // (redf may still be read from the previous call)
   if (lane == 0) redf[wave] = e;
   __syncthreads();
@@ -478,7 +530,7 @@ __global__ void __launch_bounds__(256) k_tv_dual(NlkTvLevel L, int n, int nparts
     __shared__ double red[4];
     double s = 0.0;
     for (int k = threadIdx.x; k < nparts; k += 256) s += (double)L.part[k];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    s = nlk_tv_wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -540,7 +592,7 @@ __device__ __forceinline__ int nlk_tv_judge(const NlkTvLevel& L, const float* __
     }
 #pragma unroll
     for (int k = 0; k < KI; ++k) {
-      for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off, 64);
+      s[k] = nlk_tv_wave_sum(s[k]);
       if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s[k];
     }
   }
@@ -573,11 +625,11 @@ __device__ __forceinline__ void nlk_tv_post(const NlkTvLevel& L, unsigned seq) {
 // batch); 3: closes a group whose batches were all judged by k_tv_decide.
 // Judging inside the batches saves a launch per batch where the grid is small (every workgroup
 // re-adds all partial sums: cheap for a few hundred workgroups, not for thousands)
-template <int TH, int BT, int KI>
+template <int TW, int TH, int BT, int KI>
 __global__ void __launch_bounds__(BT, 4)  // (>= 4 wavefronts per SIMD: 16 per CU either way)
 k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode, unsigned seq) {
 #pragma clang fp contract(off)
-  constexpr int RW = NLK_TV_TW + 2 * KI, RH = TH + 2 * KI, RPT = (RW * RH + BT - 1) / BT;
+  constexpr int RW = TW + 2 * KI, RH = TH + 2 * KI, RPT = (RW * RH + BT - 1) / BT;
   __shared__ double red[KI][4];
   __shared__ float errs[KI];
   const int nblocks = gridDim.x * gridDim.y, block = blockIdx.y * gridDim.x + blockIdx.x;
@@ -633,7 +685,7 @@ k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode,
   __shared__ float s_p21[RW * RH], s_p22[RW * RH];
   __shared__ float redf[BT / 64];
   const int nx = L.nx, ny = L.ny;
-  const int rx0 = blockIdx.x * NLK_TV_TW - KI, ry0 = blockIdx.y * TH - KI;
+  const int rx0 = blockIdx.x * TW - KI, ry0 = blockIdx.y * TH - KI;
   // the region pixels of this thread: index in the region, in the image, constants of the warp
   int gidx[RPT];
   bool on[RPT], mine[RPT];
@@ -644,7 +696,7 @@ k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode,
     const int ly = r / RW, lx = r - ly * RW;
     const int j = rx0 + lx, i = ry0 + ly;
     on[m] = r < RW * RH && j >= 0 && j < nx && i >= 0 && i < ny;
-    mine[m] = on[m] && lx >= KI && lx < KI + NLK_TV_TW && ly >= KI && ly < KI + TH;
+    mine[m] = on[m] && lx >= KI && lx < KI + TW && ly >= KI && ly < KI + TH;
     gidx[m] = on[m] ? i * nx + j : 0;
     rc[m] = L.rho_c[gidx[m]]; gx[m] = L.I1wx[gidx[m]]; gy[m] = L.I1wy[gidx[m]]; gr[m] = L.grad[gidx[m]];
     if (r < RW * RH) {

@@ -112,20 +112,36 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
   // tile shape by the number of tiles: tall tiles do a quarter less halo work but need enough tiles to
   // keep every CU busy; with at least two tall tiles per CU, workgroups of 512 (two per CU) let one
   // tile load or store while the other computes
-  const int tx = (nx + NLK_TV_TW - 1) / NLK_TV_TW;
-  const int nb16 = tx * ((ny + NLK_TV_TH - 1) / NLK_TV_TH), nb32 = tx * ((ny + NLK_TV_TH2 - 1) / NLK_TV_TH2);
+  const int nb16 = ((nx + 63) / 64) * ((ny + NLK_TV_TH - 1) / NLK_TV_TH), nb32 = ((nx + 63) / 64) * ((ny + NLK_TV_TH2 - 1) / NLK_TV_TH2);
   int shape = nb32 >= 512 ? 2 : nb16 >= 400 ? nlk_or(c->sw.tv_mid, 1) : 0;
+  // levels that leave most of the chip idle (fewer than 100 tiles of 64 x 16): tiles of 16 x 16 in workgroups of 576
+  // (the 24 x 24 region, a pixel per thread) - a launch there is a chain of latencies (judge, load, 8 half iterations
+  // between barriers, store), shorter with 9 wavefronts per workgroup than with 16; 1080p flow at fscale 1: 3.20 ->
+  // 3.02 ms (tools/sweep_tv_small.sh; levels of 100-400 tiles do not respond)
+  if (shape == 0) shape = nb16 >= 100 ? nlk_or(c->sw.tv_s1, 0) : nb16 >= 20 ? nlk_or(c->sw.tv_s2, 7) : nlk_or(c->sw.tv_s3, 7);
   shape = nlk_or(c->sw.tv_shape, shape);
-  const int th = shape >= 1 && shape <= 2 ? NLK_TV_TH2 : NLK_TV_TH;
-  const int bt = shape >= 2 ? NLK_TV_BT2 : NLK_TV_BT;
   const bool deep = shape == 0 && nlk_set(c->sw.tv_deep);  // (8 iterations per launch: measured slower, kept for experiments)
   const int K = deep ? NLK_TV_K2 : NLK_TV_K;
-  const auto block_kernel = shape == 0 ? (deep ? k_tv_block<NLK_TV_TH, NLK_TV_BT, NLK_TV_K2> : k_tv_block<NLK_TV_TH, NLK_TV_BT, NLK_TV_K>)
-                          : shape == 1 ? k_tv_block<NLK_TV_TH2, NLK_TV_BT, NLK_TV_K>
-                          : shape == 2 ? k_tv_block<NLK_TV_TH2, NLK_TV_BT2, NLK_TV_K>
-                                       : k_tv_block<NLK_TV_TH, NLK_TV_BT2, NLK_TV_K>;
+  // shape -> tile width, tile height, threads, kernel
+  struct Shape { int tw, th, bt; decltype(&k_tv_block<64, NLK_TV_TH, NLK_TV_BT, NLK_TV_K>) kern; };
+  static const Shape shapes[] = {
+    {64, NLK_TV_TH, NLK_TV_BT, k_tv_block<64, NLK_TV_TH, NLK_TV_BT, NLK_TV_K>},      // 0
+    {64, NLK_TV_TH2, NLK_TV_BT, k_tv_block<64, NLK_TV_TH2, NLK_TV_BT, NLK_TV_K>},    // 1
+    {64, NLK_TV_TH2, NLK_TV_BT2, k_tv_block<64, NLK_TV_TH2, NLK_TV_BT2, NLK_TV_K>},  // 2
+    {64, NLK_TV_TH, NLK_TV_BT2, k_tv_block<64, NLK_TV_TH, NLK_TV_BT2, NLK_TV_K>},    // 3
+    {32, 16, 1024, k_tv_block<32, 16, 1024, NLK_TV_K>},                              // 4
+    {32, 16, 512, k_tv_block<32, 16, 512, NLK_TV_K>},                                // 5
+    {32, 32, 1024, k_tv_block<32, 32, 1024, NLK_TV_K>},                              // 6
+    {16, 16, 576, k_tv_block<16, 16, 576, NLK_TV_K>},                                // 7
+    {32, 8, 640, k_tv_block<32, 8, 640, NLK_TV_K>},                                  // 8
+    {16, 16, 320, k_tv_block<16, 16, 320, NLK_TV_K>},                                // 9
+  };
+  if (shape < 0 || shape >= (int)(sizeof(shapes) / sizeof(shapes[0]))) shape = 0;
+  const Shape& sh = shapes[shape];
+  const int th = sh.th, bt = sh.bt;
+  const auto block_kernel = deep ? k_tv_block<64, NLK_TV_TH, NLK_TV_BT, NLK_TV_K2> : sh.kern;
   const auto decide_kernel = deep ? k_tv_decide<NLK_TV_K2> : k_tv_decide<NLK_TV_K>;
-  const dim3 bgrid((nx + NLK_TV_TW - 1) / NLK_TV_TW, (ny + th - 1) / th);
+  const dim3 bgrid((nx + sh.tw - 1) / sh.tw, (ny + th - 1) / th);
   const int nblocks = bgrid.x * bgrid.y;
   const bool inline_judge = nblocks <= nlk_or(c->sw.tv_inline, 600);
   // batches between two looks at the state (a warp needs 5 to 50 iterations, mostly under 16)
@@ -229,7 +245,10 @@ int nlk_dev_tvl1_flow(nlk_ctx* c, float* flow, const float* I0, const float* I1,
   }
   const size_t n0 = (size_t)w * h;
   // scratch: 4 pyramids (I0, I1, u1, u2) + 10 work images + 2 temporaries at full size + partial sums
-  const size_t nparts0 = (size_t)((w + 63) / 64) * ((h + 3) / 4);  // workgroups of an iteration kernel at full size
+  // workgroups of an iteration kernel at full size: 64 x 4 pixels each (k_tv_primal), or the smallest tiles of the
+  // blocked kernel (16 wide or 8 tall: tv_scale's table)
+  const size_t nparts_a = (size_t)((w + 63) / 64) * ((h + 3) / 4), nparts_b = (size_t)((w + 15) / 16) * ((h + 7) / 8);
+  const size_t nparts0 = nparts_a > nparts_b ? nparts_a : nparts_b;
   const size_t floats = 4 * pyr + 18 * n0 + 2 * NLK_TV_K2 * nparts0 + 64;
   int rc = reserve(c, c->tv, sizeof(float) * floats);
   if (rc) return rc;
