@@ -394,13 +394,26 @@ __device__ __forceinline__ float nlk_tv_block_sum(float e, float* redf) {
   for (int k = 0; k < (int)(blockDim.x >> 6); ++k) bs += redf[k];
   return bs;
 }
+// The same inside a loop of iterations that END with a barrier: with two buffers taken in turn the barrier in front
+// of the write can go (buffer `it & 1` was last read two iterations ago, with a barrier in between), which leaves
+// ONE barrier here - the one that also publishes what the first half of the iteration wrote.
+__device__ __forceinline__ float nlk_tv_block_sum2(float e, float (*redf2)[32], int it) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* redf = redf2[it & 1];
+  e = nlk_tv_wave_sum(e);
+  if (lane == 0) redf[wave] = e;
+  __syncthreads();
+  float bs = 0.f;
+  for (int k = 0; k < (int)(blockDim.x >> 6); ++k) bs += redf[k];
+  return bs;
+}
 
 __global__ void __launch_bounds__(NLK_TV_THREADS) k_tv_level_wg(NlkTvLevel L) {
 #pragma clang fp contract(off)
   // the flow and the dual variables of the whole level live in LDS, the per-warp constants of a
   // thread's pixels in registers: an iteration costs two LDS round trips instead of two trips to L2
   constexpr int SL = (NLK_TV_WG_PIXELS + NLK_TV_THREADS - 1) / NLK_TV_THREADS;
-  __shared__ float redf[NLK_TV_WAVES];
+  __shared__ float redf2[2][32];
   __shared__ float s_u1[NLK_TV_WG_PIXELS], s_u2[NLK_TV_WG_PIXELS];
   __shared__ float s_p11[NLK_TV_WG_PIXELS], s_p12[NLK_TV_WG_PIXELS], s_p21[NLK_TV_WG_PIXELS], s_p22[NLK_TV_WG_PIXELS];
   const int nx = L.nx, ny = L.ny, npix = nx * ny;
@@ -458,7 +471,7 @@ __global__ void __launch_bounds__(NLK_TV_THREADS) k_tv_level_wg(NlkTvLevel L) {
       }
       // fixed-order sum (the reference adds the pixels one by one in float, which rounds
       // differently in the last bits); its barriers also separate the two halves
-      err = nlk_tv_block_sum(e, redf);
+      err = nlk_tv_block_sum2(e, redf2, n);
       err /= (float)npix;
 #pragma unroll
       for (int m = 0; m < SL; ++m) {
@@ -683,7 +696,7 @@ k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode,
   __shared__ float s_u1[RW * RH], s_u2[RW * RH];
   __shared__ float s_p11[RW * RH], s_p12[RW * RH];
   __shared__ float s_p21[RW * RH], s_p22[RW * RH];
-  __shared__ float redf[BT / 64];
+  __shared__ float redf2[2][32];
   const int nx = L.nx, ny = L.ny;
   const int rx0 = blockIdx.x * TW - KI, ry0 = blockIdx.y * TH - KI;
   // the region pixels of this thread: index in the region, in the image, constants of the warp
@@ -734,7 +747,7 @@ k_tv_block(NlkTvLevel L, NlkTvBuf in, NlkTvBuf out, int n0, int count, int mode,
       s_u2[r] = nb;
       if (mine[m]) e += (na - a) * (na - a) + (nb - b) * (nb - b);
     }
-    e = nlk_tv_block_sum(e, redf);  // (its barriers also publish the new u)
+    e = nlk_tv_block_sum2(e, redf2, k);  // (its barrier also publishes the new u)
     if (threadIdx.x == 0) part[k * nblocks + block] = e;
 #pragma unroll
     for (int m = 0; m < RPT; ++m) {
