@@ -117,10 +117,10 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
   // levels that leave most of the chip idle (fewer than 100 tiles of 64 x 16): tiles of 16 x 16 in workgroups of 576
   // (the 24 x 24 region, a pixel per thread) - a launch there is a chain of latencies (judge, load, 8 half iterations
   // between barriers, store), shorter with 9 wavefronts per workgroup than with 16; 1080p flow at fscale 1: 3.20 ->
-  // 3.02 ms (tools/sweep_tv_small.sh; levels of 100-400 tiles do not respond)
-  if (shape == 0) shape = nb16 >= 100 ? nlk_or(c->sw.tv_s1, 0) : nb16 >= 20 ? nlk_or(c->sw.tv_s2, 7) : nlk_or(c->sw.tv_s3, 7);
+  // 3.02 ms (profiles/README.md round 5: six shapes per level class; levels of 100-400 tiles do not respond)
+  if (shape == 0 && nb16 < 100) shape = 4;
   shape = nlk_or(c->sw.tv_shape, shape);
-  const bool deep = shape == 0 && nlk_set(c->sw.tv_deep);  // (8 iterations per launch: measured slower, kept for experiments)
+  const bool deep = shape == 0 && nlk_set(c->sw.tv_deep);  // (8 iterations per launch, shape 0 only: measured slower, kept for experiments)
   const int K = deep ? NLK_TV_K2 : NLK_TV_K;
   // shape -> tile width, tile height, threads, kernel
   struct Shape { int tw, th, bt; decltype(&k_tv_block<64, NLK_TV_TH, NLK_TV_BT, NLK_TV_K>) kern; };
@@ -129,12 +129,7 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
     {64, NLK_TV_TH2, NLK_TV_BT, k_tv_block<64, NLK_TV_TH2, NLK_TV_BT, NLK_TV_K>},    // 1
     {64, NLK_TV_TH2, NLK_TV_BT2, k_tv_block<64, NLK_TV_TH2, NLK_TV_BT2, NLK_TV_K>},  // 2
     {64, NLK_TV_TH, NLK_TV_BT2, k_tv_block<64, NLK_TV_TH, NLK_TV_BT2, NLK_TV_K>},    // 3
-    {32, 16, 1024, k_tv_block<32, 16, 1024, NLK_TV_K>},                              // 4
-    {32, 16, 512, k_tv_block<32, 16, 512, NLK_TV_K>},                                // 5
-    {32, 32, 1024, k_tv_block<32, 32, 1024, NLK_TV_K>},                              // 6
-    {16, 16, 576, k_tv_block<16, 16, 576, NLK_TV_K>},                                // 7
-    {32, 8, 640, k_tv_block<32, 8, 640, NLK_TV_K>},                                  // 8
-    {16, 16, 320, k_tv_block<16, 16, 320, NLK_TV_K>},                                // 9
+    {16, 16, 576, k_tv_block<16, 16, 576, NLK_TV_K>},                                // 4
   };
   if (shape < 0 || shape >= (int)(sizeof(shapes) / sizeof(shapes[0]))) shape = 0;
   const Shape& sh = shapes[shape];
@@ -246,8 +241,8 @@ int nlk_dev_tvl1_flow(nlk_ctx* c, float* flow, const float* I0, const float* I1,
   const size_t n0 = (size_t)w * h;
   // scratch: 4 pyramids (I0, I1, u1, u2) + 10 work images + 2 temporaries at full size + partial sums
   // workgroups of an iteration kernel at full size: 64 x 4 pixels each (k_tv_primal), or the smallest tiles of the
-  // blocked kernel (16 wide or 8 tall: tv_scale's table)
-  const size_t nparts_a = (size_t)((w + 63) / 64) * ((h + 3) / 4), nparts_b = (size_t)((w + 15) / 16) * ((h + 7) / 8);
+  // blocked kernel (16 x 16: tv_scale's table)
+  const size_t nparts_a = (size_t)((w + 63) / 64) * ((h + 3) / 4), nparts_b = (size_t)((w + 15) / 16) * ((h + 15) / 16);
   const size_t nparts0 = nparts_a > nparts_b ? nparts_a : nparts_b;
   const size_t floats = 4 * pyr + 18 * n0 + 2 * NLK_TV_K2 * nparts0 + 64;
   int rc = reserve(c, c->tv, sizeof(float) * floats);
