@@ -188,6 +188,7 @@ def test_default_bench_line():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["unit"] == "Mpix/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert "1080p" in d["metric"] and d["config"]["workload"].startswith("C2: 1920x1080x3")
+    assert d["clock_settle_steps"] == 80      # untimed steps in front of the W warm-up steps (the clocks' ramp: bench.py)
     assert abs(d["value"] - 1920 * 1080 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * d["value"]
     ro = d["roofline"]
     assert ro["bound"] in ("hbm", "mfma") and ro["unit"] in ("GB/s", "TFLOP/s") and ro["peak"] > 0
