@@ -141,6 +141,14 @@ def measured_traffic(workload, instance, largest_grid=False):
                                   f"(fetch x2 bound: {ent['traffic_bytes_fetch_x2']:.4g})")
 
 
+def settle_steps(w, h, ch, ms_1080p_rgb=1.0):
+    """Untimed steps in front of the warm-up steps: ~80 ms of the step, so that the timed loop runs at settled clocks
+    (the GPU takes ~25 ms of sustained load after an idle phase: DESIGN.md §5, profiles/r05_step_trace.txt). A fixed
+    number by frame size - every rank runs the same. NLK_BENCH_SETTLE_STEPS overrides (0: none)."""
+    return int(os.environ.get("NLK_BENCH_SETTLE_STEPS",
+                              min(2000, max(16, round(80.0 / (ms_1080p_rgb * w * h * ch / (1920 * 1080 * 3.0)))))))
+
+
 def bench_flow(args, pkg, synth, ctx, torch, dist, rank, world, dev):
     """Workload F1: one step = one multiscale TV-L1 flow between two resident gray frames.
     The path does not shard (every iteration couples the whole image): N > 1 runs N independent
@@ -162,7 +170,8 @@ def bench_flow(args, pkg, synth, ctx, torch, dist, rank, world, dev):
             dist.barrier()
         torch.cuda.synchronize()
     iters = 0
-    for _ in range(args.warmup):
+    settle = settle_steps(w, h, 3, 6.0)
+    for _ in range(settle + args.warmup):
         iters = ctx.tvl1_flow(flow.data_ptr(), g0.data_ptr(), g1.data_ptr(), w, h, prm)
     barrier()
     t0 = time.perf_counter()
@@ -203,7 +212,7 @@ def bench_flow(args, pkg, synth, ctx, torch, dist, rank, world, dev):
     traffic, traffic_note = (None, "single-GPU runs only") if world > 1 else measured_traffic("F1", "k_tv_block", largest_grid=True)
     traffic = traffic / 4 if traffic else None
     res = {"metric": "Mpix/s per flow (tvl1flow, 1080p, default parameters)", "value": round(world * w * h / (dt / args.steps) / 1e6, 3),
-           "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_settle_steps": settle,
            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"F1: dual TV-L1 flow between two {w}x{h} noisy frames (sigma {sigma:g}), "
@@ -301,7 +310,8 @@ def bench_sequence(args, pkg, synth, ctx, torch, rank, world, dev):
         for j in range(n):
             sf.push(noisy[(k0 + j) % nfr].data_ptr())
         sf.ctx.sync()
-    k = 1 + args.warmup
+    settle = settle_steps(w, h, ch, 5.0)
+    k = 1 + settle + args.warmup
     for sf in sfs:
         run(sf, k, 0)
     t0 = time.perf_counter()
@@ -318,7 +328,7 @@ def bench_sequence(args, pkg, synth, ctx, torch, rank, world, dev):
     out = sf.download_rgb(sf.flt2)
     res = {"metric": "Mpix/s per frame (flow + mask + nlkalman-flt x2, 1080p sigma=20, frames resident)",
            "value": round(w * h / (dt / args.steps) / 1e6, 3), "unit": "Mpix/s", "n_gpus": 1,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+           "steps": args.steps, "warmup": args.warmup, "clock_settle_steps": settle, "ms_per_step": round(ms, 4), "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"S1: {w}x{h}x{ch} sigma={sigma:g}, per frame: TV-L1 flow (lambda 0.25, fscale 1: the default of scripts/nlkalman-seq.sh) "
                                   "to the previous FLT2 output, occlusion mask (0.75), warp + FLT1, warp + FLT2 "
@@ -782,9 +792,8 @@ def main():
     # 1080p step falls from 1.19 to 1.02 ms over its first 25 repetitions after an idle phase - the CPU legs above are
     # one): a timed loop of a few dozen 1 ms steps right after W warm-up steps would time that ramp, not the filter. So
     # the same step runs untimed for ~80 ms first (a fixed number of steps by frame size: every rank runs the same);
-    # then the W warm-up steps and the K timed ones, as always. NLK_BENCH_SETTLE_STEPS overrides (0: none).
-    settle = int(os.environ.get("NLK_BENCH_SETTLE_STEPS",
-                                min(2000, max(16, round(80.0 / (w * h * ch / (1920 * 1080 * 3.0)))))))
+    # then the W warm-up steps and the K timed ones, as always (settle_steps).
+    settle = settle_steps(w, h, ch)
     for _ in range(settle):
         one_step()
     for _ in range(args.warmup):
