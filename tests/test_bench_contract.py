@@ -189,6 +189,7 @@ def test_default_bench_line():
     assert d["unit"] == "Mpix/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert "1080p" in d["metric"] and d["config"]["workload"].startswith("C2: 1920x1080x3")
     assert d["clock_settle_steps"] == 80      # untimed steps in front of the W warm-up steps (the clocks' ramp: bench.py)
+    assert d["ms_per_step_first_20_unsettled"] > 0.9 * d["ms_per_step"]   # (reported beside, never instead)
     assert abs(d["value"] - 1920 * 1080 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * d["value"]
     ro = d["roofline"]
     assert ro["bound"] in ("hbm", "mfma") and ro["unit"] in ("GB/s", "TFLOP/s") and ro["peak"] > 0
