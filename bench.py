@@ -141,6 +141,80 @@ def measured_traffic(workload, instance, largest_grid=False):
                                   f"(fetch x2 bound: {ent['traffic_bytes_fetch_x2']:.4g})")
 
 
+def c5_roofline(c5, w, h, ch, psz, ngrid, ps):
+    """Roofline object of config 5's dominant launch: the smoother's group kernel (`k_group8m<CH, true, ...>`, the
+    largest single launch of the chain). Algorithmic flops from the launch's records with the terms of SURVEY.md
+    Appendix B: per processed target with previous-frame patches, forward transforms of the kept candidates' image
+    patches (M1, V1 over all of them, `src/nlkalman.c:1646-1658`) and of the valid previous-frame patches (M0, V0, V01,
+    group slots, `:1659-1676`), inverse transforms of the group members (`:1780`), `2 psz^3` MACs per channel each;
+    statistics 16 flop per coefficient and candidate, gains 68 per coefficient, aggregation 2 per member pixel and
+    plane. A target without a valid previous patch aggregates its own patch unchanged (`:1795-1804`): no transform."""
+    import numpy as np
+    rec, tm = c5["smo1"]["rec"], c5["smo1"]["ms"]
+    act = rec["active"].astype(bool) & (rec["nagg"] > 0)
+    nsel, np0, nagg = (rec[k_][act].astype(np.float64) for k_ in ("nsel", "np0", "nagg"))
+    hp = np0 > 0
+    ntr = float(((nsel + np0 + nagg) * hp).sum())
+    group_flops = ntr * ch * 2 * 2 * psz ** 3
+    other = float(((nsel * ch * psz * psz * 16 + ch * psz * psz * 68) * hp + nagg * psz * psz * (ch + 1) * 2).sum())
+    dur = tm["group_ms"] * 1e-3
+    k = ps.npatches_t
+    alg_bytes = 2 * w * h * ch * 4 + (ch + 1) * w * h * 4 + ngrid * k * 4
+    sep = os.environ.get("NLK_GROUP_SEP", "2" if ch == 1 else "0")
+    unit = 1 if ch == 3 and sep == "0" and os.environ.get("NLK_GROUP_ILP", "1") != "0" else 0
+    inst = f"k_group8m<{ch}, true, {sep}, {unit}>"
+    traffic, traffic_note = measured_traffic("C5", inst)
+    tfl = group_flops / dur / 1e12 if dur > 0 else 0.0
+    chain = sum(c5[n_]["ms"]["total_ms"] for n_ in c5)
+    return {"kernel": inst, "what": "the smoother's group launch: the largest single launch of the chain "
+                                    f"({tm['group_ms']:.3f} of {chain:.3f} ms of kernels per step)",
+            "bound": "mfma", "achieved": round(tfl, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+            "launch_ms": round(tm["group_ms"], 4),
+            "frac_all_survey_terms": round((group_flops + other) / dur / 1e12 / MFMA_F32_PEAK_TFLOPS, 4) if dur > 0 else None,
+            "algorithmic_flops_per_launch": int(group_flops), "algorithmic_bytes_per_launch": int(alg_bytes),
+            "targets": {"processed": int(act.sum()), "with_previous_patches": int(hp.sum()),
+                        "mean_candidates": round(float(nsel[hp].mean()) if hp.any() else 0.0, 2),
+                        "mean_members": round(float(nagg[hp].mean()) if hp.any() else 0.0, 2)},
+            "hbm": {"achieved": round(alg_bytes / dur / 1e9, 3) if dur > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(alg_bytes / dur / 1e9 / HBM_PEAK_GBS, 6) if dur > 0 else 0.0},
+            "valu": {"achieved": round(other / dur / 1e12, 3) if dur > 0 else 0.0, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(other / dur / 1e12 / MFMA_F32_PEAK_TFLOPS, 4) if dur > 0 else 0.0,
+                     "what": "statistics 16 flop per coefficient and candidate, gains 68 per coefficient, aggregation 2 per "
+                             "member pixel and plane (estimate), over the same launch time"},
+            "other_launches": {n_: {"group_ms": round(c5[n_]["ms"]["group_ms"], 4), "match_ms": round(c5[n_]["ms"]["match_ms"], 4)}
+                               for n_ in ("flt1", "flt2")},
+            "note": "frac = transform flops only (matrix cores) over the launch's mean time from HIP events on the "
+                    "context's stream; compute bound like the filter's group launch (DESIGN.md \u00a75)"}
+
+
+def cpu_baseline_chain(O, o1, prev, sigma, p1, p2, ps, reps=3):
+    """Config 5's chain - flt1 temporal, flt2 on its basic estimate, smo1 - on the CPU restatement built with the
+    reference's release flags, OpenMP over the host cores: one warm-up chain, then the median of `reps`."""
+    nthr = min(O.max_threads(), os.cpu_count() or 1, 100)
+    fn = O.release_filter_frame()
+    cv = lambda p_: O.Params(*[getattr(p_, k) for k, _ in p_._fields_])
+    h, w = o1.shape[:2]
+
+    def chain():
+        f1 = O.filter_frame_with(fn, o1, prev, None, sigma, cv(p1), nthreads=nthr)
+        f2 = O.filter_frame_with(fn, o1, prev, f1, sigma, cv(p2), nthreads=nthr)
+        return O.smooth_frame(prev, f2, None, sigma, cv(ps), nthreads=nthr)
+    chain()
+    ts = []
+    for _ in range(reps):
+        t0 = time.time()
+        chain()
+        ts.append(time.time() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"value": round(w * h / med / 1e6, 4), "unit": "Mpix/s", "cores": nthr, "kind": "port",
+            "flags": O.RELEASE_FLAGS + " (the two filter calls); " + O.STRICT_FLAGS + " (the smoother)",
+            "dct": "table (FFTW absent)", "cpu": cpu_model(), "threads": nthr, "median_s": round(med, 4),
+            "sample": f"full chains flt1 -> flt2 -> smo1 on {w}x{h}x{o1.shape[2]} frames, OpenMP over {nthr} threads: "
+                      f"1 warm-up + median of {reps}; oracle/nlk_oracle.c (table DCT, FFTW absent)"}
+
+
 def settle_steps(w, h, ch, ms_1080p_rgb=1.0):
     """Untimed steps in front of the warm-up steps: ~80 ms of the step, so that the timed loop runs at settled clocks
     (the GPU takes ~25 ms of sustained load after an idle phase: DESIGN.md §5, profiles/r05_step_trace.txt). A fixed
@@ -820,6 +894,22 @@ def main():
         one_step()
     barrier()
     tm = ctx.timings()
+    c5 = None
+    if args.workload == "C5":
+        # the chain's three calls one at a time (HIP events around every kernel, as above): which launch dominates and
+        # what it did - the smoother's records feed its roofline below (missing 3 / next 2)
+        c5 = {}
+        for name_, call_ in (("flt1", lambda: ctx.filter_frame(t_f1.data_ptr(), t_n1.data_ptr(), t_prev.data_ptr(), None, w, h, ch, sigma, p)),
+                             ("flt2", lambda: ctx.filter_frame(t_f2.data_ptr(), t_n1.data_ptr(), t_prev.data_ptr(), t_f1.data_ptr(), w, h, ch, sigma, p2)),
+                             ("smo1", lambda: ctx.smooth_frame(t_out.data_ptr(), t_prev.data_ptr(), t_f2.data_ptr(), None, w, h, ch, sigma, ps))):
+            call_()
+            barrier()
+            ctx.set_profiling(False)
+            ctx.set_profiling(True)     # (restarts the sums)
+            for _ in range(args.steps):
+                call_()
+            barrier()
+            c5[name_] = {"ms": ctx.timings(), "rec": ctx.read_records()}
     ctx.set_profiling(False)
     striped = world > 1 or args.force_strips
     # transforms this rank's group kernel really ran (from its records): the roofline's flops
@@ -1046,7 +1136,14 @@ def main():
             res["config"]["workload"] = (f"C5: {w}x{h}x{ch} sigma={sigma:g}: flt1 temporal -> flt2 -> smo1 "
                                          f"(3 frame calls per step), frames resident")
             res["kernels_ms"] = {k_: round(3 * v, 4) for k_, v in tm.items()}  # per step = 3 calls
-            res.pop("roofline")
+            res["stages_ms"] = {n_: {k_: round(v, 4) for k_, v in c5[n_]["ms"].items()} for n_ in c5}
+            res["roofline"] = c5_roofline(c5, w, h, ch, psz, ngx * ngy, ps)
+            res["metric"] = "Mpix/s per frame (flt1 -> flt2 -> smo1 chain, 1080p sigma=20, frames resident)"
+            if not args.no_cpu:
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import oracle as O
+                res["cpu_baseline"] = cpu_baseline_chain(O, t_n1.cpu().numpy(), t_prev.cpu().numpy(), sigma, p, p2, ps)
+                res["speedup_vs_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
         if not args.no_cpu and args.workload != "C5":
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle as O

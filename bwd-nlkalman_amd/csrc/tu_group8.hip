@@ -101,9 +101,24 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
     tl.nmain = mfma ? nlk_g8m_grid(tl.ntx, tl.nty) : 0;
     const int rw_max = (tl.tgx - 1) * g.step + 2 * tl.wmax + g.psz;
     tl.rh_max = (tl.tgy - 1) * g.step + 2 * tl.wmax + g.psz;
-    if (mfma) {
-      // one aggregation access = 4x4 pixels of each plane: row stride = 4 (mod 8) and plane
-      // stride = 16 (mod 32 banks) make the 64 lanes hit every bank twice
+    if (mfma && sep == 2 && CH > 1) {
+      // Separable pass B (round 6). A tile update is a ds_read_b32 / ds_write_b32 of lane
+      // (column g4 = lane >> 4, plane spl = (lane >> 2) & 3, row si = lane & 3): the LDS serves a 4-byte access in
+      // two groups of 32 lanes, {0-31} and {32-63}, on 32 banks (MI355X_MICROARCH.md, LDS) - and a half wavefront
+      // holds all FOUR planes here, two columns and four rows. With the Kronecker layout's strides (below: plane
+      // stride 16 mod 32) planes 0 / 2 and 1 / 3 of a half met on the same banks: a 2-way conflict on every one of
+      // the 160 tile instructions of a target (SQ_LDS_BANK_CONFLICT 1.6e6 -> 3.1e7 per C2 launch when the
+      // separable pass B came in round 5). Conflict-free: row stride = 2 (mod 4) - rows si give four different
+      // multiples of 2, the two columns fill the odd banks - and plane stride = 8 (mod 16) (brute force over all
+      // strides: tools/lds_banks.py). At 1080p the row stride is the region's own 26 floats (28 before) and the
+      // workgroup's LDS falls from ten to nine 1280-byte pieces.
+      tl.rwp = rw_max + ((2 - rw_max) % 4 + 4) % 4;
+      tl.plane = tl.rwp * tl.rh_max;
+      tl.plane += ((8 - tl.plane) % 16 + 16) % 16;
+    } else if (mfma) {
+      // Kronecker pass B (plane = lane >> 4, pixel (pi, pj) = lane & 15; also the 16-member steps of one-channel
+      // frames, whose rounds touch two planes): one aggregation access = 4x4 pixels of each plane; row stride = 4
+      // (mod 8) and plane stride = 16 (mod 32 banks) make the 32 lanes of a half wavefront hit 32 banks
       tl.rwp = rw_max + ((4 - rw_max) % 8 + 8) % 8;
       tl.plane = tl.rwp * tl.rh_max;
       tl.plane += ((16 - tl.plane) % 32 + 32) % 32;
