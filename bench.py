@@ -1053,7 +1053,12 @@ def main():
                                       f"patch {psz}, defaults of nlkalman_default_params",
                           "parallelism": f"row strips x{world}" if world > 1 else "single GPU",
                           "mask_order": "serial-exact" if world == 1 else
-                          "serial-exact (mark words all-gathered, mask replayed on every rank)"},
+                          "serial-exact (mark words all-gathered, mask replayed on every rank)",
+                          # (the opt-in block-summed distance order, 8 x 8 patches: k_match.h; `value` of a default run
+                          # is always the exact order)
+                          "match_order": ("block-summed (NLK_MATCH_ORDER=block: NOT the reference's summation order)"
+                                          if os.environ.get("NLK_MATCH_ORDER", "") in ("block", "1") and psz == 8
+                                          else "exact (the reference's hy, hx, c order)")},
                "kernels_ms": {k_: round(v, 4) for k_, v in tm.items()},
                "kernels_ms_note": "second loop of the same steps with HIP events around every kernel on the "
                                   "context's stream; ms_per_step is the timed (unprofiled) loop. Whole-frame calls "

@@ -43,6 +43,7 @@ struct NlkTile {
   int halo;           // search halo held in LDS (windows reaching further read HBM/L2)
   int block;          // 4 x 2-target blocks share their squared differences (0: NLK_MATCH_NOBLOCK, target by target)
   int threads;        // k_bm_topk: threads per workgroup (256, or 512 for tiles of 8 x 8 targets)
+  int order;          // summation order of the distances: 0 = the reference's (exact), 1 = block-summed (opt-in; 8 x 8 patches)
 };
 
 __device__ inline uint64_t nlk_wave_or(uint64_t v) {
@@ -164,7 +165,9 @@ __device__ __forceinline__ void nlk_match_select(const float (&acc)[M], const ui
 // Leaves the k kept candidates, sorted, in sel[0..k).
 // (forced inline: as a real call the LDS tile pointer becomes a generic one, the candidate reads
 // turn into FLAT loads and the spatial search runs 3x slower)
-template <int PSZ, int CH, int M>
+// ORD = 1: the opt-in block-summed order (NLK_MATCH_ORDER=block; nlk_match_block_sum below): the four quarter
+// patches summed separately, then added - the same number whichever path computes it.
+template <int PSZ, int CH, int M, int ORD = 0>
 __device__ __forceinline__ void nlk_match_target(const float* __restrict__ tile, int plane, int rwp,
                                         const float* __restrict__ tgt, int tplane, int trw,
                                         int cbase, int nwx, int n, int k, int x0, int y0,
@@ -180,6 +183,36 @@ __device__ __forceinline__ void nlk_match_target(const float* __restrict__ tile,
     cq[m] = cbase + wy * rwp + wx;
     wxy[m] = ((uint32_t)wy << 16) | (uint32_t)wx;
     acc[m] = 0.f;
+  }
+  if constexpr (ORD == 1) {
+    constexpr int step = PSZ / 2;
+    float sb[2][2][M];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int m = 0; m < M; ++m) sb[i >> 1][i & 1][m] = 0.f;
+#pragma unroll
+    for (int sy = 0; sy < 2; ++sy) {
+#pragma unroll 1
+      for (int hy = sy * step; hy < (sy + 1) * step; ++hy) {
+        const float* trow = tgt + hy * trw;
+#pragma unroll
+        for (int hx = 0; hx < PSZ; ++hx)
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            const float tv = trow[c * tplane + hx];
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+              const float e = tile[c * plane + cq[m] + hy * rwp + hx] - tv;
+              sb[sy][hx / step][m] = fmaf(e, e, sb[sy][hx / step][m]);
+            }
+          }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) acc[m] = (sb[0][0][m] + sb[0][1][m]) + (sb[1][0][m] + sb[1][1][m]);
+    nlk_match_select<PSZ, CH, M>(acc, wxy, n, k, x0, y0, surv, sel, lane);
+    return;
   }
 #pragma unroll 1
   for (int hy = 0; hy < PSZ; ++hy) {
@@ -291,6 +324,72 @@ __device__ __forceinline__ void nlk_match_block(const float* __restrict__ tile, 
   nlk_block_rows<PSZ, CH, BX, M, false, true>(tile, plane, rwp, tbase, cq, PSZ, PSZ + step, acc, timg, w, npix);
 }
 
+// ---- The opt-in BLOCK-SUMMED order (round 6; NLK_MATCH_ORDER=block, never the default).
+// The grid step is half a patch, so a patch is 2 x 2 quarter patches of step x step pixels ALIGNED with the grid, and
+// a quarter patch belongs to the four targets around it. Its sum of squared differences for a candidate offset is
+// computed ONCE - rows ascending, columns ascending, channels innermost, one fused multiply-add per term - and a
+// target's distance is (s00 + s01) + (s10 + s11) of its four quarters: the additions are shared too, not only the
+// subtractions and multiplications (per target and candidate of a 2 x 2 block: 9/4 quarters x 48 terms x {sub, fma}
+// = 216 vector operations + 3 adds against 408 in the exact order). This is NOT the reference's (hy, hx, c) order:
+// the distances differ from the exact mode's in their last bits (the reference binary itself is built -ffast-math
+// and promises no order, CMakeLists.txt:10), the k-NN lists where two candidates are within those bits
+// (tests/test_gpu_parity.py::test_block_summed_match_order). Every path - blocks, single targets, k_bm_wide -
+// uses the same quarters, so the result does not depend on tiles, strips or bands.
+template <int PSZ, int CH, int BX, int M>
+__device__ __forceinline__ void nlk_match_block_sum(const float* __restrict__ tile, int plane, int rwp, int tbase,
+                                                    int wsz, int n, int lane, float (&acc)[2][BX][M],
+                                                    const float* __restrict__ timg, int w, size_t npix) {
+  constexpr int step = PSZ / 2, NSX = BX + 1, UW = NSX * step;
+  const int nwx = 2 * wsz + 1;
+  int cq[M];
+  float sb[3][NSX][M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int i = min(lane + 64 * m, n - 1);
+    const int wy = i / nwx, wx = i - wy * nwx;
+    cq[m] = tbase + (wy - wsz) * rwp + (wx - wsz);
+#pragma unroll
+    for (int sy = 0; sy < 3; ++sy)
+#pragma unroll
+      for (int sx = 0; sx < NSX; ++sx) sb[sy][sx][m] = 0.f;
+  }
+  const float* splane[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) splane[c] = timg + c * npix;
+#pragma unroll
+  for (int sy = 0; sy < 3; ++sy) {
+#pragma unroll 1
+    for (int ry = sy * step; ry < (sy + 1) * step; ++ry) {
+      const int soff = ry * w;
+      float tvs[CH][UW];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const float* srow = splane[c] + soff;
+#pragma unroll
+        for (int rx = 0; rx < UW; ++rx) tvs[c][rx] = srow[rx];
+      }
+#pragma unroll
+      for (int rx = 0; rx < UW; ++rx)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const float tv = tvs[c][rx];
+#pragma unroll
+          for (int m = 0; m < M; ++m) {
+            const float e = tile[c * plane + cq[m] + ry * rwp + rx] - tv;
+            sb[sy][rx / step][m] = fmaf(e, e, sb[sy][rx / step][m]);
+          }
+        }
+    }
+  }
+#pragma unroll
+  for (int by = 0; by < 2; ++by)
+#pragma unroll
+    for (int bx = 0; bx < BX; ++bx)
+#pragma unroll
+      for (int m = 0; m < M; ++m)
+        acc[by][bx][m] = (sb[by][bx][m] + sb[by][bx + 1][m]) + (sb[by + 1][bx][m] + sb[by + 1][bx + 1][m]);
+}
+
 // Group membership, records and mark word of one target whose sorted k-NN list is in sel[0..k)
 // (reference: src/nlkalman.c:725-732, 779-793, 857, 931; smoother :1669-1676, :1844).
 // STEP = grid step when known at compile time (no integer divisions), 0 = g.step.
@@ -366,7 +465,8 @@ __device__ __forceinline__ void nlk_match_epilogue(const NlkGeom& g, size_t t, i
 #ifndef NLK_BM7_WAVES
 #define NLK_BM7_WAVES 4
 #endif
-template <int PSZ, int CH, int MAXM, int BX = 4>  // BX x 2 targets per block (2: twice the wavefronts on the same tile)
+// ORD: 0 = the reference's (hy, hx, c) summation order (bit-identical distances), 1 = block-summed (opt-in, above)
+template <int PSZ, int CH, int MAXM, int BX = 4, int ORD = 0>  // BX x 2 targets per block (2: twice the wavefronts on the same tile)
 __global__ void __launch_bounds__(512, MAXM == 7 ? (BX == 2 ? NLK_BM7_WAVES : 3) : ((MAXM == 2 && PSZ == 8) ? 8 : 2))  // (7 rounds in blocks: 168 registers, the LDS tile allows 3 wavefronts per SIMD)
 k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGeom g,
           NlkTile tl, uint32_t* __restrict__ topk, NlkTarget* __restrict__ tinfo,
@@ -486,15 +586,15 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
       // target patch from the LDS tile too (scalar loads from the image measured 6 % slower)
       const float* tl_tgt = tile + (py - ry0) * rwp + (px - rx0);
       if (n <= 128)
-        nlk_match_target<PSZ, CH, 2>(tile, plane, rwp, tl_tgt, plane, rwp, cbase, nwx, n, k, x0,
-                                     y0, surv, sel, lane);
+        nlk_match_target<PSZ, CH, 2, ORD>(tile, plane, rwp, tl_tgt, plane, rwp, cbase, nwx, n, k, x0,
+                                          y0, surv, sel, lane);
       else if (MAXM <= 7 || n <= 448)
-        nlk_match_target<PSZ, CH, (MAXM < 7 ? MAXM : 7)>(tile, plane, rwp, tl_tgt, plane, rwp,
-                                                         cbase, nwx, n, k, x0, y0, surv,
-                                                         sel, lane);
+        nlk_match_target<PSZ, CH, (MAXM < 7 ? MAXM : 7), ORD>(tile, plane, rwp, tl_tgt, plane, rwp,
+                                                              cbase, nwx, n, k, x0, y0, surv,
+                                                              sel, lane);
       else
-        nlk_match_target<PSZ, CH, MAXM>(tile, plane, rwp, tl_tgt, plane, rwp, cbase, nwx, n, k,
-                                        x0, y0, surv, sel, lane);
+        nlk_match_target<PSZ, CH, MAXM, ORD>(tile, plane, rwp, tl_tgt, plane, rwp, cbase, nwx, n, k,
+                                             x0, y0, surv, sel, lane);
     } else {
       // window leaves the LDS region (a target without a valid previous patch in a
       // temporal frame): queued for k_bm_wide, which stages a window of its own
@@ -542,8 +642,12 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
     auto run_block = [&](auto mtag) {
       constexpr int M = decltype(mtag)::value;
       float acc[2][BX][M];
-      nlk_match_block<PSZ, CH, BX, M>(tile, plane, rwp, (py0 - ry0) * rwp + (px0 - rx0), wsz, n, lane, acc,
-                                      img + (size_t)py0 * g.w + px0, g.w, (size_t)g.w * g.h);
+      if constexpr (ORD == 1)
+        nlk_match_block_sum<PSZ, CH, BX, M>(tile, plane, rwp, (py0 - ry0) * rwp + (px0 - rx0), wsz, n, lane, acc,
+                                            img + (size_t)py0 * g.w + px0, g.w, (size_t)g.w * g.h);
+      else
+        nlk_match_block<PSZ, CH, BX, M>(tile, plane, rwp, (py0 - ry0) * rwp + (px0 - rx0), wsz, n, lane, acc,
+                                        img + (size_t)py0 * g.w + px0, g.w, (size_t)g.w * g.h);
       // (the window positions are only needed by the selection: worked out AFTER the row loops - carried through
       // them they were spilled to scratch at the 64-register budget, 85 MB of traffic per 1080p launch in round 3;
       // the asm keeps the compiler from hoisting the division back in front of the loops)
@@ -583,7 +687,7 @@ k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
 // Targets whose window does not fit the tile of k_bm_topk (queued there): one
 // wavefront per target stages the target's own window (patch + 2*wsz) in a
 // private LDS region and runs the same distance / selection / epilogue code.
-template <int PSZ, int CH, int MAXM>
+template <int PSZ, int CH, int MAXM, int ORD = 0>
 __global__ void __launch_bounds__(NLK_BM_THREADS)
 k_bm_wide(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGeom g, NlkTile tl,
           uint32_t* __restrict__ topk, NlkTarget* __restrict__ tinfo,
@@ -634,14 +738,14 @@ k_bm_wide(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGe
     nlk_wave_lds_fence();
     const float* tl_tgt = tile + (py - y0) * rwp + (px - x0);
     if (n <= 128)
-      nlk_match_target<PSZ, CH, 2>(tile, plane, rwp, tl_tgt, plane, rwp, 0, nwx, n, k, x0, y0, surv,
-                                   sel, lane);
+      nlk_match_target<PSZ, CH, 2, ORD>(tile, plane, rwp, tl_tgt, plane, rwp, 0, nwx, n, k, x0, y0, surv,
+                                        sel, lane);
     else if (MAXM <= 7 || n <= 448)
-      nlk_match_target<PSZ, CH, (MAXM < 7 ? MAXM : 7)>(tile, plane, rwp, tl_tgt, plane, rwp, 0, nwx,
-                                                       n, k, x0, y0, surv, sel, lane);
+      nlk_match_target<PSZ, CH, (MAXM < 7 ? MAXM : 7), ORD>(tile, plane, rwp, tl_tgt, plane, rwp, 0, nwx,
+                                                            n, k, x0, y0, surv, sel, lane);
     else
-      nlk_match_target<PSZ, CH, MAXM>(tile, plane, rwp, tl_tgt, plane, rwp, 0, nwx, n, k, x0, y0,
-                                      surv, sel, lane);
+      nlk_match_target<PSZ, CH, MAXM, ORD>(tile, plane, rwp, tl_tgt, plane, rwp, 0, nwx, n, k, x0, y0,
+                                           surv, sel, lane);
     nlk_match_epilogue<PSZ / 2>(g, t, px, py, prev_p, k, sel, grp, vmap, topk, tinfo, gcoords, marks, lane);
     __builtin_amdgcn_wave_barrier();
   }

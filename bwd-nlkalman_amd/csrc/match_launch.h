@@ -8,12 +8,12 @@
 namespace {
 
 
-template <int PSZ, int CH, int MAXM>
+template <int PSZ, int CH, int MAXM, int ORD>
 int launch_match_t(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds,
                    const float* img, bool wide) {
-  auto kern = wide ? k_bm_wide<PSZ, CH, MAXM> : k_bm_topk<PSZ, CH, MAXM>;
+  auto kern = wide ? k_bm_wide<PSZ, CH, MAXM, ORD> : k_bm_topk<PSZ, CH, MAXM, 4, ORD>;
   if constexpr (PSZ >= 8 && (MAXM == 2 || (MAXM == 7 && PSZ == 8)))
-    if (!wide && tl.bx == 2) kern = k_bm_topk<PSZ, CH, MAXM, 2>;
+    if (!wide && tl.bx == 2) kern = k_bm_topk<PSZ, CH, MAXM, 2, ORD>;
   HIPCHK(c, hipFuncSetAttribute((const void*)kern,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // k_bm_wide: the queue length is only known on the device, so a fixed grid strides over it
@@ -26,19 +26,19 @@ int launch_match_t(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds,
   return NLK_OK;
 }
 
-template <int PSZ, int CH>
+template <int PSZ, int CH, int ORD>
 int launch_match_m(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds,
                    const float* img, int maxm, bool wide) {
-  if (maxm <= 2) return launch_match_t<PSZ, CH, 2>(c, g, tl, lds, img, wide);
-  if (maxm <= 7) return launch_match_t<PSZ, CH, 7>(c, g, tl, lds, img, wide);
-  return launch_match_t<PSZ, CH, 16>(c, g, tl, lds, img, wide);
+  if (maxm <= 2) return launch_match_t<PSZ, CH, 2, ORD>(c, g, tl, lds, img, wide);
+  if (maxm <= 7) return launch_match_t<PSZ, CH, 7, ORD>(c, g, tl, lds, img, wide);
+  return launch_match_t<PSZ, CH, 16, ORD>(c, g, tl, lds, img, wide);
 }
 
 
-template <int PSZ>
+template <int PSZ, int ORD = 0>
 int launch_match_psz(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds, const float* img, int maxm, bool wide) {
-  if (g.ch == 1) return launch_match_m<PSZ, 1>(c, g, tl, lds, img, maxm, wide);
-  if (g.ch == 3) return launch_match_m<PSZ, 3>(c, g, tl, lds, img, maxm, wide);
+  if (g.ch == 1) return launch_match_m<PSZ, 1, ORD>(c, g, tl, lds, img, maxm, wide);
+  if (g.ch == 3) return launch_match_m<PSZ, 3, ORD>(c, g, tl, lds, img, maxm, wide);
   return fail(c, NLK_EUNSUP, "%d channels not supported (1 or 3)", g.ch);
 }
 
@@ -48,4 +48,10 @@ int launch_match_psz(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds
   int nlk_launch_match_p##P(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds, const float* img,    \
                             int maxm, bool wide) {                                                            \
     return launch_match_psz<P>(c, g, tl, lds, img, maxm, wide);                                               \
+  }
+// the same launcher for the opt-in block-summed distance order (k_match.h: nlk_match_block_sum; tu_match_f.hip)
+#define NLK_MATCH_PSZ_BS(P)                                                                                   \
+  int nlk_launch_match_p##P##_bs(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds, const float* img, \
+                                 int maxm, bool wide) {                                                       \
+    return launch_match_psz<P, 1>(c, g, tl, lds, img, maxm, wide);                                            \
   }

@@ -557,6 +557,9 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   }
   tl.ntx = (g.ngx + tl.tgx - 1) / tl.tgx;
   tl.block = nlk_set(c->sw.match_noblock) ? 0 : (nlk_set(c->sw.match_block) ? 1 : !small_grid);
+  // the opt-in block-summed distance order (NLK_MATCH_ORDER=block; 8 x 8 patches, k_bm_topk / k_bm_wide); everything
+  // else - and the default - sums in the reference's order
+  tl.order = (nlk_or(c->sw.match_order, 0) == 1 && g.psz == 8) ? 1 : 0;
   // LDS holds the halo of the dominant window; its row stride = window width
   // (mod 32): candidate i of a window then sits on bank i mod 32, so a
   // wavefront's 64 candidate reads are conflict free

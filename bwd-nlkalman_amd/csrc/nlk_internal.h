@@ -47,7 +47,7 @@ struct NlkRecView {
   X(deterministic, "NLK_DETERMINISTIC") X(generic_group, "NLK_GENERIC_GROUP") X(group_packed, "NLK_GROUP_PACKED") \
   X(group_dpp, "NLK_GROUP_DPP") X(group_sep, "NLK_GROUP_SEP") X(group_ilp, "NLK_GROUP_ILP") X(generic_match, "NLK_GENERIC_MATCH") X(mtx, "NLK_MTX") X(mty, "NLK_MTY")    \
   X(match_wg8, "NLK_MATCH_WG8") X(match_bx2, "NLK_MATCH_BX2") X(match_block, "NLK_MATCH_BLOCK")              \
-  X(match_noblock, "NLK_MATCH_NOBLOCK") X(commit_wave, "NLK_COMMIT_WAVE") X(commit_lds, "NLK_COMMIT_LDS")    \
+  X(match_noblock, "NLK_MATCH_NOBLOCK") X(match_order, "NLK_MATCH_ORDER") X(commit_wave, "NLK_COMMIT_WAVE") X(commit_lds, "NLK_COMMIT_LDS")    \
   X(commit_band, "NLK_COMMIT_BAND") X(no_chase, "NLK_NO_CHASE") X(chase_test_skip0, "NLK_CHASE_TEST_SKIP0") X(bands, "NLK_BANDS") X(host_bands, "NLK_HOST_BANDS")                    \
   X(host_trace, "NLK_HOST_TRACE") X(gtx, "NLK_GTX") X(gty, "NLK_GTY") X(g8_tail, "NLK_G8_TAIL")              \
   X(g8_single, "NLK_G8_SINGLE") X(tv_wg_pixels, "NLK_TV_WG_PIXELS") X(tv_unblocked, "NLK_TV_UNBLOCKED")      \
@@ -61,6 +61,8 @@ struct NlkSwitches {
 #define NLK_X(field, name) { const char* e_ = getenv(name); field = e_ ? atoi(e_) : NLK_UNSET; }
     NLK_SWITCH_LIST(NLK_X)
 #undef NLK_X
+    // NLK_MATCH_ORDER = exact | block (or 0 | 1): the summation order of the patch distances (k_match.h)
+    if (const char* e_ = getenv("NLK_MATCH_ORDER")) match_order = (!strcmp(e_, "block") || atoi(e_) == 1) ? 1 : 0;
   }
 };
 static inline bool nlk_set(int v) { return v != NLK_UNSET; }                 // the variable exists (any value)

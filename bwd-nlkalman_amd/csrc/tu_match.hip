@@ -7,9 +7,11 @@
 #define NLK_MATCH_DECL(P) \
   int nlk_launch_match_p##P(nlk_ctx*, const NlkGeom&, const NlkTile&, size_t, const float*, int, bool);
 NLK_MATCH_DECL(4) NLK_MATCH_DECL(6) NLK_MATCH_DECL(8) NLK_MATCH_DECL(10) NLK_MATCH_DECL(12) NLK_MATCH_DECL(16)
+int nlk_launch_match_p8_bs(nlk_ctx*, const NlkGeom&, const NlkTile&, size_t, const float*, int, bool);  // tu_match_f.hip
 
 int nlk_launch_match(nlk_ctx* c, const NlkGeom& g, const NlkTile& tl, size_t lds, const float* img,
                      int maxm, bool wide) {
+  if (tl.order == 1 && g.psz == 8) return nlk_launch_match_p8_bs(c, g, tl, lds, img, maxm, wide);
   switch (g.psz) {
     case 4: return nlk_launch_match_p4(c, g, tl, lds, img, maxm, wide);
     case 6: return nlk_launch_match_p6(c, g, tl, lds, img, maxm, wide);

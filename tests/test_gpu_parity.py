@@ -714,6 +714,103 @@ def test_group_kernel_dct_forms_agree(ctx, built, synth, monkeypatch):
     monkeypatch.delenv("NLK_GROUP_SEP", raising=False)
 
 
+def _patch_dist64(img, px, py, q, psz=8):
+    """squared patch distance in float64 (mean over the patch and the channels), q = array of packed x | y << 16"""
+    a = img[py:py + psz, px:px + psz].astype(np.float64)
+    out = np.empty(len(q))
+    for i, v in enumerate(q):
+        x, y = int(v) & 0xFFFF, int(v) >> 16
+        d = img[y:y + psz, x:x + psz].astype(np.float64) - a
+        out[i] = (d * d).mean()
+    return out
+
+
+def test_block_summed_match_order(ctx, built, synth, monkeypatch):
+    """NLK_MATCH_ORDER=block (opt-in, never the default): the matcher sums a patch distance as four quarter-patch
+    sums shared between the targets that hold them (k_match.h: nlk_match_block_sum) instead of in the reference's
+    (hy, hx, c) order. The k-NN SETS may then differ from the exact mode's only where two candidates' distances are
+    within float-summation noise of each other; whatever path computes a distance - blocks of targets, single
+    targets, clipped windows, other tile shapes - gives the same bits; and the filtered frame keeps its PSNR."""
+    w, h, ch, sigma = 640, 360, 3, 20.0
+    n0, n1, c1 = synth.noisy_pair(w, h, ch, sigma, 11)
+    o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+    p1 = built.default_params(sigma, built.FLT1)
+    step = p1.patch_sz // 2
+    ngx = (w - p1.patch_sz) // step + 1
+
+    def run():
+        f0, r0 = _dev_frame(ctx, False, o0, None, None, sigma, p1)
+        hole = f0.copy()
+        hole[100:140, 200:300] = np.nan                        # spatial-branch targets in the temporal frame (k_bm_wide)
+        f1, r1 = _dev_frame(ctx, False, o1, hole, None, sigma, p1)
+        return f0, r0, f1, r1, hole
+
+    monkeypatch.delenv("NLK_MATCH_ORDER", raising=False)
+    e = run()
+    monkeypatch.setenv("NLK_MATCH_ORDER", "block")
+    b = run()
+    # the same bits from every path in block order: target by target, and the small-grid tiles
+    monkeypatch.setenv("NLK_MATCH_NOBLOCK", "1")
+    b2 = run()
+    monkeypatch.delenv("NLK_MATCH_NOBLOCK", raising=False)
+    monkeypatch.setenv("NLK_MTX", "4")
+    monkeypatch.setenv("NLK_MTY", "2")
+    b3 = run()
+    monkeypatch.delenv("NLK_MTX", raising=False)
+    monkeypatch.delenv("NLK_MTY", raising=False)
+    for other, what in ((b2, "target by target"), (b3, "4 x 2 tiles")):
+        for ri in (1, 3):
+            for f in ("nsel", "np0", "nagg", "topk", "gcoords"):
+                assert np.array_equal(b[ri][f], other[ri][f]), f"block order, {what}: {f} differs from the block path"
+    monkeypatch.delenv("NLK_MATCH_ORDER", raising=False)
+
+    worst, ndiff, ntargets = 0.0, 0, 0
+    for img, prev_in, re_, rb_ in ((o0, None, e[1], b[1]), (o1, e[4], e[3], b[3])):
+        assert np.array_equal(re_["nsel"], rb_["nsel"])
+        for t in range(len(re_["nsel"])):
+            k = int(re_["nsel"][t])
+            se, sb_ = re_["topk"][t, :k], rb_["topk"][t, :k]
+            ntargets += 1
+            if np.array_equal(np.sort(se), np.sort(sb_)):
+                continue
+            ndiff += 1
+            gy, gx = divmod(t, ngx)
+            only = np.concatenate([np.setdiff1d(se, sb_), np.setdiff1d(sb_, se)])
+            d_only = _patch_dist64(img, gx * step, gy * step, only)
+            d_kth = _patch_dist64(img, gx * step, gy * step, se).max()
+            worst = max(worst, float(np.abs(d_only - d_kth).max() / max(d_kth, 1e-30)))
+    print(f"block-summed order: {ndiff} of {ntargets} k-NN sets differ; the exchanged candidates lie within "
+          f"{worst:.2e} (relative) of the k-th distance")
+    assert ndiff <= ntargets // 50
+    assert worst <= 2e-5   # a float32 sum of 192 terms: a few ulp
+    # the frames: same quality
+    for fe, fb, what in ((e[0], b[0], "spatial"), (e[2], b[2], "temporal")):
+        assert np.isfinite(fb).all()
+        pe, pb = synth.psnr(built.opp2rgb(fe), c1 if what == "temporal" else synth.clean_frame(w, h, ch, 0)), \
+            synth.psnr(built.opp2rgb(fb), c1 if what == "temporal" else synth.clean_frame(w, h, ch, 0))
+        assert abs(pe - pb) <= 0.02, f"block order, {what}: PSNR {pb:.4f} against {pe:.4f}"
+
+
+def test_block_summed_match_order_psnr_1080p(ctx, built, synth, monkeypatch):
+    """|dPSNR| <= 0.02 dB at C2 (1920x1080x3, sigma 20, FLT1 temporal) between the exact and the block-summed order."""
+    w, h, ch, sigma = 1920, 1080, 3, 20.0
+    n0, n1, c1 = synth.noisy_pair(w, h, ch, sigma, 1)
+    o0, o1 = built.rgb2opp(n0), built.rgb2opp(n1)
+    p1 = built.default_params(sigma, built.FLT1)
+    out = {}
+    for order in ("exact", "block"):
+        monkeypatch.setenv("NLK_MATCH_ORDER", order)
+        f0, _ = _dev_frame(ctx, False, o0, None, None, sigma, p1)
+        f1, rec = _dev_frame(ctx, False, o1, f0, None, sigma, p1)
+        out[order] = (synth.psnr(built.opp2rgb(f1), c1), rec)
+    monkeypatch.delenv("NLK_MATCH_ORDER", raising=False)
+    same = sum(np.array_equal(np.sort(a[:k]), np.sort(b[:k])) for a, b, k in
+               zip(out["exact"][1]["topk"][::37], out["block"][1]["topk"][::37], out["exact"][1]["nsel"][::37]))
+    print(f"PSNR exact {out['exact'][0]:.4f} dB, block {out['block'][0]:.4f} dB; "
+          f"{same} of {len(out['exact'][1]['nsel'][::37])} sampled k-NN sets identical")
+    assert abs(out["exact"][0] - out["block"][0]) <= 0.02
+
+
 def test_group_kernels_agree_matrix_vs_dpp(ctx, built, synth, monkeypatch):
     """The 8x8 group kernel has two implementations: k_group8m (DCTs on the f32
     matrix cores, the default) and k_group8 (registers + DPP, NLK_GROUP_DPP=1).
