@@ -160,9 +160,8 @@ def c5_roofline(c5, w, h, ch, psz, ngrid, ps):
     dur = tm["group_ms"] * 1e-3
     k = ps.npatches_t
     alg_bytes = 2 * w * h * ch * 4 + (ch + 1) * w * h * 4 + ngrid * k * 4
-    sep = os.environ.get("NLK_GROUP_SEP", "2" if ch == 1 else "0")
-    unit = 1 if ch == 3 and sep == "0" and os.environ.get("NLK_GROUP_ILP", "1") != "0" else 0
-    inst = f"k_group8m<{ch}, true, {sep}, {unit}>"
+    sep = os.environ.get("NLK_GROUP_SEP", "2")   # (tu_group8.hip: the separable pass B on the difference image)
+    inst = f"k_group8m<{ch}, true, {sep}, 0>"
     traffic, traffic_note = measured_traffic("C5", inst)
     tfl = group_flops / dur / 1e12 if dur > 0 else 0.0
     chain = sum(c5[n_]["ms"]["total_ms"] for n_ in c5)

@@ -11,7 +11,8 @@ k_layout(const float* __restrict__ cur, float* __restrict__ pl_cur, const float*
          float* __restrict__ pl_prev, const float* __restrict__ basic, float* __restrict__ pl_basic,
          uint8_t* __restrict__ rowok, float* __restrict__ acc_zero, int w, int h, int ch, int psz, int planar,
          int y0,    // (rows y0 .. y0 + gridDim.y - 1: a frame that arrives from the host in row bands)
-         uint32_t* __restrict__ zero_word) {  // one more word to clear (the wide-window queue's length), or nullptr
+         uint32_t* __restrict__ zero_word,    // one more word to clear (the wide-window queue's length), or nullptr
+         float* __restrict__ pl_diff) {       // smoother calls: planar prev - cur (k_group8m's pass B reads one image instead of two), or nullptr
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = y0 + blockIdx.y;
   if (zero_word && x == 0 && blockIdx.y == 0) *zero_word = 0u;
   if (x >= w) return;
@@ -21,6 +22,7 @@ k_layout(const float* __restrict__ cur, float* __restrict__ pl_cur, const float*
       pl_cur[c * npix + i] = cur[i * ch + c];
       if (prev) pl_prev[c * npix + i] = prev[i * ch + c];
       if (basic) pl_basic[c * npix + i] = basic[i * ch + c];
+      if (pl_diff) pl_diff[c * npix + i] = prev[i * ch + c] - cur[i * ch + c];
     }
   }
   if (prev) {

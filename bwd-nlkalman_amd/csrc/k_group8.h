@@ -61,6 +61,7 @@ struct NlkGTile {
   // k_group8m: start of the allocation that holds every planar image of the call (nlk_ctx::planes, < 4 GiB):
   // patches are addressed as this base + a 32-bit byte offset
   const float* pbase;
+  const float* diff;   // k_group8m, smoother: planar (previous - image) inside the same slab, or nullptr (then the kernel subtracts)
   // k_group8m, mask replay inside the launch (chase != 0): workgroup 0 first replays the processed mask of the grid
   // rows [0, chase_rows) from the bit planes (k_commit_rows.h) and publishes every row's decisions as
   // generation-tagged words; every workgroup polls the words of its own targets instead of reading `active`.

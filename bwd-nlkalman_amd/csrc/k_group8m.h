@@ -514,7 +514,12 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         return live ? (oc & 0x7fffffffu) + e_slot : e_dead;
       };
       // rows g4 and 7-g4 of the patch at element offset `off` (plane 0) of channel cc
+      bool rows_first = true;
       auto rows_read = [&](uint32_t off, int cc, float (&R)[16]) {
+#ifdef NLK_G8_EXP_NOROWS   // (timing experiment: only the first step's rows are loaded - what any prefetch scheme could gain at most)
+        if (!rows_first) { asm volatile("" : "+v"(R[0]), "+v"(R[5]), "+v"(R[10]), "+v"(R[15]) : "v"(off)); return; }
+        rows_first = false;
+#endif
         nlk_rows_load32(pbase, off + (uint32_t)cc * (uint32_t)npix, rowa, rowb, R);
       };
       float R[16], F[4][4];
@@ -907,13 +912,16 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       const uint32_t qm = nlk_bperm_u(n < 64 ? greg[0] : greg[1], n & 63);
       return (uint32_t)bchc * (uint32_t)npix + (uint32_t)(nlk_y(qm) * g.w + nlk_x(qm));
     };
-    const uint32_t e_psrc = passthrough ? e_src : e_prev;  // (smoother) previous-frame patches
-    float R[16], Rp[16], F[4][4];
-    {
-      const uint32_t off = member_off(0);
-      nlk_rows_load32(pbase, e_src + off, rowaB, rowbB, R);
-      if (SMO) nlk_rows_load32(pbase, e_psrc + off, rowaB, rowbB, Rp);
-    }
+    // (smoother) the difference image previous - image laid out with the frame (k_layout): ONE row set per member
+    // instead of two, no subtraction here - the same float operation on the same operands, done once per pixel.
+    // Pass B of the smoother loads 8 x 16 bytes per lane and step, every lane from cache lines of its own: the
+    // vector L1 (~2 lines a cycle) is what the separable form's shorter steps waited for (round 6: SMO1 group
+    // 1.316 ms -> 1.097 with these loads compiled out; the Kronecker form 1.278 -> 1.236).
+    // (Without a previous frame there is no difference image and every target is passed through: its coefficients
+    // are set to zero below whatever was loaded - the image's own rows then.)
+    const uint32_t e_bsrc = (SMO && tl.diff) ? (uint32_t)(tl.diff - pbase) : e_src;
+    float R[16], F[4][4];
+    nlk_rows_load32(pbase, e_bsrc + member_off(0), rowaB, rowbB, R);
     uint32_t offn = member_off(MPS);
     // Where every member lands in the tile, worked out once per target with one member per lane: its offset
     // (floats) inside a plane, and one bit per member "inside the tile" (entries past the last member count as
@@ -945,21 +953,21 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     constexpr int QST = SEPB ? 4 : 16;
     for (int n0 = 0; n0 < nagg; n0 += MPS) {
       nlk_f4 Y[4];
-      if (SMO) {
-        // The smoother's update (1 - a) A + a B of a member's coefficients (A image, B previous frame,
-        // reference: :1775) is A + a (B - A), and every step from here to the frame is linear: the member's
-        // pixels are its image patch + IDCT(a . DCT(previous patch - image patch)), and the image patches,
-        // added with the members' weights, sum to image x weight plane. So only the SECOND term goes through
-        // the transforms - one forward transform of the pixel difference instead of two - and the image term is
-        // added where the tile leaves for the frame (the flush below): image x the tile's weight plane.
-#pragma unroll
-        for (int c = 0; c < 16; ++c) R[c] = Rp[c] - R[c];
-      }
+      // The smoother's update (1 - a) A + a B of a member's coefficients (A image, B previous frame,
+      // reference: :1775) is A + a (B - A), and every step from here to the frame is linear: the member's
+      // pixels are its image patch + IDCT(a . DCT(previous patch - image patch)), and the image patches,
+      // added with the members' weights, sum to image x weight plane. So only the SECOND term goes through
+      // the transforms - one forward transform of the pixel difference (R holds it: the difference image) instead
+      // of two - and the image term is added where the tile leaves for the frame (the flush below): image x the
+      // tile's weight plane.
       nlk_fold(R, F);
-      nlk_rows_load32(pbase, e_src + offn, rowaB, rowbB, R);
+#ifdef NLK_G8_EXP_NOROWSB   // (timing experiment: pass B's rows loaded once per target)
+      asm volatile("" : "+v"(R[0]), "+v"(R[5]), "+v"(R[10]), "+v"(R[15]) : "v"(offn));
+#else
+      nlk_rows_load32(pbase, e_bsrc + offn, rowaB, rowbB, R);
+#endif
 #pragma unroll
       for (int q = 0; q < 4; ++q) Y[q] = nlk_f4{0.f, 0.f, 0.f, 0.f};
-      if (SMO) nlk_rows_load32(pbase, e_psrc + offn, rowaB, rowbB, Rp);
       offn = member_off(n0 + 2 * MPS);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (SEPB) {

@@ -388,6 +388,7 @@ int nlk_dev_warp_bicubic(nlk_ctx* c, float* imw, const float* im, const float* o
 struct NlkPlan {
   NlkGeom g{};                   // the whole call: target rows [0, g.ngy) from image row g.oy
   const float *img_cur = nullptr, *img_prev = nullptr, *img_basic = nullptr, *img_match = nullptr;
+  const float* img_diff = nullptr;   // smoother calls: planar prev - cur
   NlkTile tl{}, tw{};            // match tiles: dominant window / wide window
   size_t lds = 0, lds_w = 0;
   int maxm = 0, maxm_w = 0;
@@ -428,7 +429,7 @@ static int layout_rows(nlk_ctx* c, const float* cur, const float* prev, const fl
   if (y1 > y0)
     hipLaunchKernelGGL(k_layout, dim3((w + 255) / 256, y1 - y0), dim3(256), 0, c->stream, cur, slab, prev,
                        slab + img_floats, basic, slab + 2 * img_floats, (uint8_t*)c->rowok.p, acc_zero, w, h, ch, psz,
-                       1, y0, zero_word);
+                       1, y0, zero_word, (c->layout_diff && prev) ? slab + 3 * img_floats : nullptr);
   if (prev && v1 > v0) {
     if (w % 4 == 0)
       hipLaunchKernelGGL(k_nan_cols4, dim3((w / 4 + 255) / 256, v1 - v0), dim3(256), 0, c->stream,
@@ -498,7 +499,11 @@ static int plan_frame(nlk_ctx* c, NlkPlan& pl, const float* cur, const float* pr
   {
     // planar copies of the (up to) three images in ONE allocation: [cur | prev | basic]
     const size_t img_floats = (size_t)npix * ch;
-    if ((rc = reserve(c, c->planes, sizeof(float) * img_floats * (basic ? 3 : (prev ? 2 : 1))))) return rc;
+    // (a smoother call keeps a fourth image, prev - cur: what the pass B of k_group8m<.., true, ..> transforms)
+    c->layout_diff = g.smoother && prev != nullptr;
+    if ((rc = reserve(c, c->planes, sizeof(float) * img_floats * (c->layout_diff ? 4 : (basic ? 3 : (prev ? 2 : 1)))))) return rc;
+    pl.img_diff = c->layout_diff ? (const float*)c->planes.p + 3 * img_floats : nullptr;
+    c->p_diff = pl.img_diff;
     pl.img_cur = (const float*)c->planes.p;
     pl.img_prev = prev ? pl.img_cur + img_floats : nullptr;
     pl.img_basic = basic ? pl.img_cur + 2 * img_floats : nullptr;

@@ -103,6 +103,8 @@ struct nlk_ctx {
   NlkGeom last{};
   bool have_last = false;
   const float *p_match = nullptr, *p_cur = nullptr, *p_prev = nullptr;  // planar images of the last match phase
+  const float* p_diff = nullptr;   // ... and of a smoother call: planar prev - cur (k_layout), else nullptr
+  bool layout_diff = false;        // the call being laid out keeps that image
   // profiling: one set of NEV events per frame call, read back (and averaged)
   // only by nlk_ctx_get_timings, so the timed loop never synchronises
   static constexpr int NEV = 7, MAXSETS = 512;

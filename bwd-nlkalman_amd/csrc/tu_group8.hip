@@ -25,7 +25,10 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
   // Single-channel frames (`r05_mode_times_1080p_gray_by_sep.txt`; the separable pass B packs 16 members per step
   // there): FLT1 temporal 0.514 (Kronecker) / 0.404 (2) / 0.393 (6), first frame 0.594 / 0.487 / 0.482, the smoother
   // 0.926 / 0.547 / 0.576, FLT2 0.315 / 0.331 / 0.358.
-  const int sep_default = g.ch == 1 ? (g.ntagg < 4 ? 0 : (g.smoother ? 2 : 6)) : ((g.smoother || g.ntagg < 4) ? 0 : 2);
+  // Round 6: the smoother's pass B reads the difference image previous - image (k_layout) - one row set per member
+  // instead of two - and with half the cache lines to fetch the separable pass B wins there too: SMO1 group at 1080p
+  // RGB 1.287 ms (Kronecker, two row sets) -> 1.234 (Kronecker, difference image) -> 1.101 (separable pass B).
+  const int sep_default = g.ch == 1 ? (g.ntagg < 4 ? 0 : (g.smoother ? 2 : 6)) : (g.ntagg < 4 ? 0 : 2);
   int sep = mfma ? nlk_or(c->sw.group_sep, sep_default) : 0;
   if (sep != 0 && sep != 6) sep = 2;
   // (k_group8m addresses every patch as planes base + a 32-bit byte offset: the call's images must lie in the
@@ -39,6 +42,11 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
       return nlk_launch_groupp_a(c, g, img, cur, prev, acc, active);
     }
   }
+  if (mfma && SMO && prev && !(c->p_diff && cur == c->p_cur && prev == c->p_prev)) {
+    // (the smoother's pass B reads the difference image the layout kernel made of exactly these two images)
+    if (c->rv.chase_words) return fail(c, NLK_EINVAL, "internal: mask replay handed to a group kernel that cannot run it");
+    return nlk_launch_groupp_a(c, g, img, cur, prev, acc, active);
+  }
   if (c->rv.chase_words && (!mfma || c->deterministic))
     return fail(c, NLK_EINVAL, "internal: mask replay handed to a group kernel that cannot run it");
   if (c->deterministic && !mfma)
@@ -50,6 +58,8 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
   auto shape = [&](int pass) {
     NlkGTile tl{};
     tl.pbase = (const float*)c->planes.p;
+    // (the smoother's pass B transforms previous - image: laid out once per call by k_layout; `cur` is what gets filtered)
+    tl.diff = (SMO && prev) ? c->p_diff : nullptr;
     tl.split = split;
     tl.far = pass;
     tl.chase = c->rv.chase_words ? c->rv.chase_reach : 0;
