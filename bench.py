@@ -23,6 +23,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+T_PROCESS_START = __import__("time").time()
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
@@ -413,6 +414,62 @@ def bench_sequence(args, pkg, synth, ctx, torch, rank, world, dev):
     emit(res)
 
 
+def descendants(pid):
+    """Every live descendant of `pid`, children first, from /proc (no psutil needed: ADVICE r5). The ranks of
+    torch.distributed.run sit in sessions of their own, so a killpg of the launcher does not reach them."""
+    kids = {}
+    for d in os.listdir("/proc"):
+        if not d.isdigit():
+            continue
+        try:
+            with open(f"/proc/{d}/stat") as f:
+                st = f.read()
+            ppid = int(st[st.rindex(")") + 2:].split()[1])    # (the command name may hold spaces and parentheses)
+        except (OSError, ValueError, IndexError):
+            continue
+        kids.setdefault(ppid, []).append(int(d))
+    out, todo = [], [pid]
+    while todo:
+        for k in kids.get(todo.pop(), []):
+            out.append(k)
+            todo.append(k)
+    return out
+
+
+def kill_tree(proc):
+    """SIGKILL for `proc` (a Popen started in its own session), its process group and every descendant; says so
+    loudly if somebody survives - fresh ranks must not be started beside ranks that still hold the GPUs."""
+    import signal
+    victims = descendants(proc.pid)
+    try:
+        os.killpg(proc.pid, signal.SIGKILL)
+    except (ProcessLookupError, PermissionError):
+        pass
+    for v in victims:
+        try:
+            os.kill(v, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError):
+            pass
+    deadline = time.time() + 10
+    left = victims
+    while left and time.time() < deadline:
+        left = [v for v in left if os.path.exists(f"/proc/{v}") and "Z" not in _proc_state(v)]
+        if left:
+            time.sleep(0.1)
+    if left:
+        print(f"bench.py: could not end the processes {left}: they may still hold the GPUs", file=sys.stderr)
+    return not left
+
+
+def _proc_state(pid):
+    try:
+        with open(f"/proc/{pid}/stat") as f:
+            st = f.read()
+        return st[st.rindex(")") + 2:].split()[0]
+    except (OSError, ValueError, IndexError):
+        return "Z"
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1
     --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a
@@ -448,21 +505,8 @@ def launch_ranks(args):
         except subprocess.TimeoutExpired:
             # the launcher AND every rank: the ranks may sit in sessions of their own (a killpg of the launcher's
             # group would leave them running, holding the pipe open), so the descendants are collected first
-            victims = []
-            try:
-                import psutil
-                victims = psutil.Process(proc.pid).children(recursive=True)
-            except Exception:                                                # noqa: BLE001
-                pass
-            try:
-                os.killpg(proc.pid, signal.SIGKILL)
-            except (ProcessLookupError, PermissionError):
-                pass
-            for v in victims:
-                try:
-                    v.kill()
-                except Exception:                                            # noqa: BLE001
-                    pass
+            if not kill_tree(proc):
+                raise SystemExit("bench.py: the hung ranks could not be ended: no fresh ranks are started beside them")
             try:
                 out, _ = proc.communicate(timeout=15)
             except subprocess.TimeoutExpired:                                # (somebody still holds the pipe: give it up)
@@ -525,8 +569,34 @@ def run_preflight(rank):
     env = dict(os.environ)
     env.pop("TORCHELASTIC_USE_AGENT_STORE", None)     # (the children's rank 0 hosts their store itself)
     env.pop("NLK_BENCH_STUCK_FILE", None)
-    port = int(env.get("MASTER_PORT", "29500"))
-    env["MASTER_PORT"] = str(20000 + (port * 31 + 7919) % 20000)
+    # The trial's rendezvous port: rank 0 takes a FREE one from the system (bind to port 0) and hands it to the other
+    # ranks through a file named after the launcher they all share (one node: nnodes = 1) - a port computed from
+    # MASTER_PORT could be taken, or be the launcher's own store.
+    port_file = os.path.join(tempfile.gettempdir(), f"nlk_bench_preflight_{os.getppid()}_{env.get('MASTER_PORT', '0')}.port")
+    tport = None
+    if rank == 0:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            tport = sk.getsockname()[1]
+        with open(port_file + ".tmp", "w") as f:
+            f.write(str(tport))
+        os.replace(port_file + ".tmp", port_file)
+    else:
+        t_wait = time.time()
+        while time.time() - t_wait < 60:
+            try:
+                if os.path.getmtime(port_file) >= T_PROCESS_START - 5:
+                    with open(port_file) as f:
+                        tport = int(f.read().strip())
+                    break
+            except (OSError, ValueError):
+                pass
+            time.sleep(0.05)
+    if tport is None:
+        return {"ok": False, "seconds": 0.0, "why": f"rank {rank} did not learn the trial's rendezvous port from rank 0 "
+                                                       "(rendezvous, not the C strip driver)"}
+    env["MASTER_PORT"] = str(tport)
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env["NLK_BENCH_C_TRIAL_TIMEOUT"] = os.environ.get("NLK_BENCH_PREFLIGHT_TRIAL", "60")
     limit = float(os.environ.get("NLK_BENCH_PREFLIGHT_TIMEOUT", 240))
@@ -541,27 +611,20 @@ def run_preflight(rank):
             if rc != 0:
                 why = f"the trial process of rank {rank} ended with status {rc}"
         except subprocess.TimeoutExpired:
-            victims = []
-            try:
-                import psutil
-                victims = psutil.Process(proc.pid).children(recursive=True)
-            except Exception:                                                # noqa: BLE001
-                pass
-            try:
-                os.killpg(proc.pid, signal.SIGKILL)
-            except (ProcessLookupError, PermissionError):
-                pass
-            for v in victims:
-                try:
-                    v.kill()
-                except Exception:                                            # noqa: BLE001
-                    pass
+            kill_tree(proc)
             proc.wait()
             why = f"the trial process of rank {rank} did not finish within {limit:.0f} s and was killed"
         if why:
             errf.seek(0)
             tail = errf.read()[-1500:]
+            if "ddress already in use" in tail or "EADDRINUSE" in tail:
+                why += " (the rendezvous port was taken: a rendezvous failure, not the C strip driver's)"
             sys.stderr.write(f"bench.py: {why}; its last words:\n{tail}\n")
+    if rank == 0:
+        try:
+            os.remove(port_file)
+        except OSError:
+            pass
     return {"ok": why is None, "seconds": round(time.time() - t0, 1), "why": why}
 
 

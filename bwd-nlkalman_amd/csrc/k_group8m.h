@@ -310,7 +310,10 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       // same generation, idempotent, and whoever else is waiting for them sees them too.
       chase_wp = tl.chase_words + (size_t)(tl.chase_row0 + gy0 + ty) * 64 + ((gx0 + tx) >> 5);
       chase_v = __hip_atomic_load(chase_wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int spin = 0; (uint32_t)(chase_v >> 32) != chase_gen && spin < 64; ++spin) {
+      // (the wait grows with the row: the replay reaches row r after ~r x 90 ns, a spin is ~1.2 us - on an 8K-class grid a
+      // fixed 64 spins would make every first-wave workgroup of the lower rows replay for itself: ADVICE r5)
+      const int spin_max = 64 + ((tl.chase_row0 + gy0 + ty) >> 2);
+      for (int spin = 0; (uint32_t)(chase_v >> 32) != chase_gen && spin < spin_max; ++spin) {
         __builtin_amdgcn_s_sleep(16);
         chase_v = __hip_atomic_load(chase_wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -327,7 +330,10 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
   if (tl.chase) {
     if (__ballot(chase_late)) {  // (wave-uniform) self-rescue: the rows down to this tile's last one
       chase_replay(tl.chase_row0 + gy0 + cy);
-      if (lane < cx * cy) chase_v = __hip_atomic_load(chase_wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (the words were stored by other lanes of this wavefront: release after the replay, acquire on the reload -
+      // a formal happens-before instead of relying on the in-order issue of the vector memory instructions)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (lane < cx * cy) chase_v = __hip_atomic_load(chase_wp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (lane < cx * cy) rec_act = ((uint32_t)chase_v >> chase_bit) & 1u;
   }

@@ -413,10 +413,15 @@ float *nlk_read_jpeg(const char *path, const unsigned char *b, size_t n, int *w,
       if (err) break;
       /* the same bound as every other format (imgio.c: sane_size), and the file must be able to hold the image at
          all: a 200-byte header that announces 65500 x 65500 must not make this process allocate 17 GB (inside
-         nlk-server that would take the resident process down). Even an all-zero baseline scan spends about a bit
-         per 8 x 8 block and component. */
-      if ((uint64_t)W * (uint64_t)H * (uint64_t)nc > ((uint64_t)1 << 31) ||
-          ((uint64_t)W * (uint64_t)H / 64) * (uint64_t)nc / 8 > (uint64_t)n + 1024) {
+         nlk-server that would take the resident process down). Every 8 x 8 block of every component costs at least
+         one bit - its DC code, baseline or progressive (a flat progressive file with optimised tables spends little
+         more: its AC scans are end-of-band runs) - so the blocks are counted from the sampling factors (a 4:2:0 file
+         has half the blocks of a 4:4:4 one: ADVICE r5) and the file must hold HALF a bit for each. */
+      uint64_t nblocks = 0;
+      for (int c = 0; c < nc; ++c)
+        nblocks += (uint64_t)((((uint64_t)W * C[c].hs + hmax - 1) / hmax + 7) / 8) *
+                   (uint64_t)((((uint64_t)H * C[c].vs + vmax - 1) / vmax + 7) / 8);
+      if ((uint64_t)W * (uint64_t)H * (uint64_t)nc > ((uint64_t)1 << 31) || nblocks / 16 > (uint64_t)n + 1024) {
         err = "JPEG size is unreasonable for the size of the file";
         break;
       }
