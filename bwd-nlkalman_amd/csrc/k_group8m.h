@@ -380,7 +380,16 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         sG[par][s] = basis[(2 * s + par) * 8 + si];
       }
   }
-  if constexpr (SEP != 6) {
+  // Hybrid form (SEP == 2): the Kronecker operand of pass A is the product of two basis values,
+  // dA[q][s] = C[2 (lo >> 2) + qr][g4] * C[2 (lo & 3) + qc][s] = Er[qr] * sE[qc][s] (lo & 3 == si), so only Er is
+  // kept across the targets and the sixteen products are rebuilt where a target's pass A starts: pass B, which
+  // needs its registers for the second PX buffer of its software pipeline, does not carry them.
+  float Er[2] = {0.f, 0.f};
+  if constexpr (SEP == 2) {
+    Er[0] = basis[(2 * (lo >> 2) + 0) * 8 + g4];
+    Er[1] = basis[(2 * (lo >> 2) + 1) * 8 + g4];
+  }
+  if constexpr (SEP == 0) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int qr = q >> 1, qc = q & 1;
@@ -489,6 +498,14 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       oreg[m] = (uint32_t)(nlk_y(qreg[m]) * g.w + nlk_x(qreg[m])) | ((uint32_t)((vbits[m] >> lane) & 1ull) << 31);
     const uint32_t o_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)oreg[0]) & 0x7fffffffu;
     if constexpr (!SEPA) {
+    if constexpr (SEP == 2) {
+      float e0 = Er[0], e1 = Er[1];
+      asm volatile("" : "+v"(e0), "+v"(e1));  // (per target: the products must not be hoisted out of the target loop)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        dA[q] = nlk_f4{(q >> 1 ? e1 : e0) * sE[q & 1][0], (q >> 1 ? e1 : e0) * sE[q & 1][1],
+                       (q >> 1 ? e1 : e0) * sE[q & 1][2], (q >> 1 ? e1 : e0) * sE[q & 1][3]};
+    }
     float S[6][4];
     nlk_f4 NX0[4];
 #pragma unroll
@@ -957,7 +974,9 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     const float* st_g = stash + bst * SST + (SEPB ? 16 * si : 4 * g4);
     const float* st_m = st_g + 64;
     constexpr int QST = SEPB ? 4 : 16;
-    for (int n0 = 0; n0 < nagg; n0 += MPS) {
+    // One step's transforms: the rows of members n0 .. n0 + MPS - 1 (in R: requested a step ahead) -> PX[m][kk], the
+    // lane's four pixels (aggregation role above) of member n0 + m, plane aplane; requests the next step's rows.
+    auto step_px = [&](int n0, float (&PX)[4][4]) {
       nlk_f4 Y[4];
       // The smoother's update (1 - a) A + a B of a member's coefficients (A image, B previous frame,
       // reference: :1775) is A + a (B - A), and every step from here to the frame is linear: the member's
@@ -995,7 +1014,6 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         }
       }
       // PX[m][kk]: the lane's four pixels (aggregation role above) of member n0 + m, plane aplane
-      float PX[4][4];
       if constexpr (SEPB) {
         nlk_f4 X[4];
         nlk_sep_inv4<PRIO>(Y, sG, X);
@@ -1041,6 +1059,63 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
           PX[m][0] = e0 + o0; PX[m][1] = e1 + o1; PX[m][2] = e0 - o0; PX[m][3] = e1 - o1;
         }
       }
+    };
+    // the tile update of a step whose four members all lie inside the tile (straight-line code)
+    auto agg_fast = [&](int n0, const float (&PX)[4][4]) {
+        const uint32_t mb = n0 < 64 ? mbase[0] : mbase[1];
+        // (read with every lane active: a lane read inside `if (agg_on)` is only defined for the lanes that are
+        // on there, and the member index runs over all 64)
+        int tile_off[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) tile_off[m] = __builtin_amdgcn_readlane((int)mb, (n0 & 63) + m);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          if (agg_on) {  // (CH = 3: every lane owns a plane)
+            float* dst = smem + tile_off[m];
+            float old[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) old[kk] = dst[poff[kk]];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) dst[poff[kk]] = fmaf(ww[kk], PX[m][kk], old[kk]);
+          }
+        }
+    };
+    // Software pipeline over the steps (round 6): a step is one long dependent chain - rows, fold, two stages of
+    // matrix products, shrink, two more stages, unfold, transposition, then four read-modify-writes of the tile one
+    // behind the other (the members overlap: they cannot be reordered) - and pass B kept the FP32 datapath busy
+    // only 59 % of its time against pass A's 80 %. When the first `npipe` members all lie inside the tile (every
+    // temporal target: the tile's halo is the temporal radius) the tile update of step n - 1 stands in the same
+    // basic block as the transforms of step n, so that the scheduler can put the LDS latencies of the one under
+    // the matrix products of the other; two PX buffers swap roles, no copies.
+    int n_start = 0;
+#ifdef NLK_G8_PIPE   // (measured slower - 10 to 15 registers spilled at 168: C2 group 0.711 -> 0.742 ms, profiles/README.md round 6)
+    if constexpr (!G16) {
+      const int npipe = min(nagg & ~3, 64);
+      const uint64_t need = npipe >= 64 ? ~0ull : ((1ull << npipe) - 1ull);
+      if (npipe >= 8 && (inside[0] & need) == need) {
+        float PXa[4][4], PXb[4][4];
+        step_px(0, PXa);
+        int n0 = 4;
+        for (; n0 + 4 < npipe; n0 += 8) {
+          step_px(n0, PXb);
+          agg_fast(n0 - 4, PXa);
+          step_px(n0 + 4, PXa);
+          agg_fast(n0, PXb);
+        }
+        if (n0 < npipe) {
+          step_px(n0, PXb);
+          agg_fast(n0 - 4, PXa);
+          agg_fast(n0, PXb);
+        } else {
+          agg_fast(n0 - 4, PXa);
+        }
+        n_start = npipe;
+      }
+    }
+#endif
+    for (int n0 = n_start; n0 < nagg; n0 += MPS) {
+      float PX[4][4];
+      step_px(n0, PX);
       if constexpr (G16) {
 #pragma unroll
         for (int jm = 0; jm < 4; ++jm)
@@ -1084,23 +1159,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       }
       const uint32_t in4 = (uint32_t)((n0 < 64 ? inside[0] >> n0 : inside[1] >> (n0 - 64)) & 0xfull);
       if (in4 == 0xfu && n0 + 4 <= nagg) {
-        const uint32_t mb = n0 < 64 ? mbase[0] : mbase[1];
-        // (read with every lane active: a lane read inside `if (agg_on)` is only defined for the lanes that are
-        // on there, and the member index runs over all 64)
-        int tile_off[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) tile_off[m] = __builtin_amdgcn_readlane((int)mb, (n0 & 63) + m);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          if (agg_on) {  // (CH = 3: every lane owns a plane)
-            float* dst = smem + tile_off[m];
-            float old[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) old[kk] = dst[poff[kk]];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) dst[poff[kk]] = fmaf(ww[kk], PX[m][kk], old[kk]);
-          }
-        }
+        agg_fast(n0, PX);
         continue;
       }
 #pragma unroll
