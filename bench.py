@@ -120,9 +120,9 @@ def kernel_sources_sha():
 def measured_traffic(workload, instance, largest_grid=False):
     """HBM-side bytes per launch of kernel `instance` (full template name, e.g. "k_bm_topk<8, 3, 2>": the
     instantiation this run timed) from the committed PMC passes (profiles/<tag>_traffic.json, made by
-    tools/profile_round.sh + tools/make_traffic.py; tag = NLK_TRAFFIC_TAG, default r05) - only while the
+    tools/profile_round.sh + tools/make_traffic.py; tag = NLK_TRAFFIC_TAG, default r06) - only while the
     kernel sources are still the ones the table was measured on; otherwise (None, why)."""
-    tag = os.environ.get("NLK_TRAFFIC_TAG", "r05")
+    tag = os.environ.get("NLK_TRAFFIC_TAG", "r06")
     tpath = os.path.join(ROOT, "profiles", f"{tag}_traffic.json")
     if not os.path.exists(tpath):
         return None, f"no PMC table profiles/{tag}_traffic.json committed"
@@ -132,9 +132,12 @@ def measured_traffic(workload, instance, largest_grid=False):
                       f"(git {tab.get('git_head', '?')[:10]}): re-run tools/profile_round.sh")
     ents = tab.get("workloads", {}).get(workload, {})
     ent = ents.get(instance)
-    if ent is None and largest_grid:  # (a kernel family with one instance per launch shape: the full-size one)
-        fam = [e for k_, e in ents.items() if k_.startswith(instance)]
-        ent = max(fam, key=lambda e: e["traffic_bytes"]) if fam else None
+    if ent is None:
+        # a kernel family with one instance per launch shape (largest_grid: the full-size one), or an instance named
+        # without its trailing template arguments (k_bm_topk<8, 3, 2> for k_bm_topk<8, 3, 2, 2, 0>)
+        stem = instance if largest_grid else instance.rstrip(">") + ","
+        fam = [e for k_, e in ents.items() if k_.startswith(stem)]
+        ent = max(fam, key=lambda e: (e["launches_per_pass"], e["traffic_bytes"]) if not largest_grid else e["traffic_bytes"]) if fam else None
     if not ent:
         return None, f"no entry for {instance} at {workload}"
     return ent["traffic_bytes"], (f"FETCH_SIZE + WRITE_SIZE per launch of {ent['instance']} ({ent['launch_shape']}, "

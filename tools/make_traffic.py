@@ -42,7 +42,7 @@ def main(tag):
                    "reads on gfx950 (MI355X_MICROARCH.md): `traffic_bytes_fetch_x2` doubles it, the upper bound for "
                    "kernels whose reads are such loads; WRITE_SIZE is exact for 16-B stores and float atomics.",
            "workloads": {}}
-    for w in ("C2", "C3", "F1"):
+    for w in ("C2", "C3", "C5", "C1L", "F1"):
         p = os.path.join(ROOT, "gpurun_out", tag, f"pmc_{w}_summary.txt")
         if not os.path.exists(p):
             continue
@@ -74,4 +74,4 @@ def main(tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r05")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r06")

@@ -1,13 +1,13 @@
 #!/bin/bash
 # The rocprofv3 part of tools/profile_round.sh alone (kernel statistics + PMC passes of C2 and C3): tools/profile_pmc_only.sh <tag>
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 T="timeout 300"
-for W in C2 C3; do
+for W in C2 C3 C5 C1L; do
   $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -o s -- python3 $ROOT/bench.py --no-cpu --no-extras --workload $W > $OUT/bench_${W}_under_rocprof.json 2>/dev/null
   i=0
   for SET in \

@@ -4,16 +4,17 @@
 #   tools/profile_round.sh <tag>      -> gpurun_out/<tag>/ ; then tools/make_traffic.py <tag>
 # Every command runs under `timeout` (a profiler that does not come back must not eat the GPU budget).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 T="timeout 300"
 for W in C2 C3 C1 C1L; do $T python3 $ROOT/bench.py --workload $W > $OUT/bench_$W.json 2> $OUT/bench_$W.err; done
-$T python3 $ROOT/bench.py --workload C5 --no-cpu > $OUT/bench_C5.json 2> $OUT/bench_C5.err
+$T python3 $ROOT/bench.py --workload C5 > $OUT/bench_C5.json 2> $OUT/bench_C5.err
 $T python3 $ROOT/bench.py --workload F1 > $OUT/bench_F1.json 2> $OUT/bench_F1.err
 $T python3 $ROOT/bench.py --workload S1 --steps 10 --warmup 2 > $OUT/bench_S1.json 2> $OUT/bench_S1.err
+NLK_MATCH_ORDER=block $T python3 $ROOT/bench.py > $OUT/bench_C2_match_order_block.json 2>/dev/null
 NLK_DETERMINISTIC=1 $T python3 $ROOT/bench.py --no-cpu > $OUT/bench_C2_deterministic.json 2>/dev/null
 NLK_DETERMINISTIC=1 $T python3 $ROOT/bench.py --no-cpu --workload C3 > $OUT/bench_C3_deterministic.json 2>/dev/null
 # the N > 1 code path of bench.py on the one GPU of this box (every rank on device 0 over gloo): plumbing, NOT a measurement
@@ -31,6 +32,8 @@ $T python3 $ROOT/tools/power_probe.py --steps 3000 --warmup 50 --no-cpu > $OUT/p
 $T python3 $ROOT/tools/mode_times.py > $OUT/mode_times_1080p.txt 2>&1
 $T python3 $ROOT/tools/mode_times.py 1920 1080 1 20 > $OUT/mode_times_1080p_gray.txt 2>&1
 (cd $ROOT && bash tools/ab_sep.sh C2 2) > $OUT/ab_group_sep.txt 2>&1
+(cd $ROOT && bash tools/ab_env.sh NLK_MATCH_ORDER=block C2 2) > $OUT/ab_match_order.txt 2>&1
+for s in 0 2 6; do echo "NLK_GROUP_SEP=$s"; NLK_GROUP_SEP=$s $T python3 $ROOT/tools/mode_times.py 1920 1080 1 20 2>/dev/null | grep layout; done > $OUT/mode_times_1080p_gray_by_sep.txt 2>&1
 for s in 0 2 6; do echo "NLK_GROUP_SEP=$s"; NLK_GROUP_SEP=$s $T python3 $ROOT/tools/mode_times.py 2>/dev/null | grep layout; done > $OUT/mode_times_1080p_by_sep.txt 2>&1
 NLK_HOST_TRACE=1 $T python3 $ROOT/tools/api_wall.py > $OUT/api_wall.txt 2>&1
 # the one-rank-of-N model (exchanges skipped) and where its step goes
