@@ -46,13 +46,21 @@ struct NlkTile {
   int order;          // summation order of the distances: 0 = the reference's (exact), 1 = block-summed (opt-in; 8 x 8 patches)
 };
 
-__device__ inline uint64_t nlk_wave_or(uint64_t v) {
-  for (int off = 32; off > 0; off >>= 1) {
-    const uint32_t lo = __shfl_xor((uint32_t)v, off, 64);
-    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off, 64);
-    v |= ((uint64_t)hi << 32) | lo;
-  }
-  return v;
+// OR over the 64 lanes, in every lane. (Round 6: four DPP steps inside the rows of 16 lanes and the two row-swap
+// instructions instead of six ds_bpermute round trips per half word - no LDS instruction, no LDS latency in the
+// per-target epilogue; tools/ubench/permlane_swap.hip for what the swaps do.)
+__device__ __forceinline__ uint32_t nlk_wave_or32(uint32_t v) {
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, true);
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141 /* row_half_mirror */, 0xF, 0xF, true);
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140 /* row_mirror */, 0xF, 0xF, true);
+  const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = a[0] | a[1];
+  const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return b[0] | b[1];
+}
+__device__ __forceinline__ uint64_t nlk_wave_or(uint64_t v) {
+  return (uint64_t)nlk_wave_or32((uint32_t)v) | ((uint64_t)nlk_wave_or32((uint32_t)(v >> 32)) << 32);
 }
 
 // Selection for one target whose window holds n <= 64*M candidates and whose sums of squared
@@ -140,7 +148,15 @@ __device__ __forceinline__ void nlk_match_select(const float (&acc)[M], const ui
     const uint64_t mine = p < k ? surv[p] : ~0ull;
     const int j0 = half ? kh : 0, j1 = half ? k : kh;
     int rank = 0;
-    for (int j = 0; j < kh; ++j) rank += (j0 + j < j1) && surv[min(j0 + j, k - 1)] < mine;
+    // (four survivors per round: their LDS reads are in flight together - one after the other every compare waited
+    // for its own read - and the loop's scalar bookkeeping is paid once per four)
+    for (int j = 0; j < kh; j += 4) {
+      uint64_t sv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sv[u] = surv[min(j0 + j + u, k - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rank += (j + u < kh && j0 + j + u < j1) && sv[u] < mine;
+    }
     rank += __shfl_xor(rank, 32, 64);
     if (lane < k) {
       const uint32_t mi = (uint32_t)mine;
@@ -151,7 +167,13 @@ __device__ __forceinline__ void nlk_match_select(const float (&acc)[M], const ui
       const int p = base + lane;
       const uint64_t mine = p < k ? surv[p] : ~0ull;
       int rank = 0;
-      for (int j = 0; j < k; ++j) rank += surv[j] < mine;
+      for (int j = 0; j < k; j += 4) {
+        uint64_t sv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sv[u] = surv[min(j + u, k - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rank += (j + u < k) && sv[u] < mine;
+      }
       if (p < k) {
         const uint32_t mi = (uint32_t)mine;
         sel[rank] = nlk_pack_xy(x0 + (int)(mi & 0xFFFFu), y0 + (int)(mi >> 16));

@@ -52,7 +52,7 @@ struct NlkRecView {
   X(host_trace, "NLK_HOST_TRACE") X(gtx, "NLK_GTX") X(gty, "NLK_GTY") X(g8_tail, "NLK_G8_TAIL")              \
   X(g8_single, "NLK_G8_SINGLE") X(tv_wg_pixels, "NLK_TV_WG_PIXELS") X(tv_unblocked, "NLK_TV_UNBLOCKED")      \
   X(tv_batch, "NLK_TV_BATCH") X(tv_mid, "NLK_TV_MID") X(tv_shape, "NLK_TV_SHAPE") X(tv_deep, "NLK_TV_DEEP")  \
-  X(tv_inline, "NLK_TV_INLINE") X(tv_look, "NLK_TV_LOOK") X(tv_look2, "NLK_TV_LOOK2") X(tv_trace, "NLK_TV_TRACE")
+  X(tv_inline, "NLK_TV_INLINE") X(tv_wg_full, "NLK_TV_WG_FULL") X(tv_look, "NLK_TV_LOOK") X(tv_look2, "NLK_TV_LOOK2") X(tv_trace, "NLK_TV_TRACE")
 struct NlkSwitches {
 #define NLK_X(field, name) int field = NLK_UNSET;
   NLK_SWITCH_LIST(NLK_X)

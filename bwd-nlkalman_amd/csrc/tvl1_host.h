@@ -75,7 +75,13 @@ int tv_scale(nlk_ctx* c, const float* I0, const float* I1, float* u1, float* u2,
   size_t wg_max = nlk_set(c->sw.tv_wg_pixels) ? (size_t)c->sw.tv_wg_pixels : NLK_TV_WG_PIXELS;
   if (wg_max > NLK_TV_WG_PIXELS) wg_max = NLK_TV_WG_PIXELS;  // (the kernel's LDS arrays)
   if (n <= wg_max) {  // the whole level inside one workgroup
-    hipLaunchKernelGGL(k_tv_level_wg, dim3(1), dim3(NLK_TV_THREADS), 0, c->stream, L);
+    // (round 6) no more wavefronts than the level has pixels for: thread t owns pixel t (+ 1024 m), so a level of up to
+    // 1024 pixels gets the same pixel -> lane mapping from ceil(n / 64) wavefronts as from 16, the workgroup sum adds
+    // the same wavefront sums in the same order (the idle wavefronts only ever added zeros: bit-identical), and every
+    // barrier and the serial sum over the wavefronts cost a fraction - the 30 x 17 and 15 x 8 levels of a 1080p flow
+    // are chains of such latencies (~1.9 us an iteration with 16 wavefronts).
+    const int wg_threads = n <= (size_t)NLK_TV_THREADS ? (int)((n + 63) / 64) * 64 : NLK_TV_THREADS;
+    hipLaunchKernelGGL(k_tv_level_wg, dim3(1), dim3(nlk_set(c->sw.tv_wg_full) ? NLK_TV_THREADS : wg_threads), 0, c->stream, L);
     HIPCHK(c, hipGetLastError());
     return NLK_OK;
   }
