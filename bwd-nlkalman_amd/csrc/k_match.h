@@ -95,9 +95,10 @@ __device__ __forceinline__ void nlk_match_select(const float (&acc)[M], const ui
     nalive += __popcll(alive[m]);
   }
   // walk the key bits from the top; stop as soon as exactly kk candidates are undecided
-  // (they are then all kept) — typically after ~16 of the 32 bits. (Round 4 tried starting below the keys' common
-  // prefix - OR and AND over the wavefront, ~10 rounds of ~20 dependent scalar instructions saved per target: exact,
-  // and no change in the launch time: the selection is not what the kernel waits for.)
+  // (they are then all kept) — typically after ~16 of the 32 bits. (Starting below the keys' common prefix - an AND and
+  // an OR over the wavefront, ~10 rounds of 16 mostly scalar instructions saved per target - was tried twice: in round
+  // 4 with shuffles, in round 6 with DPP / row-swap reductions: exact, and C2 match 0.2390 -> 0.2413 ms, first frame
+  // 0.743 -> 0.751: the rounds above the prefix are scalar work the kernel has room for, the reductions are vector work.)
 #pragma unroll 1
   for (int b = 31; b >= 0 && nalive != kk; --b) {
     uint64_t one[M];
@@ -146,16 +147,19 @@ __device__ __forceinline__ void nlk_match_select(const float (&acc)[M], const ui
     // two lanes per survivor: lane p counts the first half of the list, lane p + 32 the second
     const int p = lane & 31, half = lane >> 5, kh = (k + 1) >> 1;
     const uint64_t mine = p < k ? surv[p] : ~0ull;
-    const int j0 = half ? kh : 0, j1 = half ? k : kh;
+    const int j0 = half ? kh : 0;
+    const int nh = (half ? k : kh) - j0;  // how many survivors this lane counts, from j0 on
+    const uint64_t* sp = surv + j0;
     int rank = 0;
     // (four survivors per round: their LDS reads are in flight together - one after the other every compare waited
-    // for its own read - and the loop's scalar bookkeeping is paid once per four)
+    // for its own read - and the loop's bookkeeping is paid once per four. A round may read up to three entries past
+    // the list: still inside the workgroup's LDS - the lists of the other wavefronts follow -, and they do not count.)
     for (int j = 0; j < kh; j += 4) {
       uint64_t sv[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) sv[u] = surv[min(j0 + j + u, k - 1)];
+      for (int u = 0; u < 4; ++u) sv[u] = sp[j + u];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) rank += (j + u < kh && j0 + j + u < j1) && sv[u] < mine;
+      for (int u = 0; u < 4; ++u) rank += (j + u < nh) && sv[u] < mine;
     }
     rank += __shfl_xor(rank, 32, 64);
     if (lane < k) {
@@ -170,7 +174,7 @@ __device__ __forceinline__ void nlk_match_select(const float (&acc)[M], const ui
       for (int j = 0; j < k; j += 4) {
         uint64_t sv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) sv[u] = surv[min(j + u, k - 1)];
+        for (int u = 0; u < 4; ++u) sv[u] = surv[j + u];  // (past the list: see above)
 #pragma unroll
         for (int u = 0; u < 4; ++u) rank += (j + u < k) && sv[u] < mine;
       }
