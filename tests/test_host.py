@@ -113,3 +113,25 @@ def test_reference_mains_link_against_the_drop_in_library(built):
         h = subprocess.run([exe, "-h"], capture_output=True, text=True)
         ours = subprocess.run([os.path.join(ROOT, "bwd-nlkalman_amd", "bin", "nlkalman-" + t), "-h"], capture_output=True, text=True)
         assert h.returncode == ours.returncode == 0 and h.stdout == ours.stdout   # the same usage text, byte for byte
+
+
+def test_group_tile_strides_are_bank_conflict_free():
+    """The LDS strides tu_group8.hip picks for k_group8m's accumulator tile, against the bank model of
+    tools/lds_banks.py (two half wavefronts of 32 lanes on 32 banks for a 4-byte access): every region size, both
+    lane maps of pass B. (Round 5 ran the separable lane map on the Kronecker strides: a 2-way conflict on every
+    tile instruction - SQ_LDS_BANK_CONFLICT 3.1e7 per 1080p launch.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lds_banks", os.path.join(ROOT, "tools", "lds_banks.py"))
+    lb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lb)
+    assert lb.separable(28, 624) > 0                      # what round 5 ran
+    for rw in range(12, 72):
+        for rh in range(12, 48, 5):
+            rwp = rw + ((2 - rw) % 4 + 4) % 4             # tu_group8.hip, separable pass B
+            plane = rwp * rh
+            plane += ((8 - plane) % 16 + 16) % 16
+            assert plane % 4 == 0 and lb.separable(rwp, plane) == 0, (rw, rh, rwp, plane)
+            rwp = rw + ((4 - rw) % 8 + 8) % 8             # Kronecker pass B
+            plane = rwp * rh
+            plane += ((16 - plane) % 32 + 32) % 32
+            assert lb.kronecker(rwp, plane) == 0, (rw, rh, rwp, plane)
