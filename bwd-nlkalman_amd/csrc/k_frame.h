@@ -6,6 +6,8 @@
 // The layout work of a frame call in one pass over the pixels: up to three HWC images -> planar, the
 // row test of the validity map on the previous frame's channel 0 (see k_nan_cols), and the
 // accumulator cleared (whole-frame calls; a strip's accumulator belongs to the caller).
+// CH: the channel count at compile time (3: a pixel is ONE 12-byte load per image instead of three 4-byte ones), 0 = `ch`
+template <int CH>
 __global__ void __launch_bounds__(256)
 k_layout(const float* __restrict__ cur, float* __restrict__ pl_cur, const float* __restrict__ prev,
          float* __restrict__ pl_prev, const float* __restrict__ basic, float* __restrict__ pl_basic,
@@ -17,15 +19,34 @@ k_layout(const float* __restrict__ cur, float* __restrict__ pl_cur, const float*
   if (zero_word && x == 0 && blockIdx.y == 0) *zero_word = 0u;
   if (x >= w) return;
   const size_t npix = (size_t)w * h, i = (size_t)y * w + x;
-  if (planar) {  // (one channel: planar == interleaved, the images are used in place)
-    for (int c = 0; c < ch; ++c) {
-      pl_cur[c * npix + i] = cur[i * ch + c];
-      if (prev) pl_prev[c * npix + i] = prev[i * ch + c];
-      if (basic) pl_basic[c * npix + i] = basic[i * ch + c];
-      if (pl_diff) pl_diff[c * npix + i] = prev[i * ch + c] - cur[i * ch + c];
+  float own = 0.f;   // channel 0 of the previous frame's pixel (the row test below)
+  if constexpr (CH == 3) {
+    struct __attribute__((packed, aligned(4))) P3 { float v[3]; };
+    const P3 a = reinterpret_cast<const P3*>(cur)[i];
+    P3 b = a, d = a;
+    if (prev) b = reinterpret_cast<const P3*>(prev)[i];
+    if (basic) d = reinterpret_cast<const P3*>(basic)[i];
+    own = b.v[0];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      pl_cur[c * npix + i] = a.v[c];
+      if (prev) pl_prev[c * npix + i] = b.v[c];
+      if (basic) pl_basic[c * npix + i] = d.v[c];
+      if (pl_diff) pl_diff[c * npix + i] = b.v[c] - a.v[c];
+    }
+  } else {
+    if (prev) own = prev[i * ch];
+    if (planar) {  // (one channel: planar == interleaved, the images are used in place)
+      for (int c = 0; c < ch; ++c) {
+        pl_cur[c * npix + i] = cur[i * ch + c];
+        if (prev) pl_prev[c * npix + i] = prev[i * ch + c];
+        if (basic) pl_basic[c * npix + i] = basic[i * ch + c];
+        if (pl_diff) pl_diff[c * npix + i] = prev[i * ch + c] - cur[i * ch + c];
+      }
     }
   }
   if (prev) {
+#ifdef NLK_LAYOUT_ROWOK_LOADS   // (before round 6: psz loads per pixel, all but one of them for values its neighbours hold)
     uint8_t ok = (x + psz <= w);
     if (ok)
       for (int j = 0; j < psz; ++j) {
@@ -33,6 +54,17 @@ k_layout(const float* __restrict__ cur, float* __restrict__ pl_cur, const float*
         if (v != v) ok = 0;
       }
     rowok[i] = ok;
+#else
+    // row test of the validity map: no NaN in channel 0 of the psz pixels from x on. A wavefront covers 64 consecutive
+    // pixels of a row (blockDim.x = 256: four of them), so the test is a window of psz bits in the ballot of the
+    // wavefront's own NaN flags, continued by the flags of the psz - 1 pixels behind its last one (psz <= 32).
+    const int lane = threadIdx.x & 63;
+    const int xh = x + 64;   // the halo pixel this lane looks at: the wavefront's first pixel + 64 + lane
+    const bool halo_nan = lane < psz - 1 && xh < w && prev[((size_t)y * w + xh) * ch] != prev[((size_t)y * w + xh) * ch];
+    const uint64_t m_lo = __ballot(own != own), m_hi = __ballot(halo_nan);
+    const uint64_t win = (m_lo >> lane) | (lane ? m_hi << (64 - lane) : 0ull);
+    rowok[i] = (x + psz <= w) && (win & ((1ull << psz) - 1ull)) == 0ull;
+#endif
   }
   if (acc_zero)
     for (int c = 0; c <= ch; ++c) acc_zero[c * npix + i] = 0.f;
@@ -65,15 +97,30 @@ __global__ void k_nan_cols4(const uint32_t* __restrict__ rowok, uint32_t* __rest
 // out = acc_c / acc_w where acc_w > 1e-6 else the input frame
 // (reference: src/nlkalman.c:939-942, 1853-1856; the double literal 1e-6 there
 // compares like 1e-6f against a float weight)
+// CH: the channel count at compile time (3: a pixel leaves as ONE 12-byte store), 0 = `ch`
+template <int CH>
 __global__ void k_normalize(float* __restrict__ out, const float* __restrict__ acc,
                             const float* __restrict__ cur_hwc, int w, int h, int ch,
                             int y0, int y1) {
   const size_t npix = (size_t)w * h;
   for (size_t i = (size_t)y0 * w + blockIdx.x * blockDim.x + threadIdx.x;
        i < (size_t)y1 * w; i += (size_t)gridDim.x * blockDim.x) {
-    const float a = acc[(size_t)ch * npix + i];
-    for (int c = 0; c < ch; ++c)  // (the input frame is read only where it is needed)
-      out[i * ch + c] = a > 1e-6f ? acc[(size_t)c * npix + i] / a : cur_hwc[i * ch + c];
+    if constexpr (CH == 3) {
+      struct __attribute__((packed, aligned(4))) P3 { float v[3]; };
+      const float a = acc[(size_t)3 * npix + i];
+      P3 o;
+      if (a > 1e-6f) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o.v[c] = acc[(size_t)c * npix + i] / a;
+      } else {
+        o = reinterpret_cast<const P3*>(cur_hwc)[i];  // (the input frame is read only where it is needed)
+      }
+      reinterpret_cast<P3*>(out)[i] = o;
+    } else {
+      const float a = acc[(size_t)ch * npix + i];
+      for (int c = 0; c < ch; ++c)  // (the input frame is read only where it is needed)
+        out[i * ch + c] = a > 1e-6f ? acc[(size_t)c * npix + i] / a : cur_hwc[i * ch + c];
+    }
   }
 }
 

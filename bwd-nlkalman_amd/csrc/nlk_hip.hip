@@ -427,7 +427,7 @@ static int layout_rows(nlk_ctx* c, const float* cur, const float* prev, const fl
   const size_t img_floats = (size_t)w * h * ch;
   float* const slab = (float*)c->planes.p;
   if (y1 > y0)
-    hipLaunchKernelGGL(k_layout, dim3((w + 255) / 256, y1 - y0), dim3(256), 0, c->stream, cur, slab, prev,
+    hipLaunchKernelGGL(ch == 3 ? k_layout<3> : k_layout<0>, dim3((w + 255) / 256, y1 - y0), dim3(256), 0, c->stream, cur, slab, prev,
                        slab + img_floats, basic, slab + 2 * img_floats, (uint8_t*)c->rowok.p, acc_zero, w, h, ch, psz,
                        1, y0, zero_word, (c->layout_diff && prev) ? slab + 3 * img_floats : nullptr);
   if (prev && v1 > v0) {
@@ -980,7 +980,7 @@ int nlk_dev_frame_normalize(nlk_ctx* c, float* out, const float* acc, const floa
   if (!acc || y0 < 0 || y1 > h || y0 > y1) return fail(c, NLK_EINVAL, "bad normalise range");
   NLK_USE_DEVICE(c);
   mark(c, 5);
-  hipLaunchKernelGGL(k_normalize, dim3(2048), dim3(256), 0, c->stream, out, acc, cur, w, h, ch,
+  hipLaunchKernelGGL(ch == 3 ? k_normalize<3> : k_normalize<0>, dim3(2048), dim3(256), 0, c->stream, out, acc, cur, w, h, ch,
                      y0, y1);
   HIPCHK(c, hipGetLastError());
   mark(c, 6);
@@ -1117,7 +1117,7 @@ static int frame_host(nlk_ctx* c, float* out_h, const float* cur_h, const float*
     nz[b + 1] = last ? h : max(nz0, min(h, r1 * step - wall));
     if (nz[b + 1] > nz0) {
       if (b > 0) HIPCHK(c, hipStreamWaitEvent(s, c->band_ev[E_GRP][b - 1], 0));
-      hipLaunchKernelGGL(k_normalize, dim3(1024), dim3(256), 0, s, d_out, (const float*)acc, (const float*)d_cur, w, h,
+      hipLaunchKernelGGL(ch == 3 ? k_normalize<3> : k_normalize<0>, dim3(1024), dim3(256), 0, s, d_out, (const float*)acc, (const float*)d_cur, w, h,
                          ch, nz0, nz[b + 1]);
       HIPCHK(c, hipGetLastError());
     }
