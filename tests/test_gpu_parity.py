@@ -811,6 +811,29 @@ def test_block_summed_match_order_psnr_1080p(ctx, built, synth, monkeypatch):
     assert abs(out["exact"][0] - out["block"][0]) <= 0.02
 
 
+def test_smoother_with_a_basic_estimate(ctx, built, O, synth):
+    """nlkalman_smooth_frame with bsic1 != NULL (the command line never passes one, the API accepts it,
+    src/nlkalman.c:1409): matching and statistics on the basic estimate, the filtered patches from filt1 - and pass B
+    of the group kernel on the difference image smoo0 - filt1 laid out with the frame (round 6). One and three
+    channels, NaN holes in smoo0; records exact, pixels within the tolerance."""
+    for w, h, ch, seed in ((160, 96, 3, 21), (131, 75, 1, 22)):
+        sigma = 20.0
+        n0, n1, _ = synth.noisy_pair(w, h, ch, sigma, seed)
+        o0, o1 = (built.rgb2opp(n0), built.rgb2opp(n1)) if ch == 3 else (n0, n1)
+        p1, ps = built.default_params(sigma, built.FLT1), built.default_params(sigma, built.SMO1)
+        f0, _ = _dev_frame(ctx, False, o0, None, None, sigma, p1)       # filt1
+        f1, _ = _dev_frame(ctx, False, o1, f0, None, sigma, p1)         # smoo0 (no flow: the frames are 2 px apart)
+        basic = (0.5 * f0 + 0.5 * o0).astype(np.float32)                # some other estimate of the same frame
+        prev = f1.copy()
+        prev[h // 4:h // 3, w // 5:w // 2] = np.nan
+        prev[:2] = np.nan
+        g, rec = _dev_frame(ctx, True, f0, prev, basic, sigma, ps)
+        r, tr = O.smooth_frame(f0, prev, basic, sigma, _to_o(O, ps), trace=True)
+        _check_records(rec, tr, f"smoother with basic {w}x{h}x{ch}")
+        g, _ = cases.excuse_threshold_pixels(g, r, tr, f"smoother with basic {w}x{h}x{ch}", 64)
+        cases.assert_close(g, r, f"smoother with basic {w}x{h}x{ch}")
+
+
 def test_group_kernels_agree_matrix_vs_dpp(ctx, built, synth, monkeypatch):
     """The 8x8 group kernel has two implementations: k_group8m (DCTs on the f32
     matrix cores, the default) and k_group8 (registers + DPP, NLK_GROUP_DPP=1).
