@@ -33,6 +33,8 @@ for it in range(int(sys.argv[2])):
     g, rec = tp._dev_frame(ctx, smoother, cur, prev, basic, sigma, p)
     what = f"#{it} {w}x{h}x{ch} mode{mode} {over} sigma{sigma}"
     tp._check_records(rec, tr, what)
-    g, _ = cases.excuse_threshold_pixels(g, r, tr, what, 256)   # (the only excused samples: pixels AT the aggr > 1e-6 threshold)
+    # (the only excused samples: pixels AT the aggr > 1e-6 threshold - a property of the oracle's own weights; bounded by
+    # 0.05 % of the frame: a sigma-40 smoother frame of round 6's soak had 339 of 2.4 M there)
+    g, nex = cases.excuse_threshold_pixels(g, r, tr, what, max(256, w * h // 2000))
     cases.assert_close(g, r, what)
-    print("ok", what, "active", float(tr["active"].mean()), flush=True)
+    print("ok", what, "active", float(tr["active"].mean()), "threshold pixels excused", nex, flush=True)
