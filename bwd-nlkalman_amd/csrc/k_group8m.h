@@ -43,7 +43,7 @@ typedef float nlk_f4 __attribute__((ext_vector_type(4)));
 
 // tiles per chunk of the XCD-aware tile order (see the kernel); the grid is nlk_g8m_grid(ntx, nty) workgroups
 // floats per channel of the gain stash ([gain | (1-gain)*mean][quadrant][16 coefficients] = 128, + 8: pass B reads
-// 16 bytes per lane at channel * stride + 4 * lane group, and with a stride of 128 = 0 (mod 64 banks) two channels
+// 16 bytes per lane (a ds_read_b128: groups of 16 lanes on 64 banks, MI355X_MICROARCH.md) at channel * stride + 4 * lane group, and with a stride of 128 = 0 (mod 64 banks) two channels
 // of every 16-lane group met on one bank: round 2's 19 % SQ_LDS_BANK_CONFLICT, now 0. Not + 16: 12.9 KB instead of
 // 12.7 KB per workgroup costs a workgroup per CU - LDS is handed out in 1280-byte pieces - and 3.7 % of the time)
 #define NLK_G8_SST 136
@@ -208,7 +208,7 @@ __device__ __forceinline__ void nlk_sep_inv4(const nlk_f4 (&Y)[4], const float (
   if (PRIO) __builtin_amdgcn_s_setprio(0);
 }
 // floats per channel slot of the gain stash in the separable form: [gain | (1-gain)*mean][lane & 3][quadrant][a],
-// + 4: a lane reads 16 bytes at slot * stride + 16 * (lane & 3) + 4 * q - with a stride of 4 (mod 64 banks) the
+// + 4: a lane reads 16 bytes (ds_read_b128: 64 banks; the 4-byte tile updates see 32: tu_group8.hip) at slot * stride + 16 * (lane & 3) + 4 * q - with a stride of 4 (mod 64 banks) the
 // (plane, lane & 3) pairs of a wavefront meet on no bank
 #define NLK_G8S_SST 132
 // stash slots of the separable form: the image channels, the weight plane, (1-channel frames) one all-zero slot

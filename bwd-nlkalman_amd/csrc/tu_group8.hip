@@ -85,7 +85,10 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
     // 1.029 ms, 3 x 1 1.043, 3 x 2 1.042, 1 x 3 1.052, 2 x 2 1.090, 2 x 1 1.113 (the default until then), 1 x 4 1.113,
     // 1 x 1 1.143, 4 x 1 1.164, 1 x 6 1.185)
     const bool wide_full = mfma && tl.wmax > 6 && tgx_fill == 3 && pass == 0;
-    tl.tgx = nlk_or(c->sw.gtx, wide_full ? 1 : min(tgx_fill, tl.wmax > 6 ? 2 : 4));
+    // (round 6, after the tile's strides shrank its LDS footprint - first frames at 1080p RGB: 2 x 2 targets 0.896 ms,
+    // 2 x 3 0.933, 3 x 2 0.935, 1 x 2 0.939 (the default until then), 2 x 1 0.938, 1 x 3 0.953, 1 x 4 1.008; 4K RGB 3.50
+    // against 3.74; one channel 3 x 2 0.430, 2 x 3 0.433, 2 x 2 0.445, 1 x 2 0.47-0.50: tools/sweep_gt_spatial.sh)
+    tl.tgx = nlk_or(c->sw.gtx, wide_full ? (CH == 1 ? 3 : 2) : min(tgx_fill, tl.wmax > 6 ? 2 : 4));
     // (round 3, matrix-core kernel with the leaner pass A, 1080p: 3 x 2 targets 0.957 ms, 2 x 2 0.970, 3 x 1 0.976,
     // 4 x 2 1.10, 2 x 3 1.05, 3 x 3 1.04 - two target rows share the tile's vertical halo: 40 % fewer flushed bytes;
     // round 4, straight-line aggregation: 3 x 2 0.831, 2 x 2 0.851, 3 x 1 0.869, 3 x 3 0.891, 4 x 2 0.993)
