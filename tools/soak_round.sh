@@ -7,7 +7,7 @@ cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 pids=()
 for i in $(seq 1 $NP); do
-  ( echo "== seed $((600 + i)) count $CNT default kernels"; timeout 1500 python3 tools/soak_fullsize.py $((600 + i)) $CNT 2>&1 | tail -$((CNT + 3)) ) > $OUT/full_$i.txt &
+  ( echo "== seed $((${SEED0:-600} + i)) count $CNT default kernels"; timeout 1500 python3 tools/soak_fullsize.py $((${SEED0:-600} + i)) $CNT 2>&1 | tail -$((CNT + 3)) ) > $OUT/full_$i.txt &
   pids+=($!)
 done
 for s in 0 2 6; do
