@@ -927,12 +927,32 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     // 16 lanes of group pl add the member's pixels to the image plane while the 16 lanes of the next group add its
     // weights to the weight plane (an LDS instruction may touch ONE member per plane: the same 8 instructions per
     // member as before, half the lanes idle).
-    constexpr int MPS = G16 ? 16 : 4;  // members per step
-    const int bchc = G16 ? 0 : min(bch, CH - 1);
-    const int bmm = G16 ? 4 * spl + g4 : bm;
+    // M5 (three channels, separable form; round 6): FIVE members per step. The weight plane's lane group needs no
+    // transform - its pixels are the constant 1 - so its four slots carry the three channels of a fifth member
+    // (slot (g4 = c, plane 3) = member n0 + 4, channel c; the sixteenth slot idles): 20 members in 4 steps instead
+    // of 5, a fifth of pass B's transforms, loads and shrinkage gone. After the transposition the fifth member's
+    // pixels sit in the weight plane's lanes with the CHANNEL in the register index; three DPP row shifts per pixel
+    // with a bank mask each (lane 4 c + si of a row takes lane 12 + si's register c) put them in front of their own
+    // planes, the weight lanes keep the constant, and the member is aggregated by the same eight LDS instructions as
+    // every other - no exec-masked rounds (round 5's version of the idea paid four of them per step and lost).
+#ifndef NLK_G8_M5
+#define NLK_G8_M5 1
+#endif
+    constexpr bool M5 = NLK_G8_M5 && SEPB && CH == 3;
+    constexpr int MPS = G16 ? 16 : (M5 ? 5 : 4);  // members per step
+    constexpr int NPX = M5 ? 5 : 4;               // members whose pixels a step leaves in registers
+    const bool wlane = SEPB && spl == 3;          // (M5) a lane of the weight plane's group
+    const int bchc = G16 ? 0 : (M5 ? (wlane ? min(g4, CH - 1) : spl) : min(bch, CH - 1));
+    const int bmm = G16 ? 4 * spl + g4 : (M5 ? (wlane ? 4 : g4) : bm);
     auto member_off = [&](int n0) -> uint32_t {   // (element offset inside an image: channel plane + patch)
       const int n = min(n0 + bmm, nagg - 1);
-      const uint32_t qm = nlk_bperm_u(n < 64 ? greg[0] : greg[1], n & 63);
+      uint32_t qm;
+      if constexpr (M5) {  // (a step of five may straddle the two list words, and a bpermute's operand is the SOURCE lane's)
+        const uint32_t q0 = nlk_bperm_u(greg[0], n & 63), q1 = nlk_bperm_u(greg[1], n & 63);
+        qm = n < 64 ? q0 : q1;
+      } else {
+        qm = nlk_bperm_u(n < 64 ? greg[0] : greg[1], n & 63);
+      }
       return (uint32_t)bchc * (uint32_t)npix + (uint32_t)(nlk_y(qm) * g.w + nlk_x(qm));
     };
     // (smoother) the difference image previous - image laid out with the frame (k_layout): ONE row set per member
@@ -968,15 +988,15 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     float ww[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) ww[kk] = wgt * win[kk];
-    const int bst = G16 ? 0 : min(bch, NSLOT - 1);  // stash slot of the lane's load slot: image channel, weights, or nothing
-    const bool slot_is_channel = G16 ? true : bch < CH;
+    const int bst = G16 ? 0 : (M5 ? bchc : min(bch, NSLOT - 1));  // stash slot of the lane's load slot: image channel, weights, or nothing
+    const bool slot_is_channel = (G16 || M5) ? true : bch < CH;
     // gains of the lane's four coefficients of quadrant q at + 4 * q (separable) / + 16 * q (Kronecker)
     const float* st_g = stash + bst * SST + (SEPB ? 16 * si : 4 * g4);
     const float* st_m = st_g + 64;
     constexpr int QST = SEPB ? 4 : 16;
     // One step's transforms: the rows of members n0 .. n0 + MPS - 1 (in R: requested a step ahead) -> PX[m][kk], the
     // lane's four pixels (aggregation role above) of member n0 + m, plane aplane; requests the next step's rows.
-    auto step_px = [&](int n0, float (&PX)[4][4]) {
+    auto step_px = [&](int n0, float (&PX)[NPX][4]) {
       nlk_f4 Y[4];
       // The smoother's update (1 - a) A + a B of a member's coefficients (A image, B previous frame,
       // reference: :1775) is A + a (B - A), and every step from here to the frame is linear: the member's
@@ -1042,6 +1062,23 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
             PX[0][2 * sel + h] = __uint_as_float(u[0]); PX[1][2 * sel + h] = __uint_as_float(u[1]);
             PX[2][2 * sel + h] = __uint_as_float(v[0]); PX[3][2 * sel + h] = __uint_as_float(v[1]);
           }
+        if constexpr (M5) {
+          // the fifth member: register c of the weight group's lanes -> the lanes of plane c (row_shl 12 / 8 / 4 inside
+          // the rows of 16 lanes, written to bank c only); the weight group's own lanes keep the constant 1
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            int p4 = __float_as_int(1.f);
+            p4 = __builtin_amdgcn_update_dpp(p4, __float_as_int(PX[0][kk]), 0x10C /* row_shl:12 */, 0xF, 0x1, false);
+            p4 = __builtin_amdgcn_update_dpp(p4, __float_as_int(PX[1][kk]), 0x108 /* row_shl:8 */, 0xF, 0x2, false);
+            p4 = __builtin_amdgcn_update_dpp(p4, __float_as_int(PX[2][kk]), 0x104 /* row_shl:4 */, 0xF, 0x4, false);
+            PX[4][kk] = __int_as_float(p4);
+          }
+          // ... and the weight plane's pixels of the other four members: the constant
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) PX[m][kk] = wlane ? 1.f : PX[m][kk];
+        }
       } else {
         nlk_f4 Z[4];
 #pragma unroll
@@ -1061,15 +1098,16 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       }
     };
     // the tile update of a step whose four members all lie inside the tile (straight-line code)
-    auto agg_fast = [&](int n0, const float (&PX)[4][4]) {
-        const uint32_t mb = n0 < 64 ? mbase[0] : mbase[1];
+    auto agg_fast = [&](int n0, const float (&PX)[NPX][4]) {
         // (read with every lane active: a lane read inside `if (agg_on)` is only defined for the lanes that are
         // on there, and the member index runs over all 64)
-        int tile_off[4];
+        int tile_off[NPX];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) tile_off[m] = __builtin_amdgcn_readlane((int)mb, (n0 & 63) + m);
+        for (int m = 0; m < NPX; ++m)   // (a step of five may straddle the two 64-entry words)
+          tile_off[m] = (n0 + m) < 64 ? __builtin_amdgcn_readlane((int)mbase[0], (n0 + m) & 63)
+                                      : __builtin_amdgcn_readlane((int)mbase[1], (n0 + m) & 63);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < NPX; ++m) {
           if (agg_on) {  // (CH = 3: every lane owns a plane)
             float* dst = smem + tile_off[m];
             float old[4];
@@ -1089,7 +1127,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     // the matrix products of the other; two PX buffers swap roles, no copies.
     int n_start = 0;
 #ifdef NLK_G8_PIPE   // (measured slower - 10 to 15 registers spilled at 168: C2 group 0.711 -> 0.742 ms, profiles/README.md round 6)
-    if constexpr (!G16) {
+    if constexpr (!G16 && !M5) {
       const int npipe = min(nagg & ~3, 64);
       const uint64_t need = npipe >= 64 ? ~0ull : ((1ull << npipe) - 1ull);
       if (npipe >= 8 && (inside[0] & need) == need) {
@@ -1114,7 +1152,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     }
 #endif
     for (int n0 = n_start; n0 < nagg; n0 += MPS) {
-      float PX[4][4];
+      float PX[NPX][4];
       step_px(n0, PX);
       if constexpr (G16) {
 #pragma unroll
@@ -1157,13 +1195,16 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
           }
         continue;
       }
-      const uint32_t in4 = (uint32_t)((n0 < 64 ? inside[0] >> n0 : inside[1] >> (n0 - 64)) & 0xfull);
-      if (in4 == 0xfu && n0 + 4 <= nagg) {
+      // "inside the tile" bits of the step's members (a step of five may straddle the two 64-entry words)
+      uint64_t inb = n0 < 64 ? inside[0] >> n0 : inside[1] >> (n0 - 64);
+      if (NPX > 4 && n0 < 64 && n0 + NPX > 64) inb |= inside[1] << (64 - n0);
+      constexpr uint32_t in_all = (1u << NPX) - 1u;
+      if (((uint32_t)inb & in_all) == in_all && n0 + NPX <= nagg) {
         agg_fast(n0, PX);
         continue;
       }
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int m = 0; m < NPX; ++m) {
         if (n0 + m >= nagg) break;
         const uint32_t q = (n0 + m) < 64 ? __builtin_amdgcn_readlane(greg[0], n0 + m)
                                          : __builtin_amdgcn_readlane(greg[1], n0 + m - 64);
