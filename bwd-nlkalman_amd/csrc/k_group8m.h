@@ -219,6 +219,9 @@ template <int CH, int SEP> constexpr int nlk_g8_stash_floats() {
   return ((SEP & 2) ? nlk_g8s_slots<CH>() * NLK_G8S_SST : (CH + 2) * NLK_G8_SST) + ((SEP & 4) ? 64 : 0);
 }
 
+#ifndef NLK_G8_S5TRACK
+#define NLK_G8_S5TRACK 1
+#endif
 #ifndef NLK_G8_WPS
 #define NLK_G8_WPS 3  // wavefronts per SIMD the register budget is cut for (experiments: -DNLK_G8_WPS=2)
 #endif
@@ -546,6 +549,9 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         nlk_rows_load32(pbase, off + (uint32_t)cc * (uint32_t)npix, rowa, rowb, R);
       };
       float R[16], F[4][4];
+#if NLK_G8_S5TRACK
+      bool s5_track = true;
+#endif
       const uint32_t o_step0 = slot_off(0);
       rows_read(o_step0, 0, R);
       uint32_t onext = slot_off(1);
@@ -586,6 +592,21 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
           // bit j of the lane group's pair of candidates: group membership (filter) / valid previous patch (smoother)
           const uint64_t mw = MODE == 1 ? (b < 8 ? gbits[0] : gbits[1]) : (b < 8 ? vbits[0] : vbits[1]);
           const uint32_t mbyte = (uint32_t)(mw >> (8 * (b & 7))) & 0xffu;
+#if NLK_G8_S5TRACK
+          // (filter) The group members are the FIRST valid candidates of the sorted list: while every candidate of every
+          // step so far was a member, the members' sum S5 IS the sum S2 over all candidates (fmaf(1, d, s) = s + d, same
+          // order: the same bits) and is not kept; the first step that is not all members copies it, and only steps that
+          // hold a member add to it afterwards - for a temporal target of 30 candidates and 20 members one masked step of
+          // four per channel instead of four.
+          if (MODE == 1 && s5_track && mbyte != 0xffu) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) S[5][q] = S[2][q];
+            s5_track = false;
+          }
+          const bool s5_add = MODE == 1 && !s5_track && mbyte != 0u;  // (wave-uniform)
+#else
+          constexpr bool s5_add = MODE == 1;
+#endif
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const float mk = (float)((mbyte >> (2 * g4 + j)) & 1u);
@@ -600,10 +621,15 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
               S[3][q] = fmaf(d, d, S[3][q]);
               const float df = di - d;  // reference: :769-783, smoother :1659-1667
               if (MODE == 2) S[4][q] = fmaf(mk * df, df, S[4][q]);
-              else {
-                S[4][q] = fmaf(df, df, S[4][q]);
-                S[5][q] = fmaf(mk, d, S[5][q]);
-              }
+              else S[4][q] = fmaf(df, df, S[4][q]);
+            }
+          }
+          if (s5_add) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const float mk = (float)((mbyte >> (2 * g4 + j)) & 1u);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) S[5][q] = fmaf(mk, C[q][j + 2], S[5][q]);
             }
           }
         } else {
@@ -616,6 +642,13 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
             }
         }
         if (b == nb - 1) {
+#if NLK_G8_S5TRACK
+          if (MODE == 1 && s5_track) {  // (every candidate was a member)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) S[5][q] = S[2][q];
+          }
+          s5_track = true;
+#endif
           // The channel is complete: candidates are spread over the four lane groups. Each of the
           // sums is reduced over them with the row-swap instructions: two registers per
           // v_permlane32_swap + add, two of those per v_permlane16_swap + add, which leaves the total
