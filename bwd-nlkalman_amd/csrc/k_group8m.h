@@ -726,10 +726,13 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
     auto sep_gain = [&](auto mode_tag, const auto& T, int ch) {
       constexpr int MODE = decltype(mode_tag)::value;
       constexpr int NS = MODE == 0 ? 2 : (MODE == 1 ? 4 : 5);
-        const float nx0q = x0buf[16 * si + 4 * g4 + spl];
+        // the coefficient this lane owns after the reduction below: quadrant oq = 2 qr + qc, vertical index oa,
+        // horizontal index si (lane = 32 qc + 8 oa + 4 qr + si)
+        const int oq = 2 * ((lane >> 2) & 1) + (lane >> 5), oa = (lane >> 3) & 3;
+        const float nx0q = x0buf[16 * si + 4 * oq + oa];
         // (where pass B reads the gains: separable [horizontal index][quadrant][vertical index], Kronecker
         // [quadrant][coefficient])
-        const int cidx = SEPB ? 16 * si + 4 * g4 + spl : 16 * g4 + 4 * spl + si;
+        const int cidx = SEPB ? 16 * si + 4 * oq + oa : 16 * oq + 4 * oa + si;
         float a, term, m;
         if (MODE == 2) {
           const float v1 = (T[1] - T[0] * T[0] * in1) * in1;  // image variance
@@ -760,25 +763,30 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         stash[ch * SST + cidx] = a;
         stash[ch * SST + 64 + cidx] = (1 - a) * m;
     };
-    // HALF a patch per lane quad: lane = 32 h + 4 slot + i loads ONE row of its candidate - row i (h = 0) or 7 - i
-    // (h = 1) -, fetches the mirror row from the other half of the wavefront and keeps the sum P (h = 0: the
-    // quadrants of even vertical frequency) or the difference M (h = 1: odd). A batch = 8 candidates; a lane holds
+    // HALF a patch per lane quad: lane = 8 slot + u loads ONE row of its candidate - row u = 0..7 -, takes the mirror
+    // row 7 - u from lane u ^ 7 of its group of eight (ONE DPP move, row_half_mirror: round 6; round 5 had the two
+    // halves in the two halves of the wavefront and fetched the mirror row through ds_bpermute - 16 LDS round trips
+    // in every batch's dependency chain, whose issue is half a Kronecker step's but which took longer) and keeps the
+    // sum P (u < 4: the quadrants of even vertical frequency) or the difference M (u >= 4: odd; its quad holds the
+    // folded rows 3..0, so the second stage's constants are reversed there). A batch = 8 candidates; a lane holds
     // 2 quadrants x 4 vertical indices = 8 coefficients, so a statistic is 8 registers (with a whole patch per
     // quad - 16 candidates per batch, 16 registers per statistic - the kernel spilled 27-65 registers and was
     // slower: profiles/README.md round 5), both images' rows of the next batch are requested a whole batch ahead,
-    // and the reduction over the 8 lane quads of a half is one row-swap level, two rotations and a select.
+    // and the reduction over the 8 candidates' lanes is a reduce-scatter: one row-swap level per register pair for
+    // lane bits 5 and 4, a rotation for bit 3 - 15 operations per statistic, every lane ends up with the total of
+    // the ONE coefficient it owns.
     auto pass_a = [&](auto mode_tag) {
       constexpr int MODE = decltype(mode_tag)::value;
       constexpr bool HP = MODE != 0;
       constexpr int NS = MODE == 0 ? 2 : (MODE == 1 ? 4 : 5);
       const int nb = (k + 7) >> 3;
       if (nb == 0) return;
-      const int hh = lane >> 5, hp = (lane >> 2) & 7;
-      const uint32_t rowh = (uint32_t)((hh ? 7 - si : si) * g.w);
+      const int hh = (lane >> 2) & 1, hp = lane >> 3;
+      const uint32_t rowh = (uint32_t)((lane & 7) * g.w);
       const float sgn = hh ? -1.f : 1.f;
       float sEh[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sEh[i] = hh ? sE[1][i] : sE[0][i];
+      for (int i = 0; i < 4; ++i) sEh[i] = hh ? sE[1][3 - i] : sE[0][i];
       const uint32_t e_dead = o_first + e_img;
       auto slot_offs = [&](int bb, uint32_t& oi, uint32_t& op) {
         const int ci = 8 * bb + hp, cl = min(ci, k - 1);
@@ -789,7 +797,21 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         oi = live_i ? o + e_img : e_dead;
         op = (in_k && valid) ? o + e_prev : e_dead;
       };
+      int rows_seen = 0;
       auto row_read = [&](uint32_t off, int cc, float (&R)[8]) {
+#ifdef NLK_G8_EXP_NOROWS   // (timing experiment: only the first batch's rows are loaded)
+        if (rows_seen >= 2) { asm volatile("" : "+v"(R[0]), "+v"(R[3]), "+v"(R[5]), "+v"(R[7]) : "v"(off)); return; }
+        ++rows_seen;
+#endif
+#ifdef NLK_G8_EXP_LDSROWS   // (timing experiment: the rows read from LDS - garbage from the tile - as a staged window would give them)
+        if (rows_seen >= 2) {
+          const float* wp = smem + ((off + (uint32_t)cc * 7u + (uint32_t)(lane & 7) * 18u) % 1500u);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) R[c] = wp[c];
+          return;
+        }
+        ++rows_seen;
+#endif
         typedef const __attribute__((address_space(1))) nlk_f4u* gp4;
         const char* bp = reinterpret_cast<const char*>(pbase);
         const uint32_t o = (off + (uint32_t)cc * (uint32_t)npix + rowh) * 4u;
@@ -797,13 +819,11 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
 #pragma unroll
         for (int c = 0; c < 4; ++c) { R[c] = a0[c]; R[4 + c] = a1[c]; }
       };
-      // the row and its mirror row (in the other half of the wavefront) -> P or M -> F[qc][s]
+      // the row and its mirror row (lane u ^ 7 of the group of eight) -> P or M -> F[qc][s]
       auto fold_half = [&](const float (&R)[8], float (&F)[2][4]) {
-        // (the mirror row through ds_bpermute: measured in place, 32 per batch, a bpermute costs 0.6 cycles - the LDS
-        // pipe is idle here -, a v_permlane32_swap 7.2, a v_fma_f32 1.5: profiles/README.md round 5)
         float PM[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) PM[c] = fmaf(sgn, R[c], nlk_bperm(R[c], lane ^ 32));  // top + bottom | top - bottom
+        for (int c = 0; c < 8; ++c) PM[c] = fmaf(sgn, R[c], nlk_dpp<NLK_DPP_HMIRROR>(R[c]));  // top + bottom | top - bottom
 #pragma unroll
         for (int c = 0; c < 4; ++c) { F[0][c] = PM[c] + PM[7 - c]; F[1][c] = PM[c] - PM[7 - c]; }
       };
@@ -838,6 +858,26 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       for (int b = 0; b < nb; ++b) {
         const bool wrap = b + 1 == nb;
         const int chn = wrap ? min(ch + 1, CH - 1) : ch;
+#ifdef NLK_G8_EXP_LDSROWS   // (timing experiment: the cost of staging two 18 x 18 windows per channel)
+        if (HP && b == 0) {
+          float* win = stash + nlk_g8_stash_floats<CH, SEP>();
+          const uint32_t back = 10u * (uint32_t)g.w + 10u;
+          const uint32_t wo = (o_first > back ? o_first - back : o_first) + (uint32_t)ch * (uint32_t)npix;
+          float tmp[12];
+#pragma unroll
+          for (int kq = 0; kq < 6; ++kq) {
+            const uint32_t idx = min((uint32_t)lane + 64u * kq, 323u), r = (idx * 3641u) >> 16, cx = idx - 18u * r;
+            tmp[kq] = pbase[(size_t)(e_img + wo + r * (uint32_t)g.w + cx)];
+            tmp[6 + kq] = pbase[(size_t)(e_prev + wo + r * (uint32_t)g.w + cx)];
+          }
+#pragma unroll
+          for (int kq = 0; kq < 6; ++kq) {
+            win[(lane + 64 * kq) % (NLK_G8_LDS_PAD / 8)] = tmp[kq];
+            win[NLK_G8_LDS_PAD / 8 + (lane + 64 * kq) % (NLK_G8_LDS_PAD / 8)] = tmp[6 + kq];
+          }
+          nlk_wave_lds_order();
+        }
+#endif
         float Fi[2][4], Fp[2][4];
         fold_half(Ri, Fi);
         if (HP) fold_half(Rp, Fp);
@@ -919,22 +959,29 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
             }
         }
         if (wrap) {
-          // The channel is complete. Per statistic 8 registers (qc, a) x 8 lane quads per half: the horizontal parity
-          // goes to lane bit 4 (v_permlane16_swap + add: 8 -> 4 registers; the vertical parity IS the half), lane bits
-          // 2..3 are summed with row rotations, and every lane keeps the register a = its bits 2..3.
+          // The channel is complete. Per statistic 8 registers (qc, a) in every lane, to be summed over the 8 candidates'
+          // lanes (lane bits 3..5; bit 2 = the vertical parity, bits 0..1 = the horizontal index stay) - as a
+          // reduce-scatter: v_permlane32_swap + add sends the two horizontal parities to the two halves of the
+          // wavefront (8 -> 4 registers), v_permlane16_swap + add the vertical indices {0, 1} / {2, 3} to the even / odd
+          // rows of 16 lanes (-> 2), a rotation by 8 lanes the last bit (-> 1): lane 32 qc + 8 a + 4 qr + b ends up with
+          // the total of coefficient (2 a + qr, 2 b + qc).
           float T[NS];
+          const bool hi8 = (lane & 8) != 0;
 #pragma unroll
           for (int a = 0; a < NS; ++a) {
-            float Z[4];
+            float Z[4], W[2];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const auto z = __builtin_amdgcn_permlane16_swap(__float_as_uint(S[a][0][j]), __float_as_uint(S[a][1][j]), false, false);
+              const auto z = __builtin_amdgcn_permlane32_swap(__float_as_uint(S[a][0][j]), __float_as_uint(S[a][1][j]), false, false);
               Z[j] = __uint_as_float(z[0]) + __uint_as_float(z[1]);
-              Z[j] += nlk_dpp<NLK_DPP_ROR8>(Z[j]);
-              Z[j] += nlk_dpp<0x124 /* row_ror:4 */>(Z[j]);
             }
-            const float z01 = (spl & 1) ? Z[1] : Z[0], z23 = (spl & 1) ? Z[3] : Z[2];
-            T[a] = (spl & 2) ? z23 : z01;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const auto z = __builtin_amdgcn_permlane16_swap(__float_as_uint(Z[j]), __float_as_uint(Z[j + 2]), false, false);
+              W[j] = __uint_as_float(z[0]) + __uint_as_float(z[1]);
+            }
+            const float send = hi8 ? W[0] : W[1], keep = hi8 ? W[1] : W[0];
+            T[a] = keep + nlk_dpp<NLK_DPP_ROR8>(send);
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll

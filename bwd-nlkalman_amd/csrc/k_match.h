@@ -33,9 +33,6 @@
 #define NLK_BM_THREADS 256
 #endif
 #define NLK_BM_WAVES (NLK_BM_THREADS / 64)
-#ifndef NLK_BM_SGPR_ATTR
-#define NLK_BM_SGPR_ATTR
-#endif
 
 struct NlkTile {
   int tgx, tgy;       // targets per tile
@@ -496,7 +493,7 @@ __device__ __forceinline__ void nlk_match_epilogue(const NlkGeom& g, size_t t, i
 #endif
 // ORD: 0 = the reference's (hy, hx, c) summation order (bit-identical distances), 1 = block-summed (opt-in, above)
 template <int PSZ, int CH, int MAXM, int BX = 4, int ORD = 0>  // BX x 2 targets per block (2: twice the wavefronts on the same tile)
-__global__ void NLK_BM_SGPR_ATTR __launch_bounds__(512, MAXM == 7 ? (BX == 2 ? NLK_BM7_WAVES : 3) : ((MAXM == 2 && PSZ == 8) ? 8 : 2))  // (7 rounds in blocks: 168 registers, the LDS tile allows 3 wavefronts per SIMD)
+__global__ void __launch_bounds__(512, MAXM == 7 ? (BX == 2 ? NLK_BM7_WAVES : 3) : ((MAXM == 2 && PSZ == 8) ? 8 : 2))  // (7 rounds in blocks: 168 registers, the LDS tile allows 3 wavefronts per SIMD)
 k_bm_topk(const float* __restrict__ img, const uint8_t* __restrict__ vmap, NlkGeom g,
           NlkTile tl, uint32_t* __restrict__ topk, NlkTarget* __restrict__ tinfo,
           uint32_t* __restrict__ gcoords, uint64_t* __restrict__ marks,
