@@ -763,18 +763,19 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         stash[ch * SST + cidx] = a;
         stash[ch * SST + 64 + cidx] = (1 - a) * m;
     };
-    // HALF a patch per lane quad: lane = 8 slot + u loads ONE row of its candidate - row u = 0..7 -, takes the mirror
-    // row 7 - u from lane u ^ 7 of its group of eight (ONE DPP move, row_half_mirror: round 6; round 5 had the two
-    // halves in the two halves of the wavefront and fetched the mirror row through ds_bpermute - 16 LDS round trips
-    // in every batch's dependency chain, whose issue is half a Kronecker step's but which took longer) and keeps the
-    // sum P (u < 4: the quadrants of even vertical frequency) or the difference M (u >= 4: odd; its quad holds the
-    // folded rows 3..0, so the second stage's constants are reversed there). A batch = 8 candidates; a lane holds
-    // 2 quadrants x 4 vertical indices = 8 coefficients, so a statistic is 8 registers (with a whole patch per
-    // quad - 16 candidates per batch, 16 registers per statistic - the kernel spilled 27-65 registers and was
-    // slower: profiles/README.md round 5), both images' rows of the next batch are requested a whole batch ahead,
-    // and the reduction over the 8 candidates' lanes is a reduce-scatter: one row-swap level per register pair for
-    // lane bits 5 and 4, a rotation for bit 3 - 15 operations per statistic, every lane ends up with the total of
-    // the ONE coefficient it owns.
+    // HALF a patch per lane quad: lane = 8 slot + u OWNS row u = 0..7 of its candidate (it arrives as two half rows,
+    // one loaded by the lane itself and one by its neighbour u ^ 1, so that every load touches one cache line per
+    // lane pair: row_read / fold_half below), takes the mirror row 7 - u from lane u ^ 7 of its group of eight (ONE
+    // DPP move, row_half_mirror: round 6; round 5 had the two halves in the two halves of the wavefront and fetched
+    // the mirror row through ds_bpermute - 16 LDS round trips in every batch's dependency chain, whose issue is half
+    // a Kronecker step's but which took longer) and keeps the sum P (u < 4: the quadrants of even vertical frequency)
+    // or the difference M (u >= 4: odd; its quad holds the folded rows 3..0, so the second stage's constants are
+    // reversed there). A batch = 8 candidates; a lane holds 2 quadrants x 4 vertical indices = 8 coefficients, so a
+    // statistic is 8 registers (with a whole patch per quad - 16 candidates per batch, 16 registers per statistic -
+    // the kernel spilled 27-65 registers and was slower: profiles/README.md round 5), both images' rows of the next
+    // batch are requested a whole batch ahead, and the reduction over the 8 candidates' lanes is a reduce-scatter:
+    // one row-swap level per register pair for lane bits 5 and 4, a rotation for bit 3 - 15 operations per
+    // statistic, every lane ends up with the total of the ONE coefficient it owns.
     auto pass_a = [&](auto mode_tag) {
       constexpr int MODE = decltype(mode_tag)::value;
       constexpr bool HP = MODE != 0;
@@ -782,7 +783,10 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       const int nb = (k + 7) >> 3;
       if (nb == 0) return;
       const int hh = (lane >> 2) & 1, hp = lane >> 3;
-      const uint32_t rowh = (uint32_t)((lane & 7) * g.w);
+      const bool odd = (lane & 1) != 0;
+      // byte offsets of the two loads inside the candidate's patch (see row_read)
+      const uint32_t rowx = (uint32_t)(((lane & 6) * g.w + (odd ? 4 : 0)) * 4);
+      const uint32_t rowy = (uint32_t)((((lane & 6) + 1) * g.w + (odd ? 0 : 4)) * 4);
       const float sgn = hh ? -1.f : 1.f;
       float sEh[4];
 #pragma unroll
@@ -812,20 +816,36 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
         }
         ++rows_seen;
 #endif
+        // lanes 2 m and 2 m + 1 own rows 2 m and 2 m + 1 of their candidate; each of the two loads takes ONE of those
+        // rows, a half per lane, so that the two lanes read one cache line (the vector L1 takes a quad of lanes per
+        // cycle and per line it touches: a row per lane - four lines per quad - cost twice the cycles of the
+        // transforms themselves, profiles/README.md round 6): the first load row 2 m (even lane: columns 0..3, odd
+        // lane: 4..7), the second row 2 m + 1 (even lane: 4..7, odd lane: 0..3). A lane then holds the LEFT half of
+        // its own row - in R[0..3] (even) or R[4..7] (odd) - and its neighbour's right half; fold_half trades.
         typedef const __attribute__((address_space(1))) nlk_f4u* gp4;
         const char* bp = reinterpret_cast<const char*>(pbase);
-        const uint32_t o = (off + (uint32_t)cc * (uint32_t)npix + rowh) * 4u;
-        const nlk_f4u a0 = *(gp4)(bp + (size_t)o), a1 = *(gp4)(bp + (size_t)o + 16);
+        const uint32_t o = (off + (uint32_t)cc * (uint32_t)npix) * 4u;
+        const nlk_f4u a0 = *(gp4)(bp + (size_t)(o + rowx)), a1 = *(gp4)(bp + (size_t)(o + rowy));
 #pragma unroll
         for (int c = 0; c < 4; ++c) { R[c] = a0[c]; R[4 + c] = a1[c]; }
       };
-      // the row and its mirror row (lane u ^ 7 of the group of eight) -> P or M -> F[qc][s]
+      // A lane's row: left half Z from its own loads, right half from the neighbour lane (quad_perm [1, 0, 3, 2],
+      // fused into the horizontal fold H = left[c] +- right[3 - c]); then the mirror row 7 - u from lane u ^ 7 of the
+      // group of eight (row_half_mirror, fused into the vertical fold) -> P or M -> F[qc][s]
       auto fold_half = [&](const float (&R)[8], float (&F)[2][4]) {
-        float PM[8];
+        float Z[4], S[4];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) PM[c] = fmaf(sgn, R[c], nlk_dpp<NLK_DPP_HMIRROR>(R[c]));  // top + bottom | top - bottom
+        for (int c = 0; c < 4; ++c) {
+          Z[c] = odd ? R[4 + c] : R[c];  // left half of the own row
+          S[c] = odd ? R[c] : R[4 + c];  // what the neighbour needs: the right half of ITS row
+        }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { F[0][c] = PM[c] + PM[7 - c]; F[1][c] = PM[c] - PM[7 - c]; }
+        for (int c = 0; c < 4; ++c) {
+          const float rt = nlk_dpp<NLK_DPP_XOR1>(S[3 - c]);  // own row, column 7 - c
+          const float h0 = Z[c] + rt, h1 = Z[c] - rt;
+          F[0][c] = fmaf(sgn, h0, nlk_dpp<NLK_DPP_HMIRROR>(h0));  // top + bottom | top - bottom
+          F[1][c] = fmaf(sgn, h1, nlk_dpp<NLK_DPP_HMIRROR>(h1));
+        }
       };
       auto fwd_half = [&](const float (&F)[2][4], nlk_f4 (&Y)[2]) {
         nlk_f4 T[2] = {nlk_f4{0.f, 0.f, 0.f, 0.f}, nlk_f4{0.f, 0.f, 0.f, 0.f}};

@@ -28,7 +28,14 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
   // Round 6: the smoother's pass B reads the difference image previous - image (k_layout) - one row set per member
   // instead of two - and with half the cache lines to fetch the separable pass B wins there too: SMO1 group at 1080p
   // RGB 1.287 ms (Kronecker, two row sets) -> 1.234 (Kronecker, difference image) -> 1.101 (separable pass B).
-  const int sep_default = g.ch == 1 ? (g.ntagg < 4 ? 0 : (g.smoother ? 2 : 6)) : (g.ntagg < 4 ? 0 : 2);
+  // Round 6, later: the separable pass A loads a row as two halves in two ADJACENT lanes (one cache line per pair
+  // in each load: k_group8m.h, row_read) and the vector L1, which had kept it behind the Kronecker form, stops being
+  // what it waits for. Group ms at 1080p, forms 0 / 2 / 6 (`r06_mode_times_1080p_by_sep.txt`, `..._gray_by_sep.txt`):
+  // RGB FLT1 temporal 0.804 / 0.698 / 0.662, FLT2 0.607 / 0.612 / 0.576, first frame 1.125 / 0.894 / 0.894, smoother
+  // 1.207 / 0.971 / 0.992; one channel FLT1 temporal 0.534 / 0.413 / 0.384, FLT2 0.316 / 0.344 / 0.304, first frame
+  // 0.532 / 0.403 / 0.394, smoother 0.850 / 0.563 / 0.526. So: one channel 6 everywhere; RGB 6 for the filter's temporal
+  // frames, the hybrid form for first frames and the smoother (Kronecker for those with fewer than 4 members).
+  const int sep_default = g.ch == 1 ? 6 : (!g.smoother && prev) ? 6 : (g.ntagg < 4 ? 0 : 2);
   int sep = mfma ? nlk_or(c->sw.group_sep, sep_default) : 0;
   if (sep != 0 && sep != 6) sep = 2;
   // (k_group8m addresses every patch as planes base + a 32-bit byte offset: the call's images must lie in the
@@ -114,7 +121,7 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
     tl.nmain = mfma ? nlk_g8m_grid(tl.ntx, tl.nty) : 0;
     const int rw_max = (tl.tgx - 1) * g.step + 2 * tl.wmax + g.psz;
     tl.rh_max = (tl.tgy - 1) * g.step + 2 * tl.wmax + g.psz;
-    if (mfma && sep == 2 && CH > 1) {
+    if (mfma && sep != 0 && CH > 1) {
       // Separable pass B (round 6). A tile update is a ds_read_b32 / ds_write_b32 of lane
       // (column g4 = lane >> 4, plane spl = (lane >> 2) & 3, row si = lane & 3): the LDS serves a 4-byte access in
       // two groups of 32 lanes, {0-31} and {32-63}, on 32 banks (MI355X_MICROARCH.md, LDS) - and a half wavefront

@@ -10,5 +10,6 @@
 // the kernel for (channels, smoother, DCT form) if this unit holds it, else nullptr
 const void* nlk_group8m_ilp_kernel(int ch, bool smoother, int sep) {
   if (ch == 3 && !smoother && sep == 2) return (const void*)k_group8m<3, false, 2, 1>;
+  if (ch == 3 && !smoother && sep == 6) return (const void*)k_group8m<3, false, 6, 1>;
   return nullptr;
 }
