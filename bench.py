@@ -164,7 +164,7 @@ def c5_roofline(c5, w, h, ch, psz, ngrid, ps):
     dur = tm["group_ms"] * 1e-3
     k = ps.npatches_t
     alg_bytes = 2 * w * h * ch * 4 + (ch + 1) * w * h * 4 + ngrid * k * 4
-    sep = os.environ.get("NLK_GROUP_SEP", "2")   # (tu_group8.hip: the separable pass B on the difference image)
+    sep = os.environ.get("NLK_GROUP_SEP", "6" if ch == 1 else "2")   # (tu_group8.hip: the separable pass B on the difference image)
     inst = f"k_group8m<{ch}, true, {sep}, 0>"
     traffic, traffic_note = measured_traffic("C5", inst)
     tfl = group_flops / dur / 1e12 if dur > 0 else 0.0
@@ -1075,10 +1075,11 @@ def main():
         tfl = alg_flops[dom] / world / dur / 1e12 if dur > 0 else 0.0
         kname = ("k_group8m" if psz == 8 and ch in (1, 3) else "k_groupp") if dom == "group" else "k_bm_topk"
         # the instantiation the timed (temporal) frames launch: what the PMC table is looked up by
-        # (k_group8m's third template argument: which pass runs the separable DCT form - tu_group8.hip; FLT1: 2, one channel: 6)
-        # (the fourth: 1 = the copy compiled under the max-ilp scheduler, tu_group8_ilp.hip - RGB FLT1 in form 2 only)
-        g8sep = os.environ.get("NLK_GROUP_SEP", "6" if ch == 1 else "2")
-        g8unit = 1 if ch == 3 and g8sep == "2" and os.environ.get("NLK_GROUP_ILP", "1") != "0" else 0
+        # (k_group8m's third template argument: which pass runs the separable DCT form - tu_group8.hip; the filter's
+        # temporal frames: 6, separable in both passes)
+        # (the fourth: 1 = the copy compiled under the max-ilp scheduler, tu_group8_ilp.hip - the RGB filter's two forms)
+        g8sep = os.environ.get("NLK_GROUP_SEP", "6")
+        g8unit = 1 if ch == 3 and g8sep in ("2", "6") and os.environ.get("NLK_GROUP_ILP", "1") != "0" else 0
         inst = ((f"k_group8m<{ch}, false, {g8sep}, {g8unit}>" if kname == "k_group8m" else f"k_groupp<{psz}, false>") if dom == "group"
                 else f"k_bm_topk<{psz}, {ch}, {((2 * p.search_sz_t + 1) ** 2 + 63) // 64}>")
         # HBM-side bytes per launch: PMC passes of the same sources (see measured_traffic)
