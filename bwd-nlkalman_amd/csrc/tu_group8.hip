@@ -17,8 +17,9 @@ int launch_group8_t(nlk_ctx* c, const NlkGeom& g, const float* img, const float*
   // register/DPP kernel (k_group8.h) for comparison
   const bool mfma = !nlk_set(c->sw.group_dpp);
   // the matrix-core kernel's DCTs: the Kronecker form on 16 x 16 products (rounds 2-4) or the separable form on
-  // 4 x 4 blocks (round 5), by pass - NLK_GROUP_SEP = 0: Kronecker in both passes, 2 (default): Kronecker statistics,
-  // separable filter / inverse / aggregate (pass B), 6: separable in both (measured slower: profiles/README.md)
+  // 4 x 4 blocks (round 5), by pass - NLK_GROUP_SEP = 0: Kronecker in both passes, 2: Kronecker statistics,
+  // separable filter / inverse / aggregate (pass B), 6: separable in both; the default by mode is worked out below.
+  // Round 5's measurements, when the separable pass A still loaded a cache line per lane:
   // Default by what was measured at 1080p RGB (profiles/r05_mode_times_1080p.txt, group kernel, Kronecker -> hybrid):
   // FLT1 temporal 0.796 -> 0.740 ms, FLT1 spatial 1.043 -> 0.978; FLT2 (one member per group) 0.612 -> 0.628 and the
   // smoother 1.281 -> 1.322 stay with the Kronecker form.
