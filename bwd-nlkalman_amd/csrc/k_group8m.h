@@ -790,7 +790,7 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
       const float sgn = hh ? -1.f : 1.f;
       float sEh[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sEh[i] = hh ? sE[1][3 - i] : sE[0][i];
+      for (int i = 0; i < 4; ++i) sEh[i] = hh ? -sE[1][3 - i] : sE[0][i];  // (minus: fold_half leaves -M in the odd quads)
       const uint32_t e_dead = o_first + e_img;
       auto slot_offs = [&](int bb, uint32_t& oi, uint32_t& op) {
         const int ci = 8 * bb + hp, cl = min(ci, k - 1);
@@ -842,10 +842,22 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const float rt = nlk_dpp<NLK_DPP_XOR1>(S[3 - c]);  // own row, column 7 - c
-          const float h0 = Z[c] + rt, h1 = Z[c] - rt;
-          F[0][c] = fmaf(sgn, h0, nlk_dpp<NLK_DPP_HMIRROR>(h0));  // top + bottom | top - bottom
-          F[1][c] = fmaf(sgn, h1, nlk_dpp<NLK_DPP_HMIRROR>(h1));
+          F[0][c] = Z[c] + rt;
+          F[1][c] = Z[c] - rt;
         }
+        // own + mirror (u < 4) | own - mirror (u >= 4: MINUS the difference top - bottom; the sign is in the second
+        // stage's constants sEh): F += sgn * F(lane u ^ 7), the mirror row as the DPP multiplicand of ONE v_fmac_f32
+        // each. (The compiler keeps a v_mov_b32_dpp + v_fmac_f32 pair per value - its DPP combiner does not fold into
+        // an accumulating operand -, 16 more vector instructions per batch; hence by hand. A DPP operand needs two
+        // wait states after the instruction that wrote it, which the compiler does not insert for inline assembly: the
+        // s_nop.)
+#define NLK_G8_FMAC_HM(i) "v_fmac_f32_dpp %" #i ", %" #i ", %8 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        asm("s_nop 1\n\t" NLK_G8_FMAC_HM(0) NLK_G8_FMAC_HM(1) NLK_G8_FMAC_HM(2) NLK_G8_FMAC_HM(3) NLK_G8_FMAC_HM(4)
+            NLK_G8_FMAC_HM(5) NLK_G8_FMAC_HM(6) NLK_G8_FMAC_HM(7)
+            : "+v"(F[0][0]), "+v"(F[0][1]), "+v"(F[0][2]), "+v"(F[0][3]), "+v"(F[1][0]), "+v"(F[1][1]), "+v"(F[1][2]),
+              "+v"(F[1][3])
+            : "v"(sgn));
+#undef NLK_G8_FMAC_HM
       };
       auto fwd_half = [&](const float (&F)[2][4], nlk_f4 (&Y)[2]) {
         nlk_f4 T[2] = {nlk_f4{0.f, 0.f, 0.f, 0.f}, nlk_f4{0.f, 0.f, 0.f, 0.f}};
@@ -943,10 +955,16 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 const float di = Yi[q][j], d = Yp[q][j];
-                S[0][q][j] += d;
-                S[1][q][j] = fmaf(d, d, S[1][q][j]);
                 const float df = di - d;  // reference: :769-783
-                S[2][q][j] = fmaf(df, df, S[2][q][j]);
+                if (b == 0) {  // (a channel's first batch assigns: these sums are not cleared per channel)
+                  S[0][q][j] = d;
+                  S[1][q][j] = d * d;
+                  S[2][q][j] = df * df;
+                } else {
+                  S[0][q][j] += d;
+                  S[1][q][j] = fmaf(d, d, S[1][q][j]);
+                  S[2][q][j] = fmaf(df, df, S[2][q][j]);
+                }
               }
             if (mixed) {
 #pragma unroll
@@ -1002,10 +1020,14 @@ k_group8m(const float* __restrict__ img,   // matching / statistics image (plana
             }
             const float send = hi8 ? W[0] : W[1], keep = hi8 ? W[1] : W[0];
             T[a] = keep + nlk_dpp<NLK_DPP_ROR8>(send);
+            // (the filter's three running sums are ASSIGNED by the next channel's first batch; the members' sum, which
+            // only the batches with a non-member add to, and the other modes' sums start from zero)
+            if (!(MODE == 1 && a < 3)) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+              for (int q = 0; q < 2; ++q)
 #pragma unroll
-              for (int j = 0; j < 4; ++j) S[a][q][j] = 0.f;
+                for (int j = 0; j < 4; ++j) S[a][q][j] = 0.f;
+            }
           }
           sep_gain(mode_tag, T, ch);
         }
