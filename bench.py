@@ -414,6 +414,21 @@ def bench_sequence(args, pkg, synth, ctx, torch, rank, world, dev):
                       "flow_iterations_last_frame": sf.flow_iterations[-1]},
            "psnr_flt2_db": round(float(synth.psnr(out, c1)), 4),
            "psnr_noisy_db": round(float(synth.psnr(n1, c1)), 4)}
+    if ns == 1:
+        # where a frame goes: a second, PROFILED pass of the same frames with a device sync after every stage
+        # (not part of `value`; the syncs cost the stages their overlap with the host's enqueueing)
+        nprof = min(args.steps, 20)
+        sf.stage_s = {}
+        run(sf, nprof, k)
+        res["stages_ms"] = {n_: round(v / nprof * 1e3, 4) for n_, v in sf.stage_s.items()}
+        res["stages_ms"]["note"] = ("profiled pass with a device sync after each stage: TV-L1 flow + occlusion mask | bicubic warp + "
+                                    "FLT1 | bicubic warp + FLT2 (basic = FLT1)")
+        sf.stage_s = None
+        # the roofline of the stage's dominant kernel is the F1 line's (`k_tv_block`, the same kernel on the same
+        # frame size; this workload starts the pyramid one level lower, fscale 1); the filter launches' are C2's / C5's
+        res["roofline"] = None
+        res["roofline_note"] = ("the frame is a chain of three stages, each with its own dominant kernel: the flow's k_tv_block "
+                                "(bench.py --workload F1 carries its roofline), FLT1's and FLT2's k_group8m (--workload C2 / C5)")
     emit(res)
 
 

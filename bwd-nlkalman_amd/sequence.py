@@ -56,6 +56,7 @@ class SequenceFilter:
         self._pool = []                      # released frame buffers (no hipMalloc / hipFree per frame)
         self.t = 0
         self.flow_iterations = []
+        self.stage_s = None   # set to {} to have push() synchronise after each stage and add up its wall times (bench.py S1)
 
     def _flow_and_mask(self, d_from_rgb, d_to_opp):
         """flow from frame `d_from_rgb` (RGB) to the frame whose opponent image is `d_to_opp`."""
@@ -78,11 +79,16 @@ class SequenceFilter:
             c.filter_frame(n1, self.d_noisy, None, None, w, h, ch, sg, self.f1)
             c.filter_frame(n2, self.d_noisy, None, n1, w, h, ch, sg, self.f2)
         else:
+            mark = self._stage_mark
+            mark(None)
             self._flow_and_mask(d_noisy_rgb, self.flt2)
+            mark("flow_and_mask")
             c.warp_bicubic(self.d_warp, self.flt1, self.d_flow, self.d_occ, w, h, ch)
             c.filter_frame(n1, self.d_noisy, self.d_warp, None, w, h, ch, sg, self.f1)
+            mark("warp_flt1")
             c.warp_bicubic(self.d_warp, self.flt2, self.d_flow, self.d_occ, w, h, ch)
             c.filter_frame(n2, self.d_noisy, self.d_warp, n1, w, h, ch, sg, self.f2)
+            mark("warp_flt2")
         if self.flt1:
             self._pool.append(self.flt1)
         if self.flt2 and self.history is None:
@@ -94,6 +100,17 @@ class SequenceFilter:
 
     def _frame(self):
         return self._pool.pop() if self._pool else self.ctx.alloc(self.nbytes)
+
+    def _stage_mark(self, name):
+        """(profiling only: self.stage_s is a dict) wall time since the last mark, after a device sync, added to `name`"""
+        if self.stage_s is None:
+            return
+        import time
+        self.ctx.sync()
+        now = time.perf_counter()
+        if name is not None:
+            self.stage_s[name] = self.stage_s.get(name, 0.0) + now - self._stage_t
+        self._stage_t = now
 
     def smooth(self, of_lambda=None, of_fscale=None, occ_th=None):
         """Backward pass over the kept flt2 frames; returns the list of smoothed frames
